@@ -1,0 +1,386 @@
+// Scene compiler: the host step that defines what the kernels read.
+// Mirrors `Scene::compile` (reference src/main.rs:173-357) with an own
+// binned-SAH builder in place of the un-vendored `bvh` 0.3.1 crate.
+#include "scene.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <stdexcept>
+
+namespace hijiki {
+
+// ---------------------------------------------------------------- Aabb
+
+Aabb Aabb::empty() {
+  Aabb b;
+  for (int i = 0; i < 3; i++) {
+    b.lo[i] = std::numeric_limits<float>::infinity();
+    b.hi[i] = -std::numeric_limits<float>::infinity();
+  }
+  return b;
+}
+void Aabb::grow(const float p[3]) {
+  for (int i = 0; i < 3; i++) {
+    lo[i] = std::min(lo[i], p[i]);
+    hi[i] = std::max(hi[i], p[i]);
+  }
+}
+void Aabb::join(const Aabb& o) {
+  for (int i = 0; i < 3; i++) {
+    lo[i] = std::min(lo[i], o.lo[i]);
+    hi[i] = std::max(hi[i], o.hi[i]);
+  }
+}
+float Aabb::half_area() const {
+  float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+  if (dx < 0 || dy < 0 || dz < 0) return 0.f;
+  return dx * dy + dy * dz + dz * dx;
+}
+
+// Shape bounds: sphere centre +- r (src/shape.rs:13-20), quad = 4 corners
+// (src/shape.rs:46-54), triangle = 3 vertices (src/main.rs:74-79).
+Aabb Scene::shape_aabb(const Shape& s) const {
+  Aabb b = Aabb::empty();
+  switch (s.kind) {
+    case ShapeKind::Sphere: {
+      float lo[3], hi[3];
+      for (int i = 0; i < 3; i++) {
+        lo[i] = s.sphere.center[i] - s.sphere.radius;
+        hi[i] = s.sphere.center[i] + s.sphere.radius;
+      }
+      b.grow(lo);
+      b.grow(hi);
+      break;
+    }
+    case ShapeKind::Quad: {
+      float p[3];
+      b.grow(s.quad.origin);
+      for (int i = 0; i < 3; i++) p[i] = s.quad.origin[i] + s.quad.edge1[i];
+      b.grow(p);
+      for (int i = 0; i < 3; i++) p[i] = s.quad.origin[i] + s.quad.edge2[i];
+      b.grow(p);
+      for (int i = 0; i < 3; i++) p[i] = (s.quad.origin[i] + s.quad.edge1[i]) + s.quad.edge2[i];
+      b.grow(p);
+      break;
+    }
+    case ShapeKind::Triangle:
+      for (int k = 0; k < 3; k++) b.grow(vertices[s.tri.v[k]].pos);
+      break;
+  }
+  return b;
+}
+
+// ---------------------------------------------------------------- BVH build
+
+namespace {
+
+constexpr int kBins = 16;
+
+struct Builder {
+  const std::vector<Aabb>& boxes;
+  std::vector<float> cx, cy, cz;  // centroids
+  std::vector<uint32_t> order;    // shape permutation being partitioned
+  std::vector<BuildNode> nodes;
+
+  explicit Builder(const std::vector<Aabb>& b) : boxes(b) {
+    size_t n = b.size();
+    cx.resize(n), cy.resize(n), cz.resize(n), order.resize(n);
+    for (size_t i = 0; i < n; i++) {
+      cx[i] = 0.5f * (b[i].lo[0] + b[i].hi[0]);
+      cy[i] = 0.5f * (b[i].lo[1] + b[i].hi[1]);
+      cz[i] = 0.5f * (b[i].lo[2] + b[i].hi[2]);
+    }
+    std::iota(order.begin(), order.end(), 0u);
+    nodes.reserve(2 * n);
+  }
+
+  float centroid(uint32_t s, int axis) const { return axis == 0 ? cx[s] : axis == 1 ? cy[s] : cz[s]; }
+
+  Aabb bounds(size_t lo, size_t hi) const {
+    Aabb b = Aabb::empty();
+    for (size_t i = lo; i < hi; i++) b.join(boxes[order[i]]);
+    return b;
+  }
+
+  // Returns node index.  Recursive; degenerate inputs (all centroids equal)
+  // fall back to median splits, so the depth stays O(log n) there.
+  int32_t build(size_t lo, size_t hi) {
+    int32_t me = (int32_t)nodes.size();
+    nodes.emplace_back();
+    if (hi - lo == 1) {
+      nodes[me].shape = (int32_t)order[lo];
+      return me;
+    }
+    // centroid bounds -> split axis
+    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = lo; i < hi; i++) {
+      uint32_t s = order[i];
+      float c[3] = {cx[s], cy[s], cz[s]};
+      for (int a = 0; a < 3; a++) {
+        cmin[a] = std::min(cmin[a], c[a]);
+        cmax[a] = std::max(cmax[a], c[a]);
+      }
+    }
+    int axis = 0;
+    float ext = cmax[0] - cmin[0];
+    for (int a = 1; a < 3; a++)
+      if (cmax[a] - cmin[a] > ext) ext = cmax[a] - cmin[a], axis = a;
+
+    size_t mid = lo + (hi - lo) / 2;
+    bool have_split = false;
+    if (ext > 1e-7f && hi - lo > 2) {
+      // binned SAH along `axis`
+      Aabb bin_box[kBins];
+      size_t bin_cnt[kBins] = {};
+      for (auto& b : bin_box) b = Aabb::empty();
+      float scale = (float)kBins / ext;
+      auto bin_of = [&](uint32_t s) {
+        int b = (int)((centroid(s, axis) - cmin[axis]) * scale);
+        return std::min(std::max(b, 0), kBins - 1);
+      };
+      for (size_t i = lo; i < hi; i++) {
+        int b = bin_of(order[i]);
+        bin_cnt[b]++;
+        bin_box[b].join(boxes[order[i]]);
+      }
+      float right_area[kBins];
+      size_t right_cnt[kBins];
+      Aabb acc = Aabb::empty();
+      size_t cnt = 0;
+      for (int b = kBins - 1; b > 0; b--) {
+        acc.join(bin_box[b]);
+        cnt += bin_cnt[b];
+        right_area[b] = acc.half_area();
+        right_cnt[b] = cnt;
+      }
+      acc = Aabb::empty();
+      cnt = 0;
+      float best = INFINITY;
+      int best_split = -1;
+      for (int b = 0; b < kBins - 1; b++) {
+        acc.join(bin_box[b]);
+        cnt += bin_cnt[b];
+        if (cnt == 0 || right_cnt[b + 1] == 0) continue;
+        float cost = acc.half_area() * (float)cnt + right_area[b + 1] * (float)right_cnt[b + 1];
+        if (cost < best) best = cost, best_split = b;
+      }
+      if (best_split >= 0) {
+        auto it = std::stable_partition(order.begin() + lo, order.begin() + hi,
+                                        [&](uint32_t s) { return bin_of(s) <= best_split; });
+        mid = (size_t)(it - order.begin());
+        have_split = mid > lo && mid < hi;
+      }
+    }
+    if (!have_split) {
+      // median split along the axis (stable for equal keys)
+      mid = lo + (hi - lo) / 2;
+      std::stable_sort(order.begin() + lo, order.begin() + hi,
+                       [&](uint32_t a, uint32_t b) { return centroid(a, axis) < centroid(b, axis); });
+    }
+    Aabb lb = bounds(lo, mid), rb = bounds(mid, hi);
+    int32_t l = build(lo, mid);
+    int32_t r = build(mid, hi);
+    nodes[me].left = l;
+    nodes[me].right = r;
+    nodes[me].left_box = lb;
+    nodes[me].right_box = rb;
+    return me;
+  }
+};
+
+}  // namespace
+
+std::vector<BuildNode> build_bvh(const std::vector<Aabb>& boxes) {
+  if (boxes.empty()) return {};
+  Builder b(boxes);
+  b.build(0, boxes.size());
+  return std::move(b.nodes);
+}
+
+// ---------------------------------------------------------------- compile
+
+CompiledScene compile(const Scene& scene) {
+  CompiledScene out;
+  out.camera = scene.camera;
+  out.vertices = scene.vertices;
+
+  const size_t n = scene.objects.size();
+  if (n < 2)
+    throw std::runtime_error("scene needs at least 2 shapes (reference panics: root would be a leaf, src/main.rs:230)");
+
+  // per-kind lists + index of each object inside its list (src/main.rs:180-196)
+  std::vector<uint32_t> index_in_kind(n);
+  std::vector<int> sphere_mat, quad_mat, tri_mat;
+  std::vector<Aabb> boxes(n);
+  for (size_t i = 0; i < n; i++) {
+    const Shape& s = scene.objects[i].first;
+    int mat = scene.objects[i].second;
+    if (mat < 0 || (size_t)mat >= scene.materials.size()) throw std::runtime_error("shape refers to unknown material");
+    switch (s.kind) {
+      case ShapeKind::Sphere:
+        index_in_kind[i] = (uint32_t)out.spheres.size();
+        out.spheres.push_back(s.sphere);
+        sphere_mat.push_back(mat);
+        break;
+      case ShapeKind::Quad:
+        index_in_kind[i] = (uint32_t)out.quads.size();
+        out.quads.push_back(s.quad);
+        quad_mat.push_back(mat);
+        break;
+      case ShapeKind::Triangle:
+        for (int k = 0; k < 3; k++)
+          if (s.tri.v[k] >= scene.vertices.size()) throw std::runtime_error("triangle refers to unknown vertex");
+        index_in_kind[i] = (uint32_t)out.triangles.size();
+        out.triangles.push_back(s.tri);
+        tri_mat.push_back(mat);
+        break;
+    }
+    boxes[i] = scene.shape_aabb(s);
+  }
+
+  // BVH::build (src/main.rs:199) -> depth-first flatten with skip links (src/main.rs:203-231)
+  std::vector<BuildNode> tree = build_bvh(boxes);
+  const uint32_t ns = (uint32_t)out.spheres.size(), nq = (uint32_t)out.quads.size();
+  auto global_index = [&](int32_t obj) -> uint32_t {  // src/main.rs:232-243
+    switch (scene.objects[obj].first.kind) {
+      case ShapeKind::Sphere: return index_in_kind[obj];
+      case ShapeKind::Quad: return ns + index_in_kind[obj];
+      default: return ns + nq + index_in_kind[obj];
+    }
+  };
+  // pass 1: pre-order numbering, left before right (src/main.rs:203-213)
+  std::vector<uint32_t> slot(tree.size(), 0);
+  {
+    std::vector<int32_t> st{0};
+    uint32_t next = 0;
+    while (!st.empty()) {
+      int32_t nd = st.back();
+      st.pop_back();
+      slot[nd] = next++;
+      if (tree[nd].shape < 0) {
+        st.push_back(tree[nd].right);
+        st.push_back(tree[nd].left);
+      }
+    }
+  }
+  // pass 2: every node stores the box its PARENT kept for it; exit of a left
+  // child = its right sibling, of a right child = the parent's exit, of the
+  // root = 1 000 000 (src/main.rs:214-231).
+  out.bvh.resize(tree.size());
+  {
+    struct Work { int32_t node; Aabb box; uint32_t exit; };
+    Aabb root_box = tree[0].left_box;
+    root_box.join(tree[0].right_box);  // src/main.rs:230
+    std::vector<Work> st;
+    st.push_back({0, root_box, HJ_BVH_ROOT_EXIT});
+    while (!st.empty()) {
+      Work w = st.back();
+      st.pop_back();
+      const BuildNode& bn = tree[w.node];
+      hj_bvh_node& nd = out.bvh[slot[w.node]];
+      std::memcpy(nd.aabb_min, w.box.lo, 12);
+      std::memcpy(nd.aabb_max, w.box.hi, 12);
+      nd.shape_index = bn.shape >= 0 ? global_index(bn.shape) : HJ_BVH_INNER;
+      nd.exit_index = w.exit;
+      if (bn.shape < 0) {
+        st.push_back({bn.right, bn.right_box, w.exit});
+        st.push_back({bn.left, bn.left_box, slot[bn.right]});
+      }
+    }
+  }
+
+  // material words (src/main.rs:246-287)
+  std::vector<uint32_t> reprs;
+  for (const Material& m : scene.materials) {
+    uint32_t ix = 0;
+    switch (m.tag) {
+      case HJ_MAT_DIFFUSE: out.diffuse.push_back(m.diffuse); ix = (uint32_t)out.diffuse.size() - 1; break;
+      case HJ_MAT_DIFFUSECBOARD: out.diffusecb.push_back(m.cboard); ix = (uint32_t)out.diffusecb.size() - 1; break;
+      case HJ_MAT_MIRROR: ix = 0; break;
+      case HJ_MAT_DIELECTRIC: out.dielectric.push_back(m.dielectric); ix = (uint32_t)out.dielectric.size() - 1; break;
+      case HJ_MAT_EMISSIVE: out.emissive.push_back(m.emissive); ix = (uint32_t)out.emissive.size() - 1; break;
+    }
+    reprs.push_back(((uint32_t)m.tag << HJ_MATERIAL_TAG_SHIFT) + ix);
+  }
+  for (int m : sphere_mat) out.materials.push_back(reprs[m]);
+  for (int m : quad_mat) out.materials.push_back(reprs[m]);
+  for (int m : tri_mat) out.materials.push_back(reprs[m]);
+
+  // uniform emitter table (src/main.rs:289-307)
+  for (size_t ix = 0; ix < out.materials.size(); ix++)
+    if ((out.materials[ix] >> HJ_MATERIAL_TAG_SHIFT) == (uint32_t)HJ_MAT_EMISSIVE)
+      out.emitters.push_back(hj_emitter{(uint32_t)ix, 0.f, 0.f, 0.f});
+  float pdf = 1.0f / (float)out.emitters.size();
+  float cdf = 0.f;
+  for (auto& e : out.emitters) {
+    cdf += pdf;
+    e.pdf = pdf;
+    e.cdf = cdf;
+  }
+  return out;
+}
+
+hj_scene_desc CompiledScene::desc() const {
+  hj_scene_desc d{};
+  d.camera = camera;
+  d.bvh = bvh.data(); d.num_bvh_nodes = bvh.size();
+  d.spheres = spheres.data(); d.num_spheres = spheres.size();
+  d.quads = quads.data(); d.num_quads = quads.size();
+  d.triangles = triangles.data(); d.num_triangles = triangles.size();
+  d.vertices = vertices.data(); d.num_vertices = vertices.size();
+  d.materials = materials.data(); d.num_materials = materials.size();
+  d.emitters = emitters.data(); d.num_emitters = emitters.size();
+  d.diffuse = diffuse.data(); d.num_diffuse = diffuse.size();
+  d.diffusecb = diffusecb.data(); d.num_diffusecb = diffusecb.size();
+  d.dielectric = dielectric.data(); d.num_dielectric = dielectric.size();
+  d.emissive = emissive.data(); d.num_emissive = emissive.size();
+  return d;
+}
+
+namespace {
+constexpr size_t kAlign = 256;  // BUFFER_ALIGNMENT, src/main.rs:411
+size_t padded(size_t bytes) { return (bytes + kAlign - 1) & ~(kAlign - 1); }
+}  // namespace
+
+size_t CompiledScene::packed_size() const {
+  return padded(sizeof(hj_scene_info)) + padded(bvh.size() * sizeof(hj_bvh_node)) +
+         padded(spheres.size() * sizeof(hj_sphere)) + padded(quads.size() * sizeof(hj_quad)) +
+         padded(triangles.size() * sizeof(hj_triangle)) + padded(vertices.size() * sizeof(hj_vertex)) +
+         padded(materials.size() * 4) + padded(emitters.size() * sizeof(hj_emitter)) +
+         padded(diffuse.size() * sizeof(hj_diffuse)) + padded(diffusecb.size() * sizeof(hj_diffuse_cb)) +
+         padded(dielectric.size() * sizeof(hj_dielectric)) + padded(emissive.size() * sizeof(hj_emissive));
+}
+
+bool CompiledScene::pack(void* buffer, size_t size) const {
+  if (size != packed_size()) return false;
+  std::memset(buffer, 0, size);
+  uint8_t* p = static_cast<uint8_t*>(buffer);
+  auto put = [&](const void* src, size_t bytes) {
+    if (bytes) std::memcpy(p, src, bytes);
+    p += padded(bytes);
+  };
+  hj_scene_info info{};
+  info.camera = camera;
+  info.num_spheres = (uint32_t)spheres.size();
+  info.num_quads = (uint32_t)quads.size();
+  info.num_triangles = (uint32_t)triangles.size();
+  info.num_emitters = (uint32_t)emitters.size();
+  put(&info, sizeof info);
+  put(bvh.data(), bvh.size() * sizeof(hj_bvh_node));
+  put(spheres.data(), spheres.size() * sizeof(hj_sphere));
+  put(quads.data(), quads.size() * sizeof(hj_quad));
+  put(triangles.data(), triangles.size() * sizeof(hj_triangle));
+  put(vertices.data(), vertices.size() * sizeof(hj_vertex));
+  put(materials.data(), materials.size() * 4);
+  put(emitters.data(), emitters.size() * sizeof(hj_emitter));
+  put(diffuse.data(), diffuse.size() * sizeof(hj_diffuse));
+  put(diffusecb.data(), diffusecb.size() * sizeof(hj_diffuse_cb));
+  put(dielectric.data(), dielectric.size() * sizeof(hj_dielectric));
+  put(emissive.data(), emissive.size() * sizeof(hj_emissive));
+  return p == static_cast<uint8_t*>(buffer) + size;
+}
+
+}  // namespace hijiki

@@ -1,0 +1,84 @@
+// Host-side scene model: mirror of Hijiki's `Scene`, `Shape`, `Material`
+// (reference src/main.rs:34-170) and of `CompiledScene` (src/main.rs:376-397).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../../include/hijiki_hip.h"
+
+namespace hijiki {
+
+// `enum Material` (src/main.rs:38-44); the payloads are the device records.
+struct Material {
+  hj_material_tag tag;
+  hj_diffuse diffuse{};
+  hj_diffuse_cb cboard{};
+  hj_dielectric dielectric{};
+  hj_emissive emissive{};
+};
+
+// `enum Shape` (src/main.rs:47-52).
+enum class ShapeKind : uint8_t { Sphere, Quad, Triangle };
+struct Shape {
+  ShapeKind kind;
+  hj_sphere sphere{};
+  hj_quad quad{};
+  hj_triangle tri{};
+};
+
+struct Aabb {
+  float lo[3], hi[3];
+  static Aabb empty();
+  void grow(const float p[3]);
+  void join(const Aabb& o);
+  float half_area() const;
+};
+
+// `struct Scene` (src/main.rs:162-170).
+struct Scene {
+  hj_camera camera{};
+  std::vector<std::pair<Shape, int>> objects;  // (shape, material index)
+  std::vector<hj_vertex> vertices;
+  std::vector<Material> materials;
+
+  Aabb shape_aabb(const Shape& s) const;  // src/main.rs:69-82, src/shape.rs:13-20,46-54
+};
+
+// `struct CompiledScene` (src/main.rs:376-397).
+struct CompiledScene {
+  hj_camera camera{};
+  std::vector<hj_bvh_node> bvh;
+  std::vector<hj_sphere> spheres;
+  std::vector<hj_quad> quads;
+  std::vector<hj_triangle> triangles;
+  std::vector<hj_vertex> vertices;
+  std::vector<uint32_t> materials;
+  std::vector<hj_emitter> emitters;
+  std::vector<hj_diffuse> diffuse;
+  std::vector<hj_diffuse_cb> diffusecb;
+  std::vector<hj_dielectric> dielectric;
+  std::vector<hj_emissive> emissive;
+
+  hj_scene_desc desc() const;
+  size_t packed_size() const;                        // src/main.rs:314-339
+  bool pack(void* buffer, size_t size) const;        // src/main.rs:561-605
+};
+
+// `Scene::compile` (src/main.rs:173-357).  Throws std::runtime_error.
+CompiledScene compile(const Scene& scene);
+
+// Binary BVH with one shape per leaf, as the `bvh` crate hands it to the
+// flattening step (src/main.rs:199-231).
+struct BuildNode {
+  int32_t left = -1, right = -1;  // children (inner) ...
+  int32_t shape = -1;             // ... or the shape (leaf)
+  Aabb left_box, right_box;       // child_l_aabb / child_r_aabb
+};
+std::vector<BuildNode> build_bvh(const std::vector<Aabb>& boxes);  // node 0 is the root
+
+// Synthetic bench scenes.
+Scene make_synthetic(int kind, uint32_t mesh_triangles, uint32_t gen_seed);
+
+}  // namespace hijiki

@@ -1,0 +1,246 @@
+/*
+ * hijiki_hip.h — the drop-in boundary of the MI355X path-tracing hot path.
+ *
+ * Plain C ABI: POD structs, pointers and sizes only.  Every record below is
+ * byte-for-byte the record the reference host (`/root/reference/src/main.rs`)
+ * writes into its scene buffer and that the reference shaders read; every
+ * entry point replaces one piece of the reference's host<->shader contract
+ * (there is no plugin interface in the reference — the boundary is what
+ * `Renderer::new/render/save_image` hand to wgpu).  A Rust host would bind to
+ * this header with an `extern "C"` block.
+ *
+ * Citations `file:line` are relative to the reference checkout.
+ */
+#ifndef HIJIKI_HIP_H
+#define HIJIKI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* libraries are built with -fvisibility=hidden */
+#endif
+
+/* ------------------------------------------------------------------ status */
+
+enum hj_status {
+  HJ_OK = 0,
+  HJ_ERR_INVALID = 1,     /* bad argument / inconsistent scene (reference: assert!/panic!) */
+  HJ_ERR_DEVICE = 2,      /* HIP runtime error                                              */
+  HJ_ERR_NOMEM = 3,       /* host or device allocation failed                               */
+  HJ_ERR_STATE = 4,       /* call order violated (e.g. render before scene upload)          */
+  HJ_ERR_UNSUPPORTED = 5  /* reference behaviour that is undefined / a panic upstream       */
+};
+
+/* ------------------------------------------------------- material tag words */
+
+/* MaterialType discriminants, src/main.rs:34-45; shader macros MATERIAL_TAG_*
+ * injected at src/main.rs:778-783.  A material word is (tag << 24) + index
+ * (src/main.rs:275; decoded at shader/render.glsl:107-109). */
+enum hj_material_tag {
+  HJ_MAT_DIFFUSE = 0,
+  HJ_MAT_DIFFUSECBOARD = 1,
+  HJ_MAT_MIRROR = 2,
+  HJ_MAT_DIELECTRIC = 3,
+  HJ_MAT_EMISSIVE = 4
+};
+#define HJ_MATERIAL_TAG_SHIFT 24u
+#define HJ_MATERIAL_INDEX_MASK 0x00FFFFFFu
+#define HJ_BVH_INNER 0xFFFFFFFFu     /* shape_index of an inner node, src/main.rs:219 */
+#define HJ_BVH_ROOT_EXIT 1000000u    /* exit index of the root,       src/main.rs:231 */
+#define HJ_BLOCK_SIZE 128u           /* src/main.rs:1485 */
+
+/* ------------------------------------------------- device records (std430) */
+
+/* Camera, src/main.rs:154-160 / shader/render.glsl:12-16.  48 bytes. */
+typedef struct hj_camera {
+  float position[4];   /* xyz used, w = 0                                  */
+  float rotation[4];   /* unit quaternion xyzw                             */
+  float fov;           /* HORIZONTAL field of view in degrees              */
+  float _pad[3];
+} hj_camera;
+
+/* SceneBufferInfo, src/main.rs:400-408 / shader/scene.glsl:1-8.  64 bytes. */
+typedef struct hj_scene_info {
+  hj_camera camera;
+  uint32_t num_spheres, num_quads, num_triangles, num_emitters;
+} hj_scene_info;
+
+/* CompiledBVHNode, src/main.rs:92-99 / shader/scene.glsl:10-13.  32 bytes.
+ * Pre-order skip-link array; see hj_host.h for the builder. */
+typedef struct hj_bvh_node {
+  float aabb_min[3];
+  uint32_t shape_index;  /* global shape index of a leaf, HJ_BVH_INNER otherwise */
+  float aabb_max[3];
+  uint32_t exit_index;   /* node to visit when this subtree is skipped / done   */
+} hj_bvh_node;
+
+/* Sphere, src/shape.rs:6-11 / shader/shapes/sphere.glsl:1-3.  16 bytes. */
+typedef struct hj_sphere { float center[3]; float radius; } hj_sphere;
+
+/* Quad, src/shape.rs:22-31 / shader/shapes/quad.glsl:1-5.  48 bytes. */
+typedef struct hj_quad {
+  float origin[3]; float _pad1;
+  float edge1[3];  float _pad2;
+  float edge2[3];  float _pad3;
+} hj_quad;
+
+/* Triangle = 3 indices into the global vertex array, src/main.rs:51,386. */
+typedef struct hj_triangle { uint32_t v[3]; } hj_triangle;
+
+/* Vertex, src/main.rs:54-60 / shader/shapes/triangle.glsl:1-4.  32 bytes. */
+typedef struct hj_vertex { float pos[3]; float u; float normal[3]; float v; } hj_vertex;
+
+/* Emitter, src/main.rs:368-374 / shader/scene.glsl:33-38.  16 bytes. */
+typedef struct hj_emitter { uint32_t shape; float pdf; float cdf; float _pad; } hj_emitter;
+
+/* Material records, src/main.rs:102-146 / shader/materials/{diffuse,diffusecb,dielectric,emissive}.glsl. */
+typedef struct hj_diffuse    { float color[3]; float _pad; } hj_diffuse;
+typedef struct hj_diffuse_cb { float color_a[3]; float scale_u; float color_b[3]; float scale_v; } hj_diffuse_cb;
+typedef struct hj_dielectric { float extinction[3]; float eta; } hj_dielectric;
+typedef struct hj_emissive   { float power[3]; float _pad; } hj_emissive;
+
+/* ImageBlock, src/main.rs:608-617 / shader/block.glsl:1-8.  40 bytes.
+ * One per integrator+reconstruction dispatch pair in the reference
+ * (src/main.rs:1322-1330). */
+typedef struct hj_image_block {
+  uint32_t id;
+  uint32_t seed;
+  uint32_t origin[2];
+  uint32_t dimension[2];
+  uint32_t original_dimension[2];
+  float sample_offset[2];
+} hj_image_block;
+
+/* ------------------------------------------------------------ scene upload */
+
+/* What CompiledScene::write_to_buffer (src/main.rs:561-605) packs into the
+ * scene buffer, as 11 borrowed (pointer,count) arrays + the camera, in the
+ * reference's sub-buffer order.  Global shape index space is
+ * [spheres | quads | triangles]; `materials` has one word per shape in that
+ * order (src/main.rs:278-287).  Arrays are borrowed for the duration of the
+ * call only. */
+typedef struct hj_scene_desc {
+  hj_camera camera;
+  const hj_bvh_node*   bvh;        size_t num_bvh_nodes;
+  const hj_sphere*     spheres;    size_t num_spheres;
+  const hj_quad*       quads;      size_t num_quads;
+  const hj_triangle*   triangles;  size_t num_triangles;
+  const hj_vertex*     vertices;   size_t num_vertices;
+  const uint32_t*      materials;  size_t num_materials;   /* == number of shapes */
+  const hj_emitter*    emitters;   size_t num_emitters;
+  const hj_diffuse*    diffuse;    size_t num_diffuse;
+  const hj_diffuse_cb* diffusecb;  size_t num_diffusecb;
+  const hj_dielectric* dielectric; size_t num_dielectric;
+  const hj_emissive*   emissive;   size_t num_emissive;
+} hj_scene_desc;
+
+/* Compile-time shader parameters of the reference, as run-time options:
+ * USE_BVH (src/main.rs:769-777), RECONSTRUCTION_RADIUS / _STDDEV
+ * (src/main.rs:916-921,1279-1286), the 1000-bounce cap and the `bounce > 3`
+ * roulette start (shader/render.glsl:92,137). */
+typedef struct hj_render_opts {
+  uint32_t use_bvh;        /* 1 = skip-link BVH walk, 0 = linear scan (reference CLI default) */
+  uint32_t recon_radius;   /* only 2 is supported (reference value)                           */
+  float    recon_stddev;   /* 0.5 in the reference                                            */
+  uint32_t max_bounces;    /* 1000                                                            */
+  uint32_t rr_start;       /* roulette applies when bounce > rr_start - 1, i.e. 4 -> b > 3    */
+  uint32_t batch_blocks;   /* blocks traced per wavefront batch; 0 = library default          */
+  uint32_t _reserved[2];
+} hj_render_opts;
+
+/* Per-render statistics (device counters; all in units of events). */
+typedef struct hj_render_stats {
+  uint64_t paths;            /* camera paths started (= sum of block areas)         */
+  uint64_t closest_rays;     /* intersectScene(ray, its) calls                      */
+  uint64_t shadow_rays;      /* intersectScene(ray) calls                           */
+  uint64_t batches;          /* wavefront batches launched                          */
+  uint64_t bounce_rounds;    /* per-bounce kernel rounds over all batches           */
+  double   trace_closest_ms; /* HIP-event time of the closest-hit kernels (if timed)*/
+  double   trace_shadow_ms;
+  double   shade_ms;
+  double   reconstruct_ms;
+  double   total_ms;         /* first launch -> last kernel complete                */
+  uint64_t closest_launches; /* number of closest-hit kernel launches timed         */
+} hj_render_stats;
+
+typedef struct hj_context hj_context;
+
+/* ---------------------------------------------------------------- lifecycle */
+
+/* Replaces GPU::new + Renderer::new resource creation (src/main.rs:684-713,
+ * 1167-1314).  One context per GPU; no global state. */
+int hj_context_create(int device_ordinal, hj_context** out_ctx);
+void hj_context_destroy(hj_context* ctx);
+/* Replaces unwrap()/panic! text: message of the last failing call on ctx
+ * (owned by ctx; valid until the next call).  ctx may be NULL for create errors. */
+const char* hj_last_error(const hj_context* ctx);
+/* Library / ABI version: (major<<16)|(minor<<8)|patch. */
+uint32_t hj_version(void);
+void hj_default_render_opts(hj_render_opts* opts);
+
+/* -------------------------------------------------------------------- scene */
+
+/* Replaces the staging copy of the packed scene buffer (src/main.rs:1186-1244)
+ * and the bind-group plumbing (src/main.rs:808-855).  Validates the same
+ * invariants the reference asserts (src/main.rs:562-565) plus index ranges,
+ * copies, and re-lays the data out for the kernels. */
+int hj_scene_upload(hj_context* ctx, const hj_scene_desc* scene);
+
+/* -------------------------------------------------------------- framebuffer */
+
+/* Replaces creation of `final_texture` (W x H RGBA32F = (sum w*rgb, sum w),
+ * src/main.rs:1209-1234).  Zero-initialised.  If `external_device_rgba` is
+ * non-NULL the context accumulates into that caller-owned device buffer of
+ * W*H*4 floats (tight pitch) instead of allocating its own — this is how a
+ * torch/RCCL host shares the buffer for the multi-GPU reduce. */
+int hj_framebuffer_create(hj_context* ctx, uint32_t width, uint32_t height,
+                          void* external_device_rgba);
+int hj_framebuffer_clear(hj_context* ctx);
+/* Device pointer of the accumulation buffer (W*H*4 floats). */
+void* hj_framebuffer_device_ptr(hj_context* ctx);
+/* Replaces Renderer::save_image's texture->buffer copy + map (src/main.rs:
+ * 1357-1394), tight pitch instead of ceil256(W) texels. */
+int hj_framebuffer_read(hj_context* ctx, float* host_rgba /* W*H*4 */);
+/* rgb / w of every pixel (src/main.rs:1395-1400, shader/preview.glsl:11). */
+int hj_framebuffer_resolve(hj_context* ctx, float* host_rgb /* W*H*3 */);
+
+/* ------------------------------------------------------------------- render */
+
+/* Replaces the body of Renderer::render (src/main.rs:1316-1355): for every
+ * block IN ORDER, integrate (shader/render.glsl:149-175) and accumulate
+ * (shader/reconstruction.glsl:22-66).  The result equals running the
+ * reference's two dispatches per block sequentially; internally many blocks
+ * are traced as one wavefront batch.  Blocks must satisfy
+ * dimension <= 128 and original_dimension == framebuffer size.
+ * Synchronous: returns when the framebuffer holds the result. */
+int hj_render_blocks(hj_context* ctx, const hj_image_block* blocks, size_t num_blocks,
+                     const hj_render_opts* opts /* NULL = defaults */,
+                     hj_render_stats* stats /* may be NULL */);
+
+/* Deterministic ImageBlockGenerator (src/main.rs:619-682) + render of the
+ * blocks owned by `rank` out of `world` (block index modulo world), for
+ * passes [pass_begin, pass_end).  With world == 1 this is the whole frame.
+ * The reference seeds blocks from the OS RNG (src/main.rs:643,670,675);
+ * here seeds/offsets come from hj_block_seed / hj_pass_offset below. */
+int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed,
+                    uint32_t pass_begin, uint32_t pass_end,
+                    uint32_t rank, uint32_t world,
+                    const hj_render_opts* opts, hj_render_stats* stats);
+
+/* The deterministic replacement of `rand::random()` in the block generator.
+ * Pure functions (no context); the same definitions are used by the host
+ * library's ImageBlockGenerator and restated by the oracle. */
+uint32_t hj_block_seed(uint64_t master_seed, uint32_t pass, uint32_t block_in_pass);
+void hj_pass_offset(uint64_t master_seed, uint32_t offset_index, float out_xy[2]);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIJIKI_HIP_H */
