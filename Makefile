@@ -27,8 +27,10 @@ hijiki_amd/lib/libhijiki_host.so: $(HOST_SRC) $(HOST_HDR)
 
 hijiki_amd/lib/libhijiki_hip.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p hijiki_amd/lib
-	$(HIPCC) --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -shared $(FP_STRICT) -fgpu-rdc=false \
-	  -Wall -Wno-unused-function -x hip hijiki_amd/csrc/hj_api.hip -x c++ hijiki_amd/csrc/host/blockgen.cpp -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -shared $(FP_STRICT) -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden \
+	  -Wall -Wno-unused-function hijiki_amd/csrc/hj_api.hip hijiki_amd/csrc/host/blockgen.cpp -o $@ \
+	  -Rpass-analysis=kernel-resource-usage 2> hijiki_amd/lib/resource_usage.txt || (cat hijiki_amd/lib/resource_usage.txt; false)
+	@strings $@ | grep -q 'amdgcn-amd-amdhsa--$(ARCH)' || (echo 'ERROR: no $(ARCH) code object in $@'; rm -f $@; false)
 
 oracle/_build/libhj_oracle.so: oracle/hj_oracle.c include/hijiki_hip.h
 	@mkdir -p oracle/_build

@@ -16,6 +16,7 @@ MATERIAL_INDEX_MASK = 0x00FFFFFF
 BVH_INNER = 0xFFFFFFFF
 BVH_ROOT_EXIT = 1000000
 BLOCK_SIZE = 128
+RENDER_TIME_KERNELS = 1
 
 f32, u32, u64 = C.c_float, C.c_uint32, C.c_uint64
 
@@ -94,7 +95,7 @@ class SceneDesc(C.Structure):
 
 class RenderOpts(C.Structure):
     _fields_ = [("use_bvh", u32), ("recon_radius", u32), ("recon_stddev", f32), ("max_bounces", u32),
-                ("rr_start", u32), ("batch_blocks", u32), ("_reserved", u32 * 2)]
+                ("rr_start", u32), ("batch_blocks", u32), ("flags", u32), ("_reserved", u32)]
 
     @staticmethod
     def default():

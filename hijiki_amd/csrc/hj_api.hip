@@ -1,0 +1,589 @@
+// libhijiki_hip.so — C ABI (include/hijiki_hip.h) over the gfx950 kernels.
+//
+// Replaces, for the hot path only, what the reference's Renderer does through
+// wgpu (reference src/main.rs:1143-1424): resource creation, scene upload,
+// the per-block dispatch loop and the read-back.  No CPU fallback exists: every
+// entry point that computes needs a HIP device and fails with HJ_ERR_DEVICE
+// otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hijiki_hip.h"
+#include "host/blockgen.hpp"
+#include "kernels/hj_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+struct EventPair { hipEvent_t a, b; int kind; };
+
+}  // namespace
+
+struct hj_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string error;
+  int num_cus = 256;
+
+  // scene
+  bool have_scene = false;
+  hj::DeviceScene scene{};
+  std::vector<DevBuf> scene_bufs;
+
+  // framebuffer
+  float4* accum = nullptr;
+  bool accum_owned = false;
+  uint32_t width = 0, height = 0;
+
+  // batch state
+  hj::BatchState st{};
+  std::vector<DevBuf> batch_bufs;
+  DevBuf d_blocks, d_wtab;
+  uint32_t* h_count = nullptr;           // pinned read-back word
+  hj::BatchCounters* h_ctr = nullptr;    // pinned copy of the counters
+
+  // timing
+  std::vector<EventPair> events;
+  size_t events_used = 0;
+};
+
+namespace {
+
+int set_error(hj_context* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->error = buf;
+  else g_create_error = buf;
+  return code;
+}
+
+#define HJ_HIP(ctx, call)                                                                         \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return set_error(ctx, e_ == hipErrorOutOfMemory ? HJ_ERR_NOMEM : HJ_ERR_DEVICE, "%s: %s", #call, \
+                       hipGetErrorString(e_));                                                    \
+  } while (0)
+
+int dev_alloc(hj_context* ctx, DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes && b.p) return HJ_OK;
+  b.release();
+  if (bytes == 0) bytes = 16;
+  HJ_HIP(ctx, hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return HJ_OK;
+}
+
+template <class T>
+int upload(hj_context* ctx, const T* src, size_t count, const T** out) {
+  ctx->scene_bufs.emplace_back();
+  DevBuf& b = ctx->scene_bufs.back();
+  int rc = dev_alloc(ctx, b, std::max<size_t>(count * sizeof(T), 16));
+  if (rc != HJ_OK) return rc;
+  if (count) HJ_HIP(ctx, hipMemcpy(b.p, src, count * sizeof(T), hipMemcpyHostToDevice));
+  *out = static_cast<const T*>(b.p);
+  return HJ_OK;
+}
+
+void release_scene(hj_context* ctx) {
+  for (auto& b : ctx->scene_bufs) b.release();
+  ctx->scene_bufs.clear();
+  ctx->have_scene = false;
+}
+
+void release_batch(hj_context* ctx) {
+  for (auto& b : ctx->batch_bufs) b.release();
+  ctx->batch_bufs.clear();
+  ctx->st = hj::BatchState{};
+}
+
+// Same invariants the reference asserts while packing (src/main.rs:562-565)
+// plus every index range a kernel dereferences, and the monotonic-exit
+// property that makes the skip-link walk terminate on any input.
+int validate_scene(hj_context* ctx, const hj_scene_desc* s) {
+  const size_t shapes = s->num_spheres + s->num_quads + s->num_triangles;
+  if (s->num_materials != shapes)
+    return set_error(ctx, HJ_ERR_INVALID, "materials (%zu) != spheres+quads+triangles (%zu) (assert src/main.rs:562-565)",
+                     s->num_materials, shapes);
+  if (shapes >= 0x7FFFFFFFu || s->num_bvh_nodes >= 0x7FFFFFFFu) return set_error(ctx, HJ_ERR_INVALID, "scene too large");
+  auto need = [&](const void* p, size_t n) { return n == 0 || p != nullptr; };
+  if (!need(s->bvh, s->num_bvh_nodes) || !need(s->spheres, s->num_spheres) || !need(s->quads, s->num_quads) ||
+      !need(s->triangles, s->num_triangles) || !need(s->vertices, s->num_vertices) ||
+      !need(s->materials, s->num_materials) || !need(s->emitters, s->num_emitters) ||
+      !need(s->diffuse, s->num_diffuse) || !need(s->diffusecb, s->num_diffusecb) ||
+      !need(s->dielectric, s->num_dielectric) || !need(s->emissive, s->num_emissive))
+    return set_error(ctx, HJ_ERR_INVALID, "null array with non-zero count");
+  for (size_t i = 0; i < s->num_bvh_nodes; i++) {
+    const hj_bvh_node& n = s->bvh[i];
+    if (n.exit_index <= i) return set_error(ctx, HJ_ERR_INVALID, "bvh node %zu: exit index %u does not move forward", i, n.exit_index);
+    if (n.shape_index != HJ_BVH_INNER && n.shape_index >= shapes)
+      return set_error(ctx, HJ_ERR_INVALID, "bvh node %zu: shape index %u out of range", i, n.shape_index);
+  }
+  for (size_t i = 0; i < s->num_triangles; i++)
+    for (int k = 0; k < 3; k++)
+      if (s->triangles[i].v[k] >= s->num_vertices)
+        return set_error(ctx, HJ_ERR_INVALID, "triangle %zu refers to vertex %u of %zu", i, s->triangles[i].v[k], s->num_vertices);
+  for (size_t i = 0; i < s->num_materials; i++) {
+    const uint32_t tag = s->materials[i] >> HJ_MATERIAL_TAG_SHIFT, idx = s->materials[i] & HJ_MATERIAL_INDEX_MASK;
+    size_t lim = 0;
+    switch (tag) {
+      case HJ_MAT_DIFFUSE: lim = s->num_diffuse; break;
+      case HJ_MAT_DIFFUSECBOARD: lim = s->num_diffusecb; break;
+      case HJ_MAT_MIRROR: lim = 1; break;
+      case HJ_MAT_DIELECTRIC: lim = s->num_dielectric; break;
+      case HJ_MAT_EMISSIVE: lim = s->num_emissive; break;
+      default: return set_error(ctx, HJ_ERR_INVALID, "shape %zu: unknown material tag %u", i, tag);
+    }
+    if (idx >= lim) return set_error(ctx, HJ_ERR_INVALID, "shape %zu: material index %u out of range for tag %u", i, idx, tag);
+  }
+  for (size_t i = 0; i < s->num_emitters; i++) {
+    const uint32_t sh = s->emitters[i].shape;
+    if (sh >= shapes) return set_error(ctx, HJ_ERR_INVALID, "emitter %zu: shape %u out of range", i, sh);
+    if ((s->materials[sh] >> HJ_MATERIAL_TAG_SHIFT) != HJ_MAT_EMISSIVE)
+      return set_error(ctx, HJ_ERR_INVALID, "emitter %zu: shape %u is not emissive", i, sh);
+  }
+  return HJ_OK;
+}
+
+int ensure_batch(hj_context* ctx, uint32_t num_blocks) {
+  const uint32_t cap = num_blocks * hj::kSlotsPerBlock;
+  if (ctx->st.capacity >= cap) return HJ_OK;
+  release_batch(ctx);
+  auto alloc = [&](size_t bytes, void** out) -> int {
+    ctx->batch_bufs.emplace_back();
+    int rc = dev_alloc(ctx, ctx->batch_bufs.back(), bytes);
+    *out = ctx->batch_bufs.back().p;
+    return rc;
+  };
+  hj::BatchState& st = ctx->st;
+  int rc = HJ_OK;
+  const size_t n = cap;
+#define HJ_ALLOC(field, type, count)                                       \
+  if (rc == HJ_OK) {                                                       \
+    void* p_ = nullptr;                                                    \
+    rc = alloc(sizeof(type) * (count), &p_);                               \
+    st.field = static_cast<type*>(p_);                                     \
+  }
+  HJ_ALLOC(ray_o, float4, n)
+  HJ_ALLOC(ray_d, float4, n)
+  HJ_ALLOC(hit, float4, n)
+  HJ_ALLOC(thr, float4, n)
+  HJ_ALLOC(ext, float4, n)
+  HJ_ALLOC(rng, uint32_t, n)
+  HJ_ALLOC(smp_rgb, float4, n)
+  HJ_ALLOC(smp_nd, float4, n)
+  HJ_ALLOC(sh_d, float4, n)
+  HJ_ALLOC(sh_c, float4, n)
+  HJ_ALLOC(q_ray[0], uint32_t, n)
+  HJ_ALLOC(q_ray[1], uint32_t, n)
+  HJ_ALLOC(q_hit, uint32_t, n * hj::kNumTags)
+  HJ_ALLOC(q_shadow, uint32_t, n)
+  HJ_ALLOC(ctr, hj::BatchCounters, 1)
+#undef HJ_ALLOC
+  if (rc != HJ_OK) {
+    release_batch(ctx);
+    return rc;
+  }
+  st.capacity = cap;
+  rc = dev_alloc(ctx, ctx->d_blocks, sizeof(hj_image_block) * num_blocks);
+  if (rc == HJ_OK) rc = dev_alloc(ctx, ctx->d_wtab, sizeof(float) * 25 * num_blocks);
+  if (rc != HJ_OK) release_batch(ctx);
+  return rc;
+}
+
+enum { EV_CLOSEST = 0, EV_SHADOW = 1, EV_SHADE = 2, EV_RECON = 3, EV_KINDS = 4 };
+
+struct Timer {
+  hj_context* ctx;
+  bool on;
+  int begin(int kind) {
+    if (!on) return -1;
+    if (ctx->events_used == ctx->events.size()) {
+      EventPair ep{};
+      if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) { on = false; return -1; }
+      ctx->events.push_back(ep);
+    }
+    EventPair& ep = ctx->events[ctx->events_used];
+    ep.kind = kind;
+    (void)hipEventRecord(ep.a, ctx->stream);
+    return (int)ctx->events_used++;
+  }
+  void end(int idx) {
+    if (idx >= 0) (void)hipEventRecord(ctx->events[idx].b, ctx->stream);
+  }
+};
+
+int render_batch(hj_context* ctx, const hj_image_block* blocks, uint32_t nb, const hj_render_opts& o, Timer& tm,
+                 hj_render_stats* stats) {
+  int rc = ensure_batch(ctx, std::max<uint32_t>(nb, 1));
+  if (rc != HJ_OK) return rc;
+  hj::BatchState st = ctx->st;
+  st.blocks = static_cast<const hj_image_block*>(ctx->d_blocks.p);
+  st.num_blocks = nb;
+  hipStream_t s = ctx->stream;
+  HJ_HIP(ctx, hipMemcpyAsync(ctx->d_blocks.p, blocks, sizeof(hj_image_block) * nb, hipMemcpyHostToDevice, s));
+  HJ_HIP(ctx, hipMemsetAsync(st.ctr, 0, sizeof(hj::BatchCounters), s));
+  const dim3 blk(hj::kBlockThreads);
+  const dim3 grid((unsigned)(ctx->num_cus * 8));
+  const bool bvh = o.use_bvh != 0;
+  hipLaunchKernelGGL(hj::k_gen_camera, grid, blk, 0, s, st, ctx->scene);
+  uint64_t rounds = 0;
+  for (uint32_t bounce = 0; bounce < o.max_bounces; bounce++) {
+    const uint32_t parity = bounce & 1u;
+    const float tmin = bounce == 0 ? hj::kEps : 2.0f * hj::kEps;   // render.glsl:33,132
+    int ev = tm.begin(EV_CLOSEST);
+    if (bvh) hipLaunchKernelGGL(hj::k_trace_closest<true>, grid, blk, 0, s, st, ctx->scene, parity, tmin);
+    else hipLaunchKernelGGL(hj::k_trace_closest<false>, grid, blk, 0, s, st, ctx->scene, parity, tmin);
+    tm.end(ev);
+    ev = tm.begin(EV_SHADE);
+    hipLaunchKernelGGL(hj::k_shade, grid, blk, 0, s, st, ctx->scene, parity, bounce, o.max_bounces, o.rr_start);
+    tm.end(ev);
+    ev = tm.begin(EV_SHADOW);
+    if (bvh) hipLaunchKernelGGL(hj::k_trace_shadow<true>, grid, blk, 0, s, st, ctx->scene);
+    else hipLaunchKernelGGL(hj::k_trace_shadow<false>, grid, blk, 0, s, st, ctx->scene);
+    tm.end(ev);
+    hipLaunchKernelGGL(hj::k_advance, dim3(1), dim3(1), 0, s, st, parity);
+    rounds++;
+    HJ_HIP(ctx, hipMemcpyAsync(ctx->h_count, &st.ctr->n_ray[parity ^ 1u], sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HJ_HIP(ctx, hipStreamSynchronize(s));
+    if (*ctx->h_count == 0) break;
+  }
+  int ev = tm.begin(EV_RECON);
+  hipLaunchKernelGGL(hj::k_recon_weights, dim3((nb * 25 + 255) / 256), dim3(256), 0, s, st.blocks, nb, o.recon_stddev,
+                     static_cast<float*>(ctx->d_wtab.p));
+  hipLaunchKernelGGL(hj::k_reconstruct, dim3((ctx->width + 15) / 16, (ctx->height + 15) / 16), dim3(256), 0, s, st,
+                     static_cast<const float*>(ctx->d_wtab.p), ctx->accum, ctx->width, ctx->height);
+  tm.end(ev);
+  HJ_HIP(ctx, hipMemcpyAsync(ctx->h_ctr, st.ctr, sizeof(hj::BatchCounters), hipMemcpyDeviceToHost, s));
+  HJ_HIP(ctx, hipStreamSynchronize(s));
+  HJ_HIP(ctx, hipGetLastError());
+  if (stats) {
+    stats->closest_rays += ctx->h_ctr->total_closest;
+    stats->shadow_rays += ctx->h_ctr->total_shadow;
+    stats->batches += 1;
+    stats->bounce_rounds += rounds;
+  }
+  return HJ_OK;
+}
+
+int check_opts(hj_context* ctx, const hj_render_opts& o) {
+  if (o.recon_radius != 2) return set_error(ctx, HJ_ERR_UNSUPPORTED, "only reconstruction radius 2 (the reference's value) is supported");
+  if (!(o.recon_stddev > 0.0f)) return set_error(ctx, HJ_ERR_INVALID, "recon_stddev must be > 0");
+  if (o.max_bounces == 0) return set_error(ctx, HJ_ERR_INVALID, "max_bounces must be >= 1");
+  return HJ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t hj_version(void) { return (0u << 16) | (1u << 8) | 0u; }
+
+void hj_default_render_opts(hj_render_opts* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof *o);
+  o->use_bvh = 1;
+  o->recon_radius = 2;
+  o->recon_stddev = 0.5f;
+  o->max_bounces = 1000;
+  o->rr_start = 4;
+  o->batch_blocks = 0;
+}
+
+const char* hj_last_error(const hj_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int hj_context_create(int device, hj_context** out) {
+  if (!out) return set_error(nullptr, HJ_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    return set_error(nullptr, HJ_ERR_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0 || device >= count) return set_error(nullptr, HJ_ERR_INVALID, "device ordinal %d out of range [0,%d)", device, count);
+  hj_context* ctx = new (std::nothrow) hj_context();
+  if (!ctx) return set_error(nullptr, HJ_ERR_NOMEM, "out of host memory");
+  ctx->device = device;
+  auto fail = [&](hipError_t err, const char* what) {
+    set_error(nullptr, HJ_ERR_DEVICE, "%s: %s", what, hipGetErrorString(err));
+    hj_context_destroy(ctx);
+    return (int)HJ_ERR_DEVICE;
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail(e, "hipGetDeviceProperties");
+  ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  if ((e = hipHostMalloc((void**)&ctx->h_count, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
+  if ((e = hipHostMalloc((void**)&ctx->h_ctr, sizeof(hj::BatchCounters), hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
+  *out = ctx;
+  return HJ_OK;
+}
+
+void hj_context_destroy(hj_context* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  release_scene(ctx);
+  release_batch(ctx);
+  ctx->d_blocks.release();
+  ctx->d_wtab.release();
+  if (ctx->accum && ctx->accum_owned) (void)hipFree(ctx->accum);
+  if (ctx->h_count) (void)hipHostFree(ctx->h_count);
+  if (ctx->h_ctr) (void)hipHostFree(ctx->h_ctr);
+  for (auto& ep : ctx->events) {
+    (void)hipEventDestroy(ep.a);
+    (void)hipEventDestroy(ep.b);
+  }
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
+  if (!ctx) return HJ_ERR_INVALID;
+  if (!s) return set_error(ctx, HJ_ERR_INVALID, "null scene");
+  int rc = validate_scene(ctx, s);
+  if (rc != HJ_OK) return rc;
+  HJ_HIP(ctx, hipSetDevice(ctx->device));
+  HJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  release_scene(ctx);
+
+  hj::DeviceScene d{};
+  d.camera = s->camera;
+  d.tan_half_fov = (float)std::tan((double)(0.5f * s->camera.fov) * (3.14159265358979323846 / 180.0));
+  d.ns = (uint32_t)s->num_spheres;
+  d.nq = (uint32_t)s->num_quads;
+  d.nt = (uint32_t)s->num_triangles;
+  d.num_emitters = (uint32_t)s->num_emitters;
+  d.num_nodes = (uint32_t)s->num_bvh_nodes;
+  d.has_extinction = 0;
+  for (size_t i = 0; i < s->num_dielectric; i++)
+    if (s->dielectric[i].extinction[0] != 0.f || s->dielectric[i].extinction[1] != 0.f || s->dielectric[i].extinction[2] != 0.f)
+      d.has_extinction = 1;
+
+  // pre-gathered triangle records (see kernels/hj_device.h)
+  std::vector<float4> isect, shade;
+  try {
+    isect.resize(3 * s->num_triangles);
+    shade.resize(4 * s->num_triangles);
+  } catch (const std::bad_alloc&) {
+    return set_error(ctx, HJ_ERR_NOMEM, "out of host memory");
+  }
+  for (size_t i = 0; i < s->num_triangles; i++) {
+    const hj_vertex& A = s->vertices[s->triangles[i].v[0]];
+    const hj_vertex& B = s->vertices[s->triangles[i].v[1]];
+    const hj_vertex& C = s->vertices[s->triangles[i].v[2]];
+    isect[3 * i + 0] = make_float4(A.pos[0], A.pos[1], A.pos[2], 0.f);
+    isect[3 * i + 1] = make_float4(B.pos[0] - A.pos[0], B.pos[1] - A.pos[1], B.pos[2] - A.pos[2], 0.f);
+    isect[3 * i + 2] = make_float4(C.pos[0] - A.pos[0], C.pos[1] - A.pos[1], C.pos[2] - A.pos[2], 0.f);
+    shade[4 * i + 0] = make_float4(A.normal[0], A.normal[1], A.normal[2], A.u);
+    shade[4 * i + 1] = make_float4(B.normal[0], B.normal[1], B.normal[2], B.u);
+    shade[4 * i + 2] = make_float4(C.normal[0], C.normal[1], C.normal[2], C.u);
+    shade[4 * i + 3] = make_float4(A.v, B.v, C.v, 0.f);
+  }
+  static_assert(sizeof(hj_bvh_node) == 2 * sizeof(float4), "node = 2 x float4");
+  static_assert(sizeof(hj_quad) == 3 * sizeof(float4) && sizeof(hj_sphere) == sizeof(float4), "shape records");
+  static_assert(sizeof(hj_diffuse_cb) == 2 * sizeof(float4), "checkerboard record");
+#define HJ_UP(expr) do { rc = (expr); if (rc != HJ_OK) { release_scene(ctx); return rc; } } while (0)
+  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->bvh), 2 * s->num_bvh_nodes, &d.nodes));
+  HJ_UP(upload(ctx, isect.data(), isect.size(), &d.tri_isect));
+  HJ_UP(upload(ctx, shade.data(), shade.size(), &d.tri_shade));
+  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->spheres), s->num_spheres, &d.spheres));
+  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->quads), 3 * s->num_quads, &d.quads));
+  HJ_UP(upload(ctx, s->triangles, s->num_triangles, &d.triangles));
+  HJ_UP(upload(ctx, s->vertices, s->num_vertices, &d.vertices));
+  HJ_UP(upload(ctx, s->materials, s->num_materials, &d.materials));
+  HJ_UP(upload(ctx, s->emitters, s->num_emitters, &d.emitters));
+  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->diffuse), s->num_diffuse, &d.diffuse));
+  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->diffusecb), 2 * s->num_diffusecb, &d.diffusecb));
+  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->dielectric), s->num_dielectric, &d.dielectric));
+  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->emissive), s->num_emissive, &d.emissive));
+#undef HJ_UP
+  ctx->scene = d;
+  ctx->have_scene = true;
+  return HJ_OK;
+}
+
+int hj_framebuffer_create(hj_context* ctx, uint32_t width, uint32_t height, void* external) {
+  if (!ctx) return HJ_ERR_INVALID;
+  if (width == 0 || height == 0 || width > 65536 || height > 65536) return set_error(ctx, HJ_ERR_INVALID, "bad framebuffer size %ux%u", width, height);
+  HJ_HIP(ctx, hipSetDevice(ctx->device));
+  HJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->accum && ctx->accum_owned) (void)hipFree(ctx->accum);
+  ctx->accum = nullptr;
+  ctx->accum_owned = false;
+  const size_t bytes = (size_t)width * height * sizeof(float4);
+  if (external) {
+    if ((reinterpret_cast<uintptr_t>(external) & 15u) != 0) return set_error(ctx, HJ_ERR_INVALID, "external framebuffer must be 16-byte aligned");
+    ctx->accum = static_cast<float4*>(external);
+  } else {
+    void* p = nullptr;
+    HJ_HIP(ctx, hipMalloc(&p, bytes));
+    ctx->accum = static_cast<float4*>(p);
+    ctx->accum_owned = true;
+  }
+  ctx->width = width;
+  ctx->height = height;
+  return hj_framebuffer_clear(ctx);
+}
+
+int hj_framebuffer_clear(hj_context* ctx) {
+  if (!ctx) return HJ_ERR_INVALID;
+  if (!ctx->accum) return set_error(ctx, HJ_ERR_STATE, "no framebuffer");
+  HJ_HIP(ctx, hipSetDevice(ctx->device));
+  HJ_HIP(ctx, hipMemsetAsync(ctx->accum, 0, (size_t)ctx->width * ctx->height * sizeof(float4), ctx->stream));
+  HJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return HJ_OK;
+}
+
+void* hj_framebuffer_device_ptr(hj_context* ctx) { return ctx ? ctx->accum : nullptr; }
+
+int hj_framebuffer_read(hj_context* ctx, float* host_rgba) {
+  if (!ctx) return HJ_ERR_INVALID;
+  if (!ctx->accum) return set_error(ctx, HJ_ERR_STATE, "no framebuffer");
+  if (!host_rgba) return set_error(ctx, HJ_ERR_INVALID, "null destination");
+  HJ_HIP(ctx, hipSetDevice(ctx->device));
+  HJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  HJ_HIP(ctx, hipMemcpy(host_rgba, ctx->accum, (size_t)ctx->width * ctx->height * sizeof(float4), hipMemcpyDeviceToHost));
+  return HJ_OK;
+}
+
+int hj_framebuffer_resolve(hj_context* ctx, float* host_rgb) {
+  if (!ctx) return HJ_ERR_INVALID;
+  if (!host_rgb) return set_error(ctx, HJ_ERR_INVALID, "null destination");
+  std::vector<float> tmp;
+  try {
+    tmp.resize((size_t)ctx->width * ctx->height * 4);
+  } catch (const std::bad_alloc&) {
+    return set_error(ctx, HJ_ERR_NOMEM, "out of host memory");
+  }
+  int rc = hj_framebuffer_read(ctx, tmp.data());
+  if (rc != HJ_OK) return rc;
+  const size_t n = (size_t)ctx->width * ctx->height;
+  for (size_t i = 0; i < n; i++) {   // [r/n, g/n, b/n], src/main.rs:1399
+    const float w = tmp[4 * i + 3];
+    host_rgb[3 * i + 0] = tmp[4 * i + 0] / w;
+    host_rgb[3 * i + 1] = tmp[4 * i + 1] / w;
+    host_rgb[3 * i + 2] = tmp[4 * i + 2] / w;
+  }
+  return HJ_OK;
+}
+
+int hj_render_blocks(hj_context* ctx, const hj_image_block* blocks, size_t n, const hj_render_opts* opts,
+                     hj_render_stats* stats) {
+  if (!ctx) return HJ_ERR_INVALID;
+  if (!ctx->have_scene) return set_error(ctx, HJ_ERR_STATE, "render before hj_scene_upload");
+  if (!ctx->accum) return set_error(ctx, HJ_ERR_STATE, "render before hj_framebuffer_create");
+  if (n && !blocks) return set_error(ctx, HJ_ERR_INVALID, "null block list");
+  hj_render_opts o;
+  if (opts) o = *opts;
+  else hj_default_render_opts(&o);
+  int rc = check_opts(ctx, o);
+  if (rc != HJ_OK) return rc;
+  uint64_t paths = 0;
+  for (size_t i = 0; i < n; i++) {
+    const hj_image_block& b = blocks[i];
+    if (b.dimension[0] == 0 || b.dimension[1] == 0 || b.dimension[0] > HJ_BLOCK_SIZE || b.dimension[1] > HJ_BLOCK_SIZE)
+      return set_error(ctx, HJ_ERR_INVALID, "block %zu: dimension %ux%u outside (0,128]", i, b.dimension[0], b.dimension[1]);
+    if (b.original_dimension[0] != ctx->width || b.original_dimension[1] != ctx->height)
+      return set_error(ctx, HJ_ERR_INVALID, "block %zu: original_dimension %ux%u != framebuffer %ux%u", i,
+                       b.original_dimension[0], b.original_dimension[1], ctx->width, ctx->height);
+    paths += (uint64_t)std::min(b.dimension[0], b.original_dimension[0]) * std::min(b.dimension[1], b.original_dimension[1]);
+  }
+  HJ_HIP(ctx, hipSetDevice(ctx->device));
+  if (stats) std::memset(stats, 0, sizeof *stats);
+  ctx->events_used = 0;
+  Timer tm{ctx, (o.flags & HJ_RENDER_TIME_KERNELS) != 0};
+  uint32_t batch = o.batch_blocks ? o.batch_blocks : 512u;
+  batch = std::min<uint32_t>(batch, 4096u);
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  HJ_HIP(ctx, hipEventCreate(&t0));
+  HJ_HIP(ctx, hipEventCreate(&t1));
+  (void)hipEventRecord(t0, ctx->stream);
+  for (size_t begin = 0; begin < n && rc == HJ_OK; begin += batch) {
+    const uint32_t nb = (uint32_t)std::min<size_t>(batch, n - begin);
+    rc = render_batch(ctx, blocks + begin, nb, o, tm, stats);
+  }
+  (void)hipEventRecord(t1, ctx->stream);
+  (void)hipEventSynchronize(t1);
+  if (rc == HJ_OK && stats) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, t0, t1);
+    stats->total_ms = ms;
+    stats->paths = paths;
+    for (size_t i = 0; i < ctx->events_used; i++) {
+      float e = 0.f;
+      if (hipEventElapsedTime(&e, ctx->events[i].a, ctx->events[i].b) != hipSuccess) continue;
+      switch (ctx->events[i].kind) {
+        case EV_CLOSEST: stats->trace_closest_ms += e; stats->closest_launches++; break;
+        case EV_SHADOW: stats->trace_shadow_ms += e; break;
+        case EV_SHADE: stats->shade_ms += e; break;
+        case EV_RECON: stats->reconstruct_ms += e; break;
+      }
+    }
+  }
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  return rc;
+}
+
+int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed, uint32_t pass_begin, uint32_t pass_end,
+                    uint32_t rank, uint32_t world, const hj_render_opts* opts, hj_render_stats* stats) {
+  if (!ctx) return HJ_ERR_INVALID;
+  if (!ctx->accum) return set_error(ctx, HJ_ERR_STATE, "render before hj_framebuffer_create");
+  if (world == 0 || rank >= world) return set_error(ctx, HJ_ERR_INVALID, "bad rank %u / world %u", rank, world);
+  if (pass_end > spp || pass_begin > pass_end) return set_error(ctx, HJ_ERR_INVALID, "bad pass range [%u,%u) of %u", pass_begin, pass_end, spp);
+  hijiki::BlockGrid grid(ctx->width, ctx->height, HJ_BLOCK_SIZE);
+  // Tile sharding: block j of every pass belongs to rank (j mod world), so that all passes of one
+  // block accumulate on one GPU in pass order.  The list is generated in chunks
+  // (4096^2 x 4096 spp would be 4.2 M blocks = 168 MB if materialised at once).
+  hj_render_stats total{};
+  std::vector<hj_image_block> chunk;
+  const uint32_t per_pass = grid.per_pass();
+  const uint32_t passes_per_chunk = std::max<uint32_t>(1u, 8192u / std::max<uint32_t>(1u, (per_pass + world - 1) / world));
+  int rc = HJ_OK;
+  for (uint32_t p0 = pass_begin; p0 < pass_end && rc == HJ_OK; p0 += passes_per_chunk) {
+    const uint32_t p1 = std::min(pass_end, p0 + passes_per_chunk);
+    chunk.clear();
+    for (uint32_t p = p0; p < p1; p++)
+      for (uint32_t j = rank; j < per_pass; j += world) chunk.push_back(grid.make(master_seed, p, j));
+    hj_render_stats st{};
+    rc = hj_render_blocks(ctx, chunk.data(), chunk.size(), opts, &st);
+    total.paths += st.paths; total.closest_rays += st.closest_rays; total.shadow_rays += st.shadow_rays;
+    total.batches += st.batches; total.bounce_rounds += st.bounce_rounds;
+    total.trace_closest_ms += st.trace_closest_ms; total.trace_shadow_ms += st.trace_shadow_ms;
+    total.shade_ms += st.shade_ms; total.reconstruct_ms += st.reconstruct_ms; total.total_ms += st.total_ms;
+    total.closest_launches += st.closest_launches;
+  }
+  if (stats) *stats = total;
+  return rc;
+}
+
+uint32_t hj_block_seed(uint64_t master, uint32_t pass, uint32_t j) { return hijiki::block_seed(master, pass, j); }
+void hj_pass_offset(uint64_t master, uint32_t k, float out[2]) { hijiki::pass_offset(master, k, out); }
+
+}  // extern "C"

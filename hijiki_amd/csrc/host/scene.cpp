@@ -275,7 +275,11 @@ CompiledScene compile(const Scene& scene) {
     Aabb root_box = tree[0].left_box;
     root_box.join(tree[0].right_box);  // src/main.rs:230
     std::vector<Work> st;
-    st.push_back({0, root_box, HJ_BVH_ROOT_EXIT});
+    // The reference hard-codes 1 000 000 (src/main.rs:231); with more than a million nodes that
+    // index lies INSIDE the array and the shader's walk would never terminate, so larger trees
+    // get the node count instead (any value >= the node count ends the walk).
+    const uint32_t root_exit = tree.size() > HJ_BVH_ROOT_EXIT ? (uint32_t)tree.size() : HJ_BVH_ROOT_EXIT;
+    st.push_back({0, root_box, root_exit});
     while (!st.empty()) {
       Work w = st.back();
       st.pop_back();

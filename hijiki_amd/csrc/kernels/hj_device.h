@@ -1,0 +1,73 @@
+// Device-side views: scene arrays as the kernels read them, and the SoA path
+// state of one wavefront batch.  All pointers are device pointers.
+#pragma once
+#include "../../../include/hijiki_hip.h"
+#include "hj_num.h"
+
+namespace hj {
+
+constexpr uint32_t kSlotsPerBlock = HJ_BLOCK_SIZE * HJ_BLOCK_SIZE;  // fixed 128x128 slot grid per ImageBlock
+constexpr uint32_t kNumTags = 5;
+
+// Scene data in HBM.  `nodes` keeps the reference's 32-byte skip-link records
+// (two float4 per node).  Triangles are additionally pre-gathered per
+// triangle so that a leaf test is ONE dependent fetch instead of the
+// reference's index -> vertex chain (shader/shapes/triangle.glsl:16-18):
+//   tri_isect[3i+0..2] = (a.xyz,-) (b-a .xyz,-) (c-a .xyz,-)        48 B
+//   tri_shade[4i+0..3] = (na.xyz,ua) (nb.xyz,ub) (nc.xyz,uc) (va,vb,vc,-)  64 B
+// b-a and c-a are the same single IEEE subtractions the shader performs.
+struct DeviceScene {
+  const float4* nodes;
+  uint32_t num_nodes;
+  const float4* tri_isect;
+  const float4* tri_shade;
+  const float4* spheres;        // hj_sphere
+  const float4* quads;          // hj_quad as 3 x float4
+  const hj_triangle* triangles; // original indices (emitter sampling)
+  const hj_vertex* vertices;    // original vertices (emitter sampling)
+  const uint32_t* materials;
+  const hj_emitter* emitters;
+  const float4* diffuse;
+  const float4* diffusecb;      // 2 x float4 per record
+  const float4* dielectric;
+  const float4* emissive;
+  uint32_t ns, nq, nt, num_emitters;
+  uint32_t has_extinction;      // any dielectric with non-zero extinction
+  hj_camera camera;
+  float tan_half_fov;           // (float)tan(radians(fov/2)) evaluated in double on the host
+};
+
+// Queue counters of one batch, in device memory (kernels read their trip
+// counts from here, the host only polls n_ray to stop the bounce loop).
+struct BatchCounters {
+  uint32_t n_ray[2];            // current / next ray queue lengths (index = bounce parity)
+  uint32_t n_hit[kNumTags];     // per-material-tag hit queues of the current bounce
+  uint32_t n_shadow;
+  uint32_t head_ray;            // work-fetch heads of the persistent kernels
+  uint32_t head_shadow;
+  uint32_t _pad[2];
+  unsigned long long total_closest, total_shadow, total_paths;
+};
+
+struct BatchState {
+  // per path slot (slot = block_in_batch * 16384 + ly * 128 + lx)
+  float4* ray_o;      // origin.xyz
+  float4* ray_d;      // direction.xyz
+  float4* hit;        // (t, objectID bits, u, v) of the raw hit
+  float4* thr;        // throughput.rgb, flags bits (bit0 wasDiscrete)
+  float4* ext;        // current extinction (only touched if scene.has_extinction)
+  uint32_t* rng;
+  float4* smp_rgb;    // layer 0 of the intermediate image: (radiance, 1)
+  float4* smp_nd;     // layer 1: (first-hit normal, first-hit t)
+  float4* sh_d;       // shadow ray direction.xyz, tMax
+  float4* sh_c;       // pending NEE contribution rgb
+  uint32_t* q_ray[2];
+  uint32_t* q_hit;    // kNumTags segments of `capacity` entries
+  uint32_t* q_shadow;
+  BatchCounters* ctr;
+  const hj_image_block* blocks;  // the batch's ImageBlocks
+  uint32_t num_blocks;
+  uint32_t capacity;             // num slots allocated
+};
+
+}  // namespace hj

@@ -1,0 +1,550 @@
+// Wavefront path-tracing kernels for gfx950 (wave64).
+//
+// One batch = up to `capacity` camera paths (many ImageBlocks of many passes)
+// advanced one bounce per round:
+//
+//   k_gen_camera                         render.glsl:149-162  seed, camera ray, queue
+//   per bounce:
+//     k_trace_closest  (ray queue)       scene.glsl:97-133    skip-link BVH walk -> hit record,
+//                                                             hits binned by MATERIAL TAG (wave ballot)
+//     k_shade          (hit queues)      scene.glsl:160-175, render.glsl:102-144, material.glsl
+//                                                             populate, emission, NEE sample, BSDF sample,
+//                                                             roulette -> next ray queue + shadow queue
+//     k_trace_shadow   (shadow queue)    scene.glsl:92-96     any-hit walk (boolean-equivalent to the
+//                                                             reference's closest-hit), adds NEE radiance
+//     k_advance                                               queue bookkeeping (1 thread)
+//   k_recon_weights / k_reconstruct      reconstruction.glsl:22-66
+//
+// Every path owns its RNG state, so queue order never changes results; the
+// per-path order of radiance additions is the reference's (emission, then
+// NEE, bounce by bounce) because each bounce's kernels run in stream order.
+#pragma once
+#include "hj_device.h"
+
+#pragma clang fp contract(off)
+
+namespace hj {
+
+constexpr int kBlockThreads = 256;
+
+// ---------------------------------------------------------------- helpers
+
+// Wave-aggregated queue append: one atomic per wave, lane order preserved.
+// Must be reached by all active lanes of the wave together.
+HJ_DEV uint32_t wave_push(uint32_t* counter, bool pred) {
+  const unsigned long long mask = __ballot(pred);
+  if (mask == 0) return 0xFFFFFFFFu;
+  const uint32_t lane = __lane_id();
+  const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  base = __shfl(base, (int)leader);
+  const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  return pred ? base + prefix : 0xFFFFFFFFu;
+}
+
+struct Ray { v3 o, d; float tmin, tmax; };
+struct RawHit { float t, u, v; int id; };
+
+// reference shader/shapes/triangle.glsl:15-52 on the pre-gathered record
+HJ_DEV bool intersect_triangle(const DeviceScene& sc, const Ray& r, uint32_t ix, RawHit& h) {
+  const float4 A = sc.tri_isect[3 * ix + 0], B = sc.tri_isect[3 * ix + 1], C = sc.tri_isect[3 * ix + 2];
+  const v3 a = xyz(A), ab = xyz(B), ac = xyz(C);
+  const v3 n = cross3(ab, ac);
+  const v3 ro = r.o - a;
+  const v3 q = cross3(ro, r.d);
+  const float d = 1.0f / dot3(r.d, n);
+  const float u = d * (-dot3(q, ac));
+  const float v = d * dot3(q, ab);
+  if (u < 0.0f || v < 0.0f || u + v > 1.0f) return false;
+  const float t = d * (-dot3(n, ro));
+  if (r.tmin <= t && t <= r.tmax) { h.t = t; h.u = u; h.v = v; return true; }
+  return false;
+}
+// reference shader/shapes/sphere.glsl:18-41
+HJ_DEV bool intersect_sphere(const Ray& r, float4 sp, RawHit& h) {
+  const v3 l = r.o - xyz(sp);
+  const float b = 2.0f * dot3(r.d, l);
+  const float c = dot3(l, l) - sp.w * sp.w;
+  float d = b * b - 4.0f * c;
+  if (d < 0.0f) return false;
+  d = __builtin_sqrtf(d);
+  const float t0 = -0.5f * (b + d);
+  if (r.tmin <= t0 && t0 <= r.tmax) { h.t = t0; return true; }
+  const float t1 = -0.5f * (b - d);
+  if (r.tmin <= t1 && t1 <= r.tmax) { h.t = t1; return true; }
+  return false;
+}
+// reference shader/shapes/quad.glsl:7-25
+HJ_DEV bool intersect_quad(const DeviceScene& sc, const Ray& r, uint32_t ix, RawHit& h) {
+  const v3 o = xyz(sc.quads[3 * ix + 0]), e1 = xyz(sc.quads[3 * ix + 1]), e2 = xyz(sc.quads[3 * ix + 2]);
+  const v3 n = cross3(e1, e2);
+  const v3 ro = r.o - o;
+  const v3 q = cross3(ro, r.d);
+  const float d = 1.0f / dot3(r.d, n);
+  const float u = d * (-dot3(q, e2));
+  const float v = d * dot3(q, e1);
+  if (u < 0.0f || u > 1.0f || v < 0.0f || v > 1.0f) return false;
+  const float t = d * (-dot3(n, ro));
+  if (r.tmin <= t && t <= r.tmax) { h.t = t; h.u = u; h.v = v; return true; }
+  return false;
+}
+
+HJ_DEV bool intersect_shape(const DeviceScene& sc, const Ray& r, uint32_t shape, RawHit& h) {
+  if (shape < sc.ns) return intersect_sphere(r, sc.spheres[shape], h);
+  if (shape < sc.ns + sc.nq) return intersect_quad(sc, r, shape - sc.ns, h);
+  return intersect_triangle(sc, r, shape - sc.ns - sc.nq, h);
+}
+
+// reference shader/scene.glsl:97-158.  ANYHIT: stop at the first accepted hit
+// (the shadow overload scene.glsl:92-96 only uses the boolean, and the first
+// accepted hit in visiting order is the same with or without tMax shrinking).
+template <bool USE_BVH, bool ANYHIT>
+HJ_DEV bool traverse(const DeviceScene& sc, Ray r, RawHit& h) {
+  h.id = -1;
+  if (USE_BVH) {
+    const v3 inv = V(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    const v3 off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
+    uint32_t cur = 0;
+    while (cur < sc.num_nodes) {
+      const float4 n0 = sc.nodes[2 * cur], n1 = sc.nodes[2 * cur + 1];
+      const uint32_t shape = __float_as_uint(n0.w), ex = __float_as_uint(n1.w);
+      if (shape != HJ_BVH_INNER) {
+        if (intersect_shape(sc, r, shape, h)) {
+          h.id = (int)shape;
+          if (ANYHIT) return true;
+          r.tmax = h.t - kEps;
+        }
+        cur = ex;
+      } else {
+        const float tnx = fmaf(n0.x, inv.x, off.x), tpx = fmaf(n1.x, inv.x, off.x);
+        const float tny = fmaf(n0.y, inv.y, off.y), tpy = fmaf(n1.y, inv.y, off.y);
+        const float tnz = fmaf(n0.z, inv.z, off.z), tpz = fmaf(n1.z, inv.z, off.z);
+        const float t0 = f_max(f_max(f_min(tnx, tpx), f_min(tny, tpy)), f_min(tnz, tpz));
+        const float t1 = f_min(f_min(f_max(tnx, tpx), f_max(tny, tpy)), f_max(tnz, tpz));
+        cur = (t0 < t1 + kEps && t0 < r.tmax && t1 > r.tmin) ? cur + 1 : ex;
+      }
+    }
+  } else {
+    if (sc.ns > 100 || sc.nq > 100) return false;  // scene.glsl:135-138
+    const uint32_t total = sc.ns + sc.nq + sc.nt;
+    for (uint32_t s = 0; s < total; s++) {
+      if (intersect_shape(sc, r, s, h)) {
+        h.id = (int)s;
+        if (ANYHIT) return true;
+        r.tmax = h.t - kEps;
+      }
+    }
+  }
+  return h.id != -1;
+}
+
+// ------------------------------------------------------------ populate (its)
+
+struct Its { v3 p, n, ft, fb; float u, v; };   // frame = [ft fb n]
+
+// reference shader/shapes/triangle.glsl:54-78
+HJ_DEV void populate_triangle(const DeviceScene& sc, uint32_t ix, float hu, float hv, Its& its) {
+  const float4 A = sc.tri_shade[4 * ix + 0], B = sc.tri_shade[4 * ix + 1], C = sc.tri_shade[4 * ix + 2],
+               Vv = sc.tri_shade[4 * ix + 3];
+  const float l0 = (1.0f - hu) - hv, l1 = hu, l2 = hv;
+  const v3 ns = (xyz(A) * l0 + xyz(B) * l1) + xyz(C) * l2;
+  its.n = normalize3(ns);
+  its.u = (A.w * l0 + B.w * l1) + C.w * l2;
+  its.v = (Vv.x * l0 + Vv.y * l1) + Vv.z * l2;
+  v3 bt = (__builtin_fabsf(its.n.x) > __builtin_fabsf(its.n.y)) ? V(0.f, 1.f, 0.f) : V(1.f, 0.f, 0.f);
+  const v3 t = normalize3(cross3(its.n, bt));
+  bt = cross3(its.n, t);
+  its.ft = t; its.fb = bt;
+}
+// reference shader/shapes/sphere.glsl:43-52
+HJ_DEV void populate_sphere(float4 sp, Its& its) {
+  const v3 n = divs(its.p - xyz(sp), sp.w);
+  its.n = n;
+  const v3 t = normalize3(V(-n.z, 0.0f, n.x));
+  its.ft = t; its.fb = cross3(n, t);
+  float ux = 0.5f + hj_atan2(n.z, n.x) * (1.0f / kTwoPi);
+  const float uy = 0.5f + hj_asin(f_min(f_max(n.y, -1.0f), 1.0f)) * kInvPi;
+  if (ux != ux) ux = 0.0f;
+  its.u = ux; its.v = uy;
+}
+// reference shader/shapes/quad.glsl:27-32 (uv stays the raw hit's)
+HJ_DEV void populate_quad(const DeviceScene& sc, uint32_t ix, float hu, float hv, Its& its) {
+  const v3 t = normalize3(xyz(sc.quads[3 * ix + 1]));
+  const v3 b = normalize3(xyz(sc.quads[3 * ix + 2]));
+  its.n = cross3(t, b); its.ft = t; its.fb = b; its.u = hu; its.v = hv;
+}
+
+// ------------------------------------------------------------ emitter sampling
+
+struct SRec { v3 p, n; float pdf; };
+
+HJ_DEV v3 ld3(const float* p) { return V(p[0], p[1], p[2]); }
+
+// reference shader/scene.glsl:44-89 + shapes/*: sample*.  Always 3 draws.
+HJ_DEV v3 sample_emitter(const DeviceScene& sc, v3 ref, uint32_t& rng, v3& sh_dir, float& sh_tmax) {
+  float xi = rng_float(rng);
+  if (sc.num_emitters == 0) {   // reference reads emitters[0] out of bounds; defined here as "no light"
+    rng_uint(rng); rng_uint(rng);
+    sh_dir = V(0, 0, 0); sh_tmax = 0.0f;
+    return V(0, 0, 0);
+  }
+  uint32_t e = 0;
+  for (uint32_t i = 0; i < sc.num_emitters; i++) {
+    xi -= sc.emitters[i].pdf;
+    if (xi < 0.0f) { e = i; break; }
+  }
+  const hj_emitter em = sc.emitters[e];
+  const uint32_t shape = em.shape;
+  SRec sr;
+  if (shape < sc.ns) {                       // sphere.glsl:54-58
+    const float4 sp = sc.spheres[shape];
+    sr.n = rand_uniform_sphere(rng);
+    sr.p = xyz(sp) + sr.n * sp.w;
+    sr.pdf = 1.0f / (((sp.w * sp.w) * 4.0f) * kPi);
+  } else if (shape < sc.ns + sc.nq) {        // quad.glsl:34-45
+    const uint32_t ix = shape - sc.ns;
+    const v3 o = xyz(sc.quads[3 * ix]), e1 = xyz(sc.quads[3 * ix + 1]), e2 = xyz(sc.quads[3 * ix + 2]);
+    const v3 n = cross3(e1, e2);
+    const float area = len3(n);
+    sr.n = divs(n, area);
+    const float u = rng_float(rng), v = rng_float(rng);
+    sr.p = (o + e1 * u) + e2 * v;
+    sr.pdf = 1.0f / area;
+  } else {                                   // triangle.glsl:81-102
+    const hj_triangle T = sc.triangles[shape - sc.ns - sc.nq];
+    const hj_vertex* A = &sc.vertices[T.v[0]];
+    const hj_vertex* B = &sc.vertices[T.v[1]];
+    const hj_vertex* C = &sc.vertices[T.v[2]];
+    const v3 a = ld3(A->pos), b = ld3(B->pos), c = ld3(C->pos);
+    const v3 n = cross3(b - a, c - a);
+    const float area = len3(n) * 0.5f;
+    const v3 l = rand_barycentric(rng);
+    sr.n = normalize3((ld3(A->normal) * l.x + ld3(B->normal) * l.y) + ld3(C->normal) * l.z);
+    sr.p = (a * l.x + b * l.y) + c * l.z;
+    sr.pdf = 1.0f / area;
+  }
+  const uint32_t mat = sc.materials[shape];
+  const v3 power = xyz(sc.emissive[mat & HJ_MATERIAL_INDEX_MASK]);
+  v3 dir = sr.p - ref;
+  const float dist = len3(dir);
+  dir = divs(dir, dist);
+  sh_dir = dir; sh_tmax = dist - kEps;
+  const float cosT = -dot3(dir, sr.n);
+  if (cosT < 0.0f) return V(0, 0, 0);
+  const float pdf = (((em.pdf * sr.pdf) * dist) * dist) / cosT;
+  return divs(power, pdf);
+}
+
+// reference shader/materials/diffusecb.glsl:6-13
+HJ_DEV v3 checkerboard(const DeviceScene& sc, uint32_t idx, float u, float v) {
+  const float4 ca = sc.diffusecb[2 * idx], cb = sc.diffusecb[2 * idx + 1];
+  float fu = (0.5f * u) / ca.w, fv = (0.5f * v) / cb.w;
+  fu = fu - __builtin_floorf(fu); fv = fv - __builtin_floorf(fv);
+  const bool a = fu < 0.5f, b = fv < 0.5f;
+  return (a != b) ? xyz(cb) : xyz(ca);
+}
+
+// ------------------------------------------------------------------ kernels
+
+// reference shader/render.glsl:26-36,149-162
+__global__ __launch_bounds__(kBlockThreads) void k_gen_camera(BatchState st, DeviceScene sc) {
+  const uint32_t total = st.num_blocks * kSlotsPerBlock;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t base = first - (threadIdx.x & 63u); base < total; base += stride) {
+    const uint32_t slot = base + (threadIdx.x & 63u);
+    bool valid = slot < total;
+    hj_image_block b;
+    uint32_t lx = 0, ly = 0;
+    if (valid) {
+      b = st.blocks[slot / kSlotsPerBlock];
+      lx = slot & (HJ_BLOCK_SIZE - 1u);
+      ly = (slot / HJ_BLOCK_SIZE) & (HJ_BLOCK_SIZE - 1u);
+      valid = lx < b.dimension[0] && ly < b.dimension[1];
+      // render.glsl:152 compares the LOCAL id with the image size
+      valid = valid && lx < b.original_dimension[0] && ly < b.original_dimension[1];
+    }
+    if (valid) {
+      const uint32_t seed = b.seed + lx + ly * b.dimension[0];          // render.glsl:156
+      const uint32_t rng = rng_seed(seed);
+      const float W = (float)b.original_dimension[0], H = (float)b.original_dimension[1];
+      const float px = (float)(lx + b.origin[0]) + b.sample_offset[0];
+      const float py = (float)(ly + b.origin[1]) + b.sample_offset[1];
+      float x = px - 0.5f * W, y = py - 0.5f * H;
+      x = (x * sc.tan_half_fov) / (0.5f * W);
+      y = (y * sc.tan_half_fov) / (0.5f * W);
+      // quaternionRotate(v, q) = (q (x) (v,0)) (x) conj(q), quaternion.glsl:1-19
+      const v3 qv = V(sc.camera.rotation[0], sc.camera.rotation[1], sc.camera.rotation[2]);
+      const float qw = sc.camera.rotation[3];
+      const v3 vv = V(x, -y, -1.0f);
+      const float tw = qw * 0.0f - dot3(qv, vv);
+      v3 c1 = cross3(qv, vv);
+      const v3 txyz = V((c1.x + qv.x * 0.0f) + vv.x * qw, (c1.y + qv.y * 0.0f) + vv.y * qw, (c1.z + qv.z * 0.0f) + vv.z * qw);
+      const v3 cq = -qv;
+      v3 c2 = cross3(txyz, cq);
+      const v3 rot = V((c2.x + txyz.x * qw) + cq.x * tw, (c2.y + txyz.y * qw) + cq.y * tw, (c2.z + txyz.z * qw) + cq.z * tw);
+      const v3 d = normalize3(rot);
+      st.ray_o[slot] = make_float4(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2], 0.f);
+      st.ray_d[slot] = make_float4(d.x, d.y, d.z, 0.f);
+      st.thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(1u));   // wasDiscrete = true
+      if (sc.has_extinction) st.ext[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+      st.rng[slot] = rng;
+      st.smp_rgb[slot] = make_float4(0.f, 0.f, 0.f, 1.f);
+      st.smp_nd[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const uint32_t qi = wave_push(&st.ctr->n_ray[0], valid);
+    if (valid) st.q_ray[0][qi] = slot;
+  }
+}
+
+template <bool USE_BVH>
+__global__ __launch_bounds__(kBlockThreads) void k_trace_closest(BatchState st, DeviceScene sc, uint32_t parity,
+                                                                 float tmin) {
+  const uint32_t n = st.ctr->n_ray[parity];
+  const uint32_t* __restrict__ q = st.q_ray[parity];
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < n; base += stride) {
+    const uint32_t i = base + lane;
+    const bool valid = i < n;
+    uint32_t slot = 0, tag = 0xFFu;
+    if (valid) {
+      slot = q[i];
+      const float4 o = st.ray_o[slot], d = st.ray_d[slot];
+      Ray r; r.o = xyz(o); r.d = xyz(d); r.tmin = tmin; r.tmax = kInf;
+      RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f;
+      if (traverse<USE_BVH, false>(sc, r, h)) {
+        st.hit[slot] = make_float4(h.t, __int_as_float(h.id), h.u, h.v);
+        tag = sc.materials[h.id] >> HJ_MATERIAL_TAG_SHIFT;
+      }
+    }
+    // bin hits by material tag (divergent BSDF sort): one ballot + one atomic per tag per wave
+#pragma unroll
+    for (uint32_t k = 0; k < kNumTags; k++) {
+      const uint32_t qi = wave_push(&st.ctr->n_hit[k], tag == k);
+      if (tag == k) st.q_hit[(size_t)k * st.capacity + qi] = slot;
+    }
+  }
+}
+
+template <bool USE_BVH>
+__global__ __launch_bounds__(kBlockThreads) void k_trace_shadow(BatchState st, DeviceScene sc) {
+  const uint32_t n = st.ctr->n_shadow;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t slot = st.q_shadow[i];
+    const float4 o = st.ray_o[slot], d = st.sh_d[slot];
+    Ray r; r.o = xyz(o); r.d = xyz(d); r.tmin = 2.0f * kEps; r.tmax = d.w;
+    RawHit h;
+    if (!traverse<USE_BVH, true>(sc, r, h)) {
+      const float4 c = st.sh_c[slot];
+      float4 s = st.smp_rgb[slot];
+      s.x += c.x; s.y += c.y; s.z += c.z;      // render.glsl:123
+      st.smp_rgb[slot] = s;
+    }
+  }
+}
+
+// reference shader/scene.glsl:160-175 (populate), render.glsl:102-144, material.glsl:18-91
+__global__ __launch_bounds__(kBlockThreads) void k_shade(BatchState st, DeviceScene sc, uint32_t parity,
+                                                         uint32_t bounce, uint32_t max_bounces, uint32_t rr_start) {
+  // virtual wave index -> (tag segment, first entry): every wave shades ONE material tag
+  uint32_t cnt[kNumTags], wbase[kNumTags + 1];
+  wbase[0] = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kNumTags; k++) {
+    cnt[k] = st.ctr->n_hit[k];
+    wbase[k + 1] = wbase[k] + (cnt[k] + 63u) / 64u;
+  }
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t waves_per_grid = gridDim.x * (blockDim.x / 64u);
+  uint32_t* __restrict__ q_next = st.q_ray[parity ^ 1u];
+  for (uint32_t w = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; w < wbase[kNumTags]; w += waves_per_grid) {
+    uint32_t tag = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < kNumTags; k++) tag += (w >= wbase[k]) ? 1u : 0u;
+    const uint32_t i = (w - wbase[tag]) * 64u + lane;
+    const bool valid = i < cnt[tag];
+    bool alive = false, want_shadow = false;
+    uint32_t slot = 0;
+    if (valid) {
+      slot = st.q_hit[(size_t)tag * st.capacity + i];
+      const float4 hr = st.hit[slot];
+      const float4 ro4 = st.ray_o[slot], rd4 = st.ray_d[slot];
+      const float4 th4 = st.thr[slot];
+      const v3 ro = xyz(ro4), rd = xyz(rd4);
+      v3 T = xyz(th4);
+      const bool was_discrete = (__float_as_uint(th4.w) & 1u) != 0u;
+      uint32_t rng = st.rng[slot];
+      const uint32_t id = (uint32_t)__float_as_int(hr.y);
+      Its its;
+      its.p = V(fmaf(hr.x, rd.x, ro.x), fmaf(hr.x, rd.y, ro.y), fmaf(hr.x, rd.z, ro.z));   // scene.glsl:164
+      if (id < sc.ns) populate_sphere(sc.spheres[id], its);
+      else if (id < sc.ns + sc.nq) populate_quad(sc, id - sc.ns, hr.z, hr.w, its);
+      else populate_triangle(sc, id - sc.ns - sc.nq, hr.z, hr.w, its);
+      if (bounce == 0) st.smp_nd[slot] = make_float4(its.n.x, its.n.y, its.n.z, hr.x);   // render.glsl:102-105
+      const uint32_t mat = sc.materials[id];
+      const uint32_t midx = mat & HJ_MATERIAL_INDEX_MASK;
+      v3 ext = V(0, 0, 0);
+      if (sc.has_extinction) {                                                             // render.glsl:111-112
+        ext = xyz(st.ext[slot]);
+        const float dist = len3(ro - its.p);
+        T = T * V(hj_exp(-ext.x * dist), hj_exp(-ext.y * dist), hj_exp(-ext.z * dist));
+      }
+      v3 wo = V(0, 0, 0);
+      alive = true;
+      switch (tag) {
+        case HJ_MAT_EMISSIVE: {
+          if (was_discrete) {                                                              // render.glsl:114-116
+            const v3 e = T * xyz(sc.emissive[midx]);
+            float4 s = st.smp_rgb[slot];
+            s.x += e.x; s.y += e.y; s.z += e.z;
+            st.smp_rgb[slot] = s;
+          }
+          alive = false;   // sampleBSDF weight 0, wo unwritten (material.glsl:88-89)
+          break;
+        }
+        case HJ_MAT_DIFFUSE:
+        case HJ_MAT_DIFFUSECBOARD: {
+          const v3 color = (tag == HJ_MAT_DIFFUSE) ? xyz(sc.diffuse[midx]) : checkerboard(sc, midx, its.u, its.v);
+          v3 sdir; float stmax;
+          const v3 imp = sample_emitter(sc, its.p, rng, sdir, stmax);                      // render.glsl:117-126
+          if (len3(imp) > kEps && dot3(sdir, its.n) > 0.0f) {
+            const float cs = dot3(its.n, sdir);
+            const v3 f = (color * cs) * kInvPi;                                            // material.glsl:18-30
+            const v3 c = (T * f) * imp;
+            st.sh_d[slot] = make_float4(sdir.x, sdir.y, sdir.z, stmax);
+            st.sh_c[slot] = make_float4(c.x, c.y, c.z, 0.f);
+            want_shadow = true;
+          }
+          const v3 l = rand_cos_hemisphere(rng);                                           // material.glsl:37-46
+          wo = (its.ft * l.x + its.fb * l.y) + its.n * l.z;
+          T = T * color;
+          break;
+        }
+        case HJ_MAT_MIRROR:
+          wo = reflect3(rd, its.n);
+          break;
+        case HJ_MAT_DIELECTRIC: {                                                          // material.glsl:50-87
+          const float4 m = sc.dielectric[midx];
+          float eta = m.w;
+          float etaInv = 1.0f / eta;
+          float cosI = -dot3(its.n, rd);
+          v3 normal = its.n;
+          bool inside = cosI > 0.0f;      // sic
+          if (cosI < 0.0f) { eta = etaInv; etaInv = 1.0f / eta; normal = -normal; cosI = -cosI; }
+          const float k = 1.0f - (etaInv * etaInv) * (1.0f - cosI * cosI);
+          if (k <= 0.0f) {
+            wo = reflect3(rd, normal);
+          } else {
+            const float cosO = __builtin_sqrtf(k);
+            const float rpar = (eta * cosI - cosO) / (eta * cosI + cosO);
+            const float rorth = (cosI - eta * cosO) / (cosI + eta * cosO);
+            const float fr = 0.5f * (rpar * rpar + rorth * rorth);
+            if (rng_float(rng) < fr) {
+              wo = reflect3(rd, normal);
+            } else {
+              inside = !inside;
+              const v3 par = rd - normal * dot3(rd, normal);
+              wo = par * etaInv - normal * cosO;
+            }
+          }
+          if (inside) ext = xyz(m);
+          break;
+        }
+        default:
+          alive = false;
+          break;
+      }
+      if (alive) {
+        const bool discrete = (tag != HJ_MAT_DIFFUSE && tag != HJ_MAT_DIFFUSECBOARD);     // render.glsl:135
+        if (bounce >= rr_start) {                                                          // render.glsl:137-144
+          const float qq = f_min(0.99f, f_max(T.x, f_max(T.y, T.z)));
+          if (rng_float(rng) > qq) alive = false;
+          else T = divs(T, qq);
+        }
+        if (bounce + 1u >= max_bounces) alive = false;                                     // render.glsl:92
+        st.ray_d[slot] = make_float4(wo.x, wo.y, wo.z, 0.f);
+        st.thr[slot] = make_float4(T.x, T.y, T.z, __uint_as_float(discrete ? 1u : 0u));
+        st.rng[slot] = rng;
+        if (sc.has_extinction) st.ext[slot] = make_float4(ext.x, ext.y, ext.z, 0.f);
+      }
+      st.ray_o[slot] = make_float4(its.p.x, its.p.y, its.p.z, 0.f);   // next origin == shadow-ray origin
+    }
+    const uint32_t qn = wave_push(&st.ctr->n_ray[parity ^ 1u], alive);
+    if (alive) q_next[qn] = slot;
+    const uint32_t qs = wave_push(&st.ctr->n_shadow, want_shadow);
+    if (want_shadow) st.q_shadow[qs] = slot;
+  }
+}
+
+// queue bookkeeping between bounces (1 thread)
+__global__ void k_advance(BatchState st, uint32_t parity) {
+  BatchCounters* c = st.ctr;
+  c->total_closest += c->n_ray[parity];
+  c->total_shadow += c->n_shadow;
+  c->n_ray[parity] = 0;
+  for (uint32_t k = 0; k < kNumTags; k++) c->n_hit[k] = 0;
+  c->n_shadow = 0;
+  c->head_ray = 0;
+  c->head_shadow = 0;
+}
+
+// ------------------------------------------------------------ reconstruction
+
+// 25 Gaussian tap weights per block (uniform over the block because the
+// sub-pixel offset is per block): reconstruction.glsl:27-28,43-44.
+__global__ void k_recon_weights(const hj_image_block* blocks, uint32_t num_blocks, float stddev, float* wtab) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= num_blocks * 25u) return;
+  const uint32_t bi = i / 25u, t = i % 25u;
+  const int dx = (int)(t / 5u) - 2, dy = (int)(t % 5u) - 2;
+  const float g = -1.0f / ((2.0f * stddev) * stddev);
+  const float c0 = hj_exp(g * 4.0f);
+  const float sx = ((float)dx + blocks[bi].sample_offset[0]) - 0.5f;
+  const float sy = ((float)dy + blocks[bi].sample_offset[1]) - 0.5f;
+  wtab[i] = hj_exp(g * (sx * sx + sy * sy)) - c0;
+}
+
+// One thread per output pixel; gathers, IN BLOCK ORDER, what every block of
+// the batch splats onto it.  Per-pixel addition order == the reference's
+// serial per-block dispatch order (reconstruction.glsl:22-66, main.rs:1316-1355).
+__global__ __launch_bounds__(256) void k_reconstruct(BatchState st, const float* __restrict__ wtab,
+                                                     float4* __restrict__ accum, uint32_t W, uint32_t H) {
+  const int tx0 = (int)(blockIdx.x * 16u), ty0 = (int)(blockIdx.y * 16u);
+  const int x = tx0 + (int)(threadIdx.x & 15u), y = ty0 + (int)(threadIdx.x >> 4);
+  const bool inimg = x < (int)W && y < (int)H;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (inimg) acc = accum[(size_t)y * W + x];
+  for (uint32_t bi = 0; bi < st.num_blocks; bi++) {
+    const hj_image_block b = st.blocks[bi];
+    const int ox = (int)b.origin[0], oy = (int)b.origin[1], Dx = (int)b.dimension[0], Dy = (int)b.dimension[1];
+    // tile-level (wave-uniform) cull
+    if (tx0 + 15 < ox - 2 || tx0 >= ox + Dx + 2 || ty0 + 15 < oy - 2 || ty0 >= oy + Dy + 2) continue;
+    const int lx = x - ox, ly = y - oy;
+    if (!inimg || lx < -2 || lx >= Dx + 2 || ly < -2 || ly >= Dy + 2) continue;
+    const uint32_t sbase = bi * kSlotsPerBlock;
+    v3 nc = V(0, 0, 0);
+    if (lx >= 0 && lx < Dx && ly >= 0 && ly < Dy) nc = xyz(st.smp_nd[sbase + (uint32_t)ly * HJ_BLOCK_SIZE + (uint32_t)lx]);
+    for (int dx = -2; dx <= 2; dx++) {
+      if (lx + dx < 0 || lx + dx >= Dx) continue;
+      for (int dy = -2; dy <= 2; dy++) {
+        if (ly + dy < 0 || ly + dy >= Dy) continue;
+        float w = wtab[bi * 25u + (uint32_t)((dx + 2) * 5 + (dy + 2))];
+        if (w < 0.0f) continue;
+        const uint32_t sp = sbase + (uint32_t)(ly + dy) * HJ_BLOCK_SIZE + (uint32_t)(lx + dx);
+        const float4 nd = st.smp_nd[sp];
+        const v3 no = xyz(nd) - nc;
+        w *= hj_exp(-(dot3(no, no) * 2.0f));
+        const float4 c = st.smp_rgb[sp];
+        const float v0 = w * c.x, v1 = w * c.y, v2 = w * c.z, v3_ = w * c.w;
+        if (v0 != v0 || v1 != v1 || v2 != v2 || v3_ != v3_) continue;
+        acc.x += v0; acc.y += v1; acc.z += v2; acc.w += v3_;
+      }
+    }
+  }
+  if (inimg) accum[(size_t)y * W + x] = acc;
+}
+
+}  // namespace hj

@@ -1,0 +1,137 @@
+"""ctypes mirror of the device C ABI (include/hijiki_hip.h -> libhijiki_hip.so).
+
+`Renderer` plays the role of the reference's `Renderer` (src/main.rs:1143-1424)
+for the hot path only: scene upload, the per-block render loop, read-back.
+There is no CPU fallback: without the HIP library or a GPU every call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.environ.get("HIJIKI_HIP_LIB", os.path.join(_HERE, "lib", "libhijiki_hip.so"))
+_LIB = None
+
+# every symbol include/hijiki_hip.h declares
+EXPORTS = ("hj_context_create", "hj_context_destroy", "hj_last_error", "hj_version", "hj_default_render_opts",
+           "hj_scene_upload", "hj_framebuffer_create", "hj_framebuffer_clear", "hj_framebuffer_device_ptr",
+           "hj_framebuffer_read", "hj_framebuffer_resolve", "hj_render_blocks", "hj_render_frame", "hj_block_seed",
+           "hj_pass_offset")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise ImportError(f"{HIP_LIB_PATH} missing: run `make hip` (or __graft_entry__.build()); "
+                              "the HIP path has no fallback")
+        L = C.CDLL(HIP_LIB_PATH)
+        vp = C.c_void_p
+        L.hj_context_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.hj_context_destroy.argtypes = [vp]
+        L.hj_context_destroy.restype = None
+        L.hj_last_error.argtypes = [vp]
+        L.hj_last_error.restype = C.c_char_p
+        L.hj_version.restype = C.c_uint32
+        L.hj_default_render_opts.argtypes = [C.POINTER(abi.RenderOpts)]
+        L.hj_default_render_opts.restype = None
+        L.hj_scene_upload.argtypes = [vp, C.POINTER(abi.SceneDesc)]
+        L.hj_framebuffer_create.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+        L.hj_framebuffer_clear.argtypes = [vp]
+        L.hj_framebuffer_device_ptr.argtypes = [vp]
+        L.hj_framebuffer_device_ptr.restype = vp
+        L.hj_framebuffer_read.argtypes = [vp, C.POINTER(C.c_float)]
+        L.hj_framebuffer_resolve.argtypes = [vp, C.POINTER(C.c_float)]
+        L.hj_render_blocks.argtypes = [vp, C.POINTER(abi.ImageBlock), C.c_size_t, C.POINTER(abi.RenderOpts),
+                                       C.POINTER(abi.RenderStats)]
+        L.hj_render_frame.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                      C.POINTER(abi.RenderOpts), C.POINTER(abi.RenderStats)]
+        L.hj_block_seed.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.hj_block_seed.restype = C.c_uint32
+        L.hj_pass_offset.argtypes = [C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]
+        L.hj_pass_offset.restype = None
+        _LIB = L
+    return _LIB
+
+
+def default_opts():
+    o = abi.RenderOpts()
+    lib().hj_default_render_opts(C.byref(o))
+    return o
+
+
+def stats_dict(st):
+    return {n: getattr(st, n) for n, _ in abi.RenderStats._fields_}
+
+
+class Renderer:
+    """One GPU context: scene + framebuffer + render calls."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib().hj_context_create(device, C.byref(self._h))
+        if rc != abi.HJ_OK:
+            raise abi.HijikiError(rc, lib().hj_last_error(None).decode())
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().hj_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != abi.HJ_OK:
+            raise abi.HijikiError(rc, lib().hj_last_error(self._h).decode())
+
+    def upload_scene(self, compiled):
+        desc = compiled.desc if hasattr(compiled, "desc") else compiled
+        self._check(lib().hj_scene_upload(self._h, C.byref(desc)))
+
+    def create_framebuffer(self, width, height, external_device_ptr=None):
+        self._check(lib().hj_framebuffer_create(self._h, width, height, external_device_ptr))
+        self.width, self.height = width, height
+
+    def clear(self):
+        self._check(lib().hj_framebuffer_clear(self._h))
+
+    @property
+    def framebuffer_ptr(self):
+        return lib().hj_framebuffer_device_ptr(self._h)
+
+    def render_blocks(self, blocks, opts=None):
+        st = abi.RenderStats()
+        n = len(blocks)
+        self._check(lib().hj_render_blocks(self._h, blocks, n, C.byref(opts) if opts is not None else None,
+                                           C.byref(st)))
+        return stats_dict(st)
+
+    def render_frame(self, spp, master_seed, pass_begin=0, pass_end=None, rank=0, world=1, opts=None):
+        st = abi.RenderStats()
+        pass_end = spp if pass_end is None else pass_end
+        self._check(lib().hj_render_frame(self._h, spp, master_seed, pass_begin, pass_end, rank, world,
+                                          C.byref(opts) if opts is not None else None, C.byref(st)))
+        return stats_dict(st)
+
+    def read(self):
+        """(H, W, 4) float32 accumulation image (sum w*rgb, sum w)."""
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        self._check(lib().hj_framebuffer_read(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def resolve(self):
+        """(H, W, 3) float32 rgb / w (src/main.rs:1399)."""
+        out = np.zeros((self.height, self.width, 3), np.float32)
+        self._check(lib().hj_framebuffer_resolve(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out

@@ -149,8 +149,11 @@ typedef struct hj_render_opts {
   uint32_t max_bounces;    /* 1000                                                            */
   uint32_t rr_start;       /* roulette applies when bounce > rr_start - 1, i.e. 4 -> b > 3    */
   uint32_t batch_blocks;   /* blocks traced per wavefront batch; 0 = library default          */
-  uint32_t _reserved[2];
+  uint32_t flags;          /* HJ_RENDER_* bits                                                */
+  uint32_t _reserved;
 } hj_render_opts;
+
+#define HJ_RENDER_TIME_KERNELS 1u  /* bracket every kernel class with HIP events (fills *_ms in stats) */
 
 /* Per-render statistics (device counters; all in units of events). */
 typedef struct hj_render_stats {
