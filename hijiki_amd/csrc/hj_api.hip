@@ -238,7 +238,7 @@ struct Timer {
 };
 
 int render_batch(hj_context* ctx, const hj_image_block* blocks, uint32_t nb, const hj_render_opts& o, Timer& tm,
-                 hj_render_stats* stats) {
+                 hj_render_stats* stats, bool reconstruct = true) {
   int rc = ensure_batch(ctx, std::max<uint32_t>(nb, 1));
   if (rc != HJ_OK) return rc;
   hj::BatchState st = ctx->st;
@@ -272,12 +272,15 @@ int render_batch(hj_context* ctx, const hj_image_block* blocks, uint32_t nb, con
     HJ_HIP(ctx, hipStreamSynchronize(s));
     if (*ctx->h_count == 0) break;
   }
-  int ev = tm.begin(EV_RECON);
+  int ev = -1;
+  if (reconstruct) {
+  ev = tm.begin(EV_RECON);
   hipLaunchKernelGGL(hj::k_recon_weights, dim3((nb * 25 + 255) / 256), dim3(256), 0, s, st.blocks, nb, o.recon_stddev,
                      static_cast<float*>(ctx->d_wtab.p));
   hipLaunchKernelGGL(hj::k_reconstruct, dim3((ctx->width + 15) / 16, (ctx->height + 15) / 16), dim3(256), 0, s, st,
                      static_cast<const float*>(ctx->d_wtab.p), ctx->accum, ctx->width, ctx->height);
   tm.end(ev);
+  }
   HJ_HIP(ctx, hipMemcpyAsync(ctx->h_ctr, st.ctr, sizeof(hj::BatchCounters), hipMemcpyDeviceToHost, s));
   HJ_HIP(ctx, hipStreamSynchronize(s));
   HJ_HIP(ctx, hipGetLastError());
@@ -581,6 +584,66 @@ int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed, uint32_
   }
   if (stats) *stats = total;
   return rc;
+}
+
+int hj_debug_trace(hj_context* ctx, const float* rays, size_t n, uint32_t use_bvh, uint32_t any_hit, float* hits) {
+  if (!ctx) return HJ_ERR_INVALID;
+  if (!ctx->have_scene) return set_error(ctx, HJ_ERR_STATE, "trace before hj_scene_upload");
+  if (n == 0) return HJ_OK;
+  if (!rays || !hits) return set_error(ctx, HJ_ERR_INVALID, "null argument");
+  if (n > 0x7FFFFFFFu) return set_error(ctx, HJ_ERR_INVALID, "too many rays");
+  HJ_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf d_rays, d_hits;
+  int rc = dev_alloc(ctx, d_rays, n * 8 * sizeof(float));
+  if (rc == HJ_OK) rc = dev_alloc(ctx, d_hits, n * sizeof(float4));
+  if (rc == HJ_OK) {
+    hipError_t e = hipMemcpyAsync(d_rays.p, rays, n * 8 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    const dim3 grid((unsigned)((n + hj::kBlockThreads - 1) / hj::kBlockThreads)), blk(hj::kBlockThreads);
+    const float* r = static_cast<const float*>(d_rays.p);
+    float4* h = static_cast<float4*>(d_hits.p);
+    const uint32_t cnt = (uint32_t)n;
+    if (e == hipSuccess) {
+      if (use_bvh && any_hit) hipLaunchKernelGGL((hj::k_debug_trace<true, true>), grid, blk, 0, ctx->stream, ctx->scene, r, cnt, h);
+      else if (use_bvh) hipLaunchKernelGGL((hj::k_debug_trace<true, false>), grid, blk, 0, ctx->stream, ctx->scene, r, cnt, h);
+      else if (any_hit) hipLaunchKernelGGL((hj::k_debug_trace<false, true>), grid, blk, 0, ctx->stream, ctx->scene, r, cnt, h);
+      else hipLaunchKernelGGL((hj::k_debug_trace<false, false>), grid, blk, 0, ctx->stream, ctx->scene, r, cnt, h);
+      e = hipMemcpyAsync(hits, d_hits.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) rc = set_error(ctx, HJ_ERR_DEVICE, "hj_debug_trace: %s", hipGetErrorString(e));
+  }
+  d_rays.release();
+  d_hits.release();
+  return rc;
+}
+
+int hj_debug_samples(hj_context* ctx, const hj_image_block* block, const hj_render_opts* opts, float* samples) {
+  if (!ctx) return HJ_ERR_INVALID;
+  if (!ctx->have_scene) return set_error(ctx, HJ_ERR_STATE, "render before hj_scene_upload");
+  if (!block || !samples) return set_error(ctx, HJ_ERR_INVALID, "null argument");
+  if (block->dimension[0] == 0 || block->dimension[1] == 0 || block->dimension[0] > HJ_BLOCK_SIZE || block->dimension[1] > HJ_BLOCK_SIZE)
+    return set_error(ctx, HJ_ERR_INVALID, "block dimension outside (0,128]");
+  hj_render_opts o;
+  if (opts) o = *opts;
+  else hj_default_render_opts(&o);
+  int rc = check_opts(ctx, o);
+  if (rc != HJ_OK) return rc;
+  HJ_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->events_used = 0;
+  Timer tm{ctx, false};
+  rc = render_batch(ctx, block, 1, o, tm, nullptr, /*reconstruct=*/false);
+  if (rc != HJ_OK) return rc;
+  std::vector<float4> rgb(hj::kSlotsPerBlock), nd(hj::kSlotsPerBlock);
+  HJ_HIP(ctx, hipMemcpy(rgb.data(), ctx->st.smp_rgb, sizeof(float4) * hj::kSlotsPerBlock, hipMemcpyDeviceToHost));
+  HJ_HIP(ctx, hipMemcpy(nd.data(), ctx->st.smp_nd, sizeof(float4) * hj::kSlotsPerBlock, hipMemcpyDeviceToHost));
+  for (uint32_t y = 0; y < block->dimension[1]; y++)
+    for (uint32_t x = 0; x < block->dimension[0]; x++) {
+      float* out = samples + ((size_t)y * block->dimension[0] + x) * 8;
+      const float4 a = rgb[y * HJ_BLOCK_SIZE + x], b = nd[y * HJ_BLOCK_SIZE + x];
+      out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+    }
+  return HJ_OK;
 }
 
 uint32_t hj_block_seed(uint64_t master, uint32_t pass, uint32_t j) { return hijiki::block_seed(master, pass, j); }

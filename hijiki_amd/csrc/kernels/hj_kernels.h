@@ -491,6 +491,19 @@ __global__ void k_advance(BatchState st, uint32_t parity) {
   c->head_shadow = 0;
 }
 
+// Probe kernel behind hj_debug_trace: arbitrary rays -> raw hit records.
+template <bool USE_BVH, bool ANYHIT>
+__global__ __launch_bounds__(kBlockThreads) void k_debug_trace(DeviceScene sc, const float* __restrict__ rays, uint32_t n,
+                                                               float4* __restrict__ hits) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r8 = rays + (size_t)i * 8;
+  Ray r; r.o = V(r8[0], r8[1], r8[2]); r.d = V(r8[3], r8[4], r8[5]); r.tmin = r8[6]; r.tmax = r8[7];
+  RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f;
+  const bool hit = traverse<USE_BVH, ANYHIT>(sc, r, h);
+  hits[i] = make_float4(__int_as_float(hit ? h.id : -1), hit ? h.t : 0.f, hit ? h.u : 0.f, hit ? h.v : 0.f);
+}
+
 // ------------------------------------------------------------ reconstruction
 
 // 25 Gaussian tap weights per block (uniform over the block because the

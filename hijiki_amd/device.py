@@ -19,7 +19,7 @@ _LIB = None
 EXPORTS = ("hj_context_create", "hj_context_destroy", "hj_last_error", "hj_version", "hj_default_render_opts",
            "hj_scene_upload", "hj_framebuffer_create", "hj_framebuffer_clear", "hj_framebuffer_device_ptr",
            "hj_framebuffer_read", "hj_framebuffer_resolve", "hj_render_blocks", "hj_render_frame", "hj_block_seed",
-           "hj_pass_offset")
+           "hj_pass_offset", "hj_debug_trace", "hj_debug_samples")
 
 
 def lib():
@@ -49,6 +49,8 @@ def lib():
                                        C.POINTER(abi.RenderStats)]
         L.hj_render_frame.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.POINTER(abi.RenderOpts), C.POINTER(abi.RenderStats)]
+        L.hj_debug_trace.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+        L.hj_debug_samples.argtypes = [vp, C.POINTER(abi.ImageBlock), C.POINTER(abi.RenderOpts), C.POINTER(C.c_float)]
         L.hj_block_seed.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         L.hj_block_seed.restype = C.c_uint32
         L.hj_pass_offset.argtypes = [C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]
@@ -123,6 +125,22 @@ class Renderer:
         self._check(lib().hj_render_frame(self._h, spp, master_seed, pass_begin, pass_end, rank, world,
                                           C.byref(opts) if opts is not None else None, C.byref(st)))
         return stats_dict(st)
+
+    def trace(self, rays, use_bvh=True, any_hit=False):
+        """intersectScene for (n,8) rays -> ids (n,) int32, t, u, v (n,) float32 (raw hit, before populate)."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        hits = np.zeros((len(rays), 4), np.float32)
+        fp = C.POINTER(C.c_float)
+        self._check(lib().hj_debug_trace(self._h, rays.ctypes.data_as(fp), len(rays), int(use_bvh), int(any_hit),
+                                         hits.ctypes.data_as(fp)))
+        return hits[:, 0].copy().view(np.int32), hits[:, 1], hits[:, 2], hits[:, 3]
+
+    def samples(self, block, opts=None):
+        """Intermediate image of one block: (dim_y, dim_x, 8) = (rgb, 1, normal, depth)."""
+        out = np.zeros((block.dimension[1], block.dimension[0], 8), np.float32)
+        self._check(lib().hj_debug_samples(self._h, C.byref(block), C.byref(opts) if opts is not None else None,
+                                           out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
 
     def read(self):
         """(H, W, 4) float32 accumulation image (sum w*rgb, sum w)."""

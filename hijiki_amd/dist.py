@@ -1,0 +1,87 @@
+"""Multi-GPU tile sharding: one process per GPU, one RCCL reduce of the framebuffer.
+
+The path shards by ImageBlock: block j of every pass belongs to
+rank j mod world, every rank accumulates its blocks (and their 2-pixel aprons)
+into a private full-frame RGBA32F buffer that starts at zero, and one
+sum-reduce over xGMI (`torch.distributed`, backend "nccl" == RCCL) produces the
+frame on rank 0.  The reference has no multi-GPU path; this is the exchange
+step BASELINE.json defines.  torch is plumbing here (device memory for the
+shared framebuffer + the collective); the rendering is the C ABI's.
+"""
+import os
+
+import numpy as np
+import torch  # noqa: F401  (before libhijiki_hip.so is loaded: one HIP runtime per process)
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def owned_blocks(num_blocks_per_pass, rank, world):
+    """Block indices (within a pass) that `rank` renders — the C ABI's hj_render_frame uses the same rule."""
+    return list(range(rank, num_blocks_per_pass, world))
+
+
+def init_process_group(backend=None):
+    """Idempotent init from the torchrun environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+    import torch
+    import torch.distributed as dist
+    rank, world, local = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def reduce_framebuffer(fb, root=0, all_ranks=False):
+    """Sum the per-rank accumulation buffers (torch tensor, in place).  No-op for world == 1."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return fb
+    if all_ranks:
+        dist.all_reduce(fb, op=dist.ReduceOp.SUM)
+    else:
+        dist.reduce(fb, dst=root, op=dist.ReduceOp.SUM)
+    return fb
+
+
+class ShardedRenderer:
+    """A `device.Renderer` whose framebuffer is a torch CUDA tensor, so RCCL can reduce it in place."""
+
+    def __init__(self, compiled, width, height, local_rank=None):
+        import torch
+        from . import device
+        rank, world, local = env_rank_world()
+        self.rank, self.world = rank, world
+        self.local = local if local_rank is None else local_rank
+        torch.cuda.set_device(self.local)
+        self.fb = torch.zeros((height, width, 4), dtype=torch.float32, device=f"cuda:{self.local}")
+        self.renderer = device.Renderer(self.local)
+        self.renderer.upload_scene(compiled)
+        self.renderer.create_framebuffer(width, height, external_device_ptr=self.fb.data_ptr())
+        self.width, self.height = width, height
+
+    def render_frame(self, spp, master_seed, opts=None, reduce=True):
+        """Zero the buffer, render this rank's blocks of all passes, reduce to rank 0.  Returns the stats dict."""
+        import torch
+        self.fb.zero_()
+        torch.cuda.synchronize(self.local)      # the C ABI renders on its own stream
+        stats = self.renderer.render_frame(spp, master_seed, rank=self.rank, world=self.world, opts=opts)
+        if reduce:
+            reduce_framebuffer(self.fb, root=0)
+        return stats
+
+    def image(self):
+        """Resolved rgb/w on the host (valid on rank 0 after a reduce)."""
+        acc = self.fb.cpu().numpy()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return acc[..., :3] / acc[..., 3:4]
+
+    def close(self):
+        self.renderer.close()

@@ -234,6 +234,22 @@ int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed,
                     uint32_t rank, uint32_t world,
                     const hj_render_opts* opts, hj_render_stats* stats);
 
+/* ------------------------------------------------------------------- probes */
+
+/* Function-level probes used by the parity tests (no counterpart in the
+ * reference; they expose intermediate values of the same kernels).
+ * hj_debug_trace: intersectScene (shader/scene.glsl:92-175) for caller-given
+ *   rays.  rays = n x 8 floats (origin.xyz, direction.xyz, tMin, tMax);
+ *   hits = n x 4 floats (objectID as int32 bits or -1, t, u, v of the raw hit
+ *   before populate*).  any_hit != 0 stops at the first accepted hit (the
+ *   shadow-ray form): then only `objectID >= 0` is meaningful.
+ * hj_debug_samples: the intermediate image of ONE block (layers 0 and 1 of
+ *   shader/render.glsl:172-173): dimension.y x dimension.x x 8 floats
+ *   (radiance rgb, 1, first-hit normal xyz, first-hit t), no reconstruction,
+ *   framebuffer untouched. */
+int hj_debug_trace(hj_context* ctx, const float* rays, size_t n, uint32_t use_bvh, uint32_t any_hit, float* hits);
+int hj_debug_samples(hj_context* ctx, const hj_image_block* block, const hj_render_opts* opts, float* samples);
+
 /* The deterministic replacement of `rand::random()` in the block generator.
  * Pure functions (no context); the same definitions are used by the host
  * library's ImageBlockGenerator and restated by the oracle. */

@@ -218,13 +218,16 @@ static inline v3 rand_barycentric(uint32_t* s) {
 
 typedef struct { v3 o, d; float tmin, tmax; } ray_t;
 /* shader/render.glsl:39-46 */
-typedef struct { int id; float t; v3 p, n; float u, v; v3 ft, fb, fn; } its_t;
+typedef struct { int id; float t; v3 p, n; float u, v; v3 ft, fb, fn; float raw_u, raw_v; } its_t;
 /* shader/render.glsl:48-52 */
 typedef struct { v3 p, n; float pdf; } srec_t;
 
+/* Work counters of the REFERENCE algorithm (closest-hit walks for camera/bounce rays and for shadow
+ * rays alike); they define the algorithmic bytes of SURVEY.md §8(d).  nodes/tri/sphere/quad count the
+ * closest (camera + bounce) calls, the shadow_* ones the intersectScene(shadowRay) calls. */
 typedef struct hjo_counters {
   uint64_t paths, closest_calls, shadow_calls, nodes, tri_tests, sphere_tests, quad_tests,
-      hits, nee_evals, bounces;
+      hits, nee_evals, shadow_nodes, shadow_tri_tests, shadow_sphere_tests, shadow_quad_tests, shadow_hits;
 } hjo_counters;
 
 typedef struct {
@@ -233,6 +236,12 @@ typedef struct {
   int use_bvh;
   hjo_counters* ctr;
 } scene_t;
+
+typedef struct { uint64_t *nodes, *tri, *sphere, *quad; } walk_ctr;
+static inline walk_ctr closest_ctr(hjo_counters* c) { walk_ctr w = {&c->nodes, &c->tri_tests, &c->sphere_tests, &c->quad_tests}; return w; }
+static inline walk_ctr shadow_ctr(hjo_counters* c) {
+  walk_ctr w = {&c->shadow_nodes, &c->shadow_tri_tests, &c->shadow_sphere_tests, &c->shadow_quad_tests}; return w;
+}
 
 static inline v3 ld3(const float* p) { return V(p[0], p[1], p[2]); }
 
@@ -333,8 +342,7 @@ static inline void populate_quad(const hj_quad* qd, its_t* its) {
 }
 
 /* shader/scene.glsl:97-175 — both the USE_BVH and the linear-scan branch */
-static int intersect_scene(const scene_t* S, ray_t ray, its_t* its) {
-  hjo_counters* c = S->ctr;
+static int intersect_scene(const scene_t* S, ray_t ray, its_t* its, walk_ctr c) {
   its->id = -1;
   const uint32_t ns = S->ns, nq = S->nq, nt = S->nt;
   if (S->use_bvh) {
@@ -344,13 +352,13 @@ static int intersect_scene(const scene_t* S, ray_t ray, its_t* its) {
     v3 off = V(-(ray.o.x * inv.x), -(ray.o.y * inv.y), -(ray.o.z * inv.z));
     for (uint32_t cur = 0; cur < nn;) {
       const hj_bvh_node* nd = &bvh[cur];
-      c->nodes++;
+      (*c.nodes)++;
       uint32_t shape = nd->shape_index, ex = nd->exit_index;
       if (shape != HJ_BVH_INNER) {
         int hit;
-        if (shape < ns) { hit = intersect_sphere(&ray, &S->sc->spheres[shape], its); c->sphere_tests++; }
-        else if (shape < ns + nq) { hit = intersect_quad(&ray, &S->sc->quads[shape - ns], its); c->quad_tests++; }
-        else { hit = intersect_triangle(S, &ray, shape - ns - nq, its); c->tri_tests++; }
+        if (shape < ns) { hit = intersect_sphere(&ray, &S->sc->spheres[shape], its); (*c.sphere)++; }
+        else if (shape < ns + nq) { hit = intersect_quad(&ray, &S->sc->quads[shape - ns], its); (*c.quad)++; }
+        else { hit = intersect_triangle(S, &ray, shape - ns - nq, its); (*c.tri)++; }
         if (hit) { ray.tmax = its->t - M_EPSF; its->id = (int)shape; }
         cur = ex;
       } else {
@@ -366,19 +374,20 @@ static int intersect_scene(const scene_t* S, ray_t ray, its_t* its) {
   } else {
     if (ns > 100 || nq > 100) return 0;   /* scene.glsl:135-138 "failsafe" */
     for (uint32_t i = 0; i < ns; i++) {
-      c->sphere_tests++;
+      (*c.sphere)++;
       if (intersect_sphere(&ray, &S->sc->spheres[i], its)) { ray.tmax = its->t - M_EPSF; its->id = (int)i; }
     }
     for (uint32_t i = 0; i < nq; i++) {
-      c->quad_tests++;
+      (*c.quad)++;
       if (intersect_quad(&ray, &S->sc->quads[i], its)) { ray.tmax = its->t - M_EPSF; its->id = (int)(ns + i); }
     }
     for (uint32_t i = 0; i < nt; i++) {
-      c->tri_tests++;
+      (*c.tri)++;
       if (intersect_triangle(S, &ray, i, its)) { ray.tmax = its->t - M_EPSF; its->id = (int)(ns + nq + i); }
     }
   }
   if (its->id == -1) return 0;
+  its->raw_u = its->u; its->raw_v = its->v;   /* probe only: the hit's own (u,v) before populate* overwrites uv */
   its->p = V(fmaf(its->t, ray.d.x, ray.o.x), fmaf(its->t, ray.d.y, ray.o.y), fmaf(its->t, ray.d.z, ray.o.z));
   uint32_t id = (uint32_t)its->id;
   if (id < ns) populate_sphere(&S->sc->spheres[id], its);
@@ -590,8 +599,8 @@ static void integrate_ray(const scene_t* S, ray_t ray, uint32_t* rng, uint32_t m
   its_t its; memset(&its, 0, sizeof its);
   for (uint32_t bounce = 0; bounce < max_bounces; bounce++) {
     c->closest_calls++;
-    if (!intersect_scene(S, ray, &its)) break;
-    c->hits++; c->bounces++;
+    if (!intersect_scene(S, ray, &its, closest_ctr(c))) break;
+    c->hits++;
     if (bounce == 0) { out->depth = its.t; out->n[0] = its.n.x; out->n[1] = its.n.y; out->n[2] = its.n.z; }
     uint32_t mat = S->sc->materials[its.id];
     uint32_t tag = mat >> HJ_MATERIAL_TAG_SHIFT, midx = mat & HJ_MATERIAL_INDEX_MASK;
@@ -606,7 +615,9 @@ static void integrate_ray(const scene_t* S, ray_t ray, uint32_t* rng, uint32_t m
       if (len3(imp) > M_EPSF && dot3(sh.d, its.n) > 0.0f) {
         its_t dummy; memset(&dummy, 0, sizeof dummy);
         c->shadow_calls++;
-        if (!intersect_scene(S, sh, &dummy)) {   /* scene.glsl:92-96: full closest hit */
+        int occluded = intersect_scene(S, sh, &dummy, shadow_ctr(c));   /* scene.glsl:92-96: full closest hit */
+        c->shadow_hits += (uint64_t)occluded;
+        if (!occluded) {
           v3 f = eval_bsdf(S, mat, sh.d, &its);
           total = v_add(total, v_mul(v_mul(T, f), imp));
         }
@@ -708,8 +719,9 @@ struct job {
 
 static void* worker_main(void* arg) {
   worker_t* w = (worker_t*)arg; job_t* J = w->job;
+  hjo_counters local; memset(&local, 0, sizeof local);   /* on this thread's stack: no false sharing between workers */
   scene_t S; S.sc = J->sc; S.ns = (uint32_t)J->sc->num_spheres; S.nq = (uint32_t)J->sc->num_quads;
-  S.nt = (uint32_t)J->sc->num_triangles; S.use_bvh = (int)J->opts->use_bvh; S.ctr = &w->ctr;
+  S.nt = (uint32_t)J->sc->num_triangles; S.use_bvh = (int)J->opts->use_bvh; S.ctr = &local;
   const size_t chunks_per_block = (HJ_BLOCK_SIZE + ROW_CHUNK - 1) / ROW_CHUNK;
   for (;;) {
     pthread_barrier_wait(&J->bar);            /* batch start */
@@ -731,6 +743,7 @@ static void* worker_main(void* arg) {
       reconstruct_block_rows(&J->blocks[J->batch_begin + bi], J->opts, J->smp[bi], J->accum, J->W, J->H, gy0, gy1);
     pthread_barrier_wait(&J->bar);            /* batch end */
   }
+  w->ctr = local;
   return NULL;
 }
 
@@ -874,7 +887,7 @@ HJO_EXPORT int hjo_intersect(const hj_scene_desc* sc, int use_bvh, const float* 
     const float* r = &rays[i * 8];
     ray_t ray; ray.o = V(r[0], r[1], r[2]); ray.d = V(r[3], r[4], r[5]); ray.tmin = r[6]; ray.tmax = r[7];
     its_t its; memset(&its, 0, sizeof its);
-    int hit = intersect_scene(&S, ray, &its);
+    int hit = intersect_scene(&S, ray, &its, closest_ctr(&c));
     int32_t id = hit ? its.id : -1;
     memcpy(&hits[i * 4], &id, 4);
     hits[i * 4 + 1] = hit ? its.t : 0.0f;
@@ -887,8 +900,8 @@ HJO_EXPORT int hjo_intersect(const hj_scene_desc* sc, int use_bvh, const float* 
         f[11] = its.fb.x; f[12] = its.fb.y; f[13] = its.fb.z;
       }
     }
-    hits[i * 4 + 2] = hit ? its.u : 0.0f;
-    hits[i * 4 + 3] = hit ? its.v : 0.0f;
+    hits[i * 4 + 2] = hit ? its.raw_u : 0.0f;
+    hits[i * 4 + 3] = hit ? its.raw_v : 0.0f;
   }
   return HJ_OK;
 }

@@ -16,7 +16,9 @@ _LIB = None
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("paths", "closest_calls", "shadow_calls", "nodes", "tri_tests",
-                                           "sphere_tests", "quad_tests", "hits", "nee_evals", "bounces")]
+                                           "sphere_tests", "quad_tests", "hits", "nee_evals", "shadow_nodes",
+                                           "shadow_tri_tests", "shadow_sphere_tests", "shadow_quad_tests",
+                                           "shadow_hits")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  Importing torch BEFORE
+# libhijiki_hip.so is loaded makes the dynamic linker resolve the library's NEEDED libamdhip64.so.7 to the copy
+# torch already mapped; the other order leaves two runtimes in the process and torch then sees no GPU.
+import torch  # noqa: E402,F401
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,0 +1,256 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+All arithmetic on the path is IEEE binary32 under the pinned numeric contract HJ-NUM-1, so the bar is EXACT
+equality of the RGBA32F accumulation buffer (tolerance 0 ulp), not BASELINE.json's per-pixel L2 < 1e-4.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from hijiki_amd import abi, device, host
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def render(r, cs, W, H, blocks, opts=None):
+    r.upload_scene(cs)
+    r.create_framebuffer(W, H)
+    st = r.render_blocks(blocks, opts)
+    return r.read(), st
+
+
+def assert_same(got, want, what):
+    bad = (bits(got) != bits(want)).any(axis=-1)
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} pixels differ, max |d| = {np.nanmax(np.abs(got - want))}"
+
+
+@pytest.mark.parametrize("name", ["cbox_64x64x4", "cbox_spheres_64x64x4", "cbox_cboard_96x40x3"])
+def test_golden_fixtures(gpu_renderer, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    W, H, spp, seed, kind = (int(g[k]) for k in ("width", "height", "spp", "seed", "kind"))
+    cs = host.Scene.synthetic(kind).compile()
+    blocks = host.make_blocks(W, H, spp, seed)
+    got, st = render(gpu_renderer, cs, W, H, blocks)
+    assert_same(got, g["accum"], name)
+    ctr = dict(zip(g["counter_names"].tolist(), g["counters"].tolist()))
+    assert st["paths"] == ctr["paths"] and st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"]
+    smp = gpu_renderer.samples(blocks[0])
+    assert (bits(smp) == bits(g["samples0"])).all()
+
+
+def test_config1_cbox_256x256_4spp(gpu_renderer, oracle, cbox):
+    """BASELINE.json configs[0]: the CPU-runnable case, whole image, exact."""
+    W = H = 256
+    blocks = host.make_blocks(W, H, 4, 1)
+    want, ctr, _ = oracle.render_blocks(cbox, blocks, W, H)
+    got, st = render(gpu_renderer, cbox, W, H, blocks)
+    assert_same(got, want, "C1")
+    assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"]
+    a, b = oracle.resolve(want), oracle.resolve(got)
+    assert float(np.sqrt(np.mean((a - b) ** 2))) < 1e-4       # the bar BASELINE.json states; actual: 0
+
+
+def test_divergent_materials_and_many_bounces(gpu_renderer, oracle, cbox_spheres):
+    """configs[2] shape (mirror + dielectric spheres): long specular chains, 5-way material sort."""
+    W, H = 256, 128
+    blocks = host.make_blocks(W, H, 6, 11)
+    want, ctr, _ = oracle.render_blocks(cbox_spheres, blocks, W, H)
+    got, st = render(gpu_renderer, cbox_spheres, W, H, blocks)
+    assert_same(got, want, "spheres")
+    assert ctr["sphere_tests"] > 0 and st["bounce_rounds"] > 30
+
+
+def test_tinted_dielectric_extinction(gpu_renderer, oracle):
+    s = host.Scene.synthetic(host.SYNTH_CBOX, mesh_triangles=320)
+    m = s.add_dielectric(1.5, extinction=(0.5, 1.5, 3.0))       # DielectricMaterial::tinted (src/main.rs:135-139)
+    s.add_sphere((0.3, 1.0, 0.2), 0.3, m)
+    cs = s.compile()
+    W = H = 128
+    blocks = host.make_blocks(W, H, 8, 5)
+    want, _, _ = oracle.render_blocks(cs, blocks, W, H)
+    got, _ = render(gpu_renderer, cs, W, H, blocks)
+    assert_same(got, want, "tinted")
+
+
+def test_quads_and_emissive_sphere(gpu_renderer, oracle):
+    """Shape-API completeness: quad shapes (never produced by the OBJ path) and a sphere light."""
+    s = host.Scene()
+    s.set_camera_cbox()
+    white, red = s.add_diffuse((0.7, 0.7, 0.7)), s.add_diffuse((0.6, 0.1, 0.1))
+    lamp = s.add_emissive((20, 18, 15))
+    cb = s.add_diffuse_cboard((0.9, 0.9, 0.2), 0.13, (0.1, 0.2, 0.8), 0.21)
+    s.add_quad((-1, 0, 1), (2, 0, 0), (0, 0, -2), white)        # floor, normal +y
+    s.add_quad((-1, 0, -1), (2, 0, 0), (0, 1.6, 0), red)        # back wall, normal +z
+    s.add_quad((-1, 0, 1), (0, 0, -2), (0, 1.6, 0), cb)         # left wall (quad uv = hit uv)
+    s.add_sphere((0.2, 1.3, 0.0), 0.15, lamp)
+    s.add_sphere((-0.3, 0.3, 0.2), 0.3, cb)
+    s.add_sphere((0.5, 0.25, 0.4), 0.25, s.add_mirror())
+    cs = s.compile()
+    W, H = 192, 128
+    blocks = host.make_blocks(W, H, 5, 21)
+    want, ctr, _ = oracle.render_blocks(cs, blocks, W, H)
+    got, _ = render(gpu_renderer, cs, W, H, blocks)
+    assert ctr["quad_tests"] > 0 and ctr["sphere_tests"] > 0
+    assert_same(got, want, "quads")
+
+
+def test_linear_scan_mode(gpu_renderer, oracle, cbox_small):
+    """USE_BVH == 0, the reference CLI's default (src/main.rs:1432-1434, scene.glsl:134-158)."""
+    W, H = 128, 128
+    blocks = host.make_blocks(W, H, 2, 8)
+    o = device.default_opts()
+    o.use_bvh = 0
+    want, _, _ = oracle.render_blocks(cbox_small, blocks, W, H, opts=o)
+    got, _ = render(gpu_renderer, cbox_small, W, H, blocks, o)
+    assert_same(got, want, "linear scan")
+
+
+def test_ragged_image_and_small_batches(gpu_renderer, oracle, cbox_small):
+    """Image size not a multiple of 128 (edge blocks 72 x 8), and a batch size that cuts passes in pieces."""
+    W, H = 200, 136
+    blocks = host.make_blocks(W, H, 3, 2)
+    want, _, _ = oracle.render_blocks(cbox_small, blocks, W, H)
+    for batch in (0, 1, 5):
+        o = device.default_opts()
+        o.batch_blocks = batch
+        got, st = render(gpu_renderer, cbox_small, W, H, blocks, o)
+        assert_same(got, want, f"ragged batch={batch}")
+        assert st["paths"] == W * H * 3
+
+
+def test_bounce_limit_and_roulette_options(gpu_renderer, oracle, cbox_small):
+    W = H = 128
+    blocks = host.make_blocks(W, H, 2, 3)
+    for mb, rr in ((1, 4), (3, 1), (6, 0)):
+        o = device.default_opts()
+        o.max_bounces, o.rr_start = mb, rr
+        want, _, _ = oracle.render_blocks(cbox_small, blocks, W, H, opts=o)
+        got, _ = render(gpu_renderer, cbox_small, W, H, blocks, o)
+        assert_same(got, want, f"max_bounces={mb} rr_start={rr}")
+
+
+def test_custom_blocks_any_order_and_overlap(gpu_renderer, oracle, cbox_small):
+    """hj_render_blocks takes ANY block list (as Renderer::render does): odd sizes, overlaps, seed 61 (RNG fixed point)."""
+    W, H = 256, 256
+    mk = lambda i, seed, ox, oy, dx, dy, off: abi.ImageBlock(id=i, seed=seed, origin=(ox, oy), dimension=(dx, dy),
+                                                            original_dimension=(W, H), sample_offset=off)
+    blocks = (abi.ImageBlock * 5)(mk(0, 61, 0, 0, 128, 128, (0.5, 0.5)), mk(1, 7, 100, 60, 64, 100, (0.1, 0.9)),
+                                  mk(2, 8, 100, 60, 64, 100, (0.7, 0.2)), mk(3, 9, 128, 128, 128, 128, (0.0, 0.0)),
+                                  mk(4, 10, 250, 250, 6, 6, (0.99, 0.99)))
+    want, _, _ = oracle.render_blocks(cbox_small, blocks, W, H)
+    got, _ = render(gpu_renderer, cbox_small, W, H, blocks)
+    assert_same(got, want, "custom blocks")
+
+
+def test_traversal_probe_matches_oracle(gpu_renderer, oracle, cbox):
+    g = np.load(os.path.join(GOLD, "cbox_rays.npz"))
+    gpu_renderer.upload_scene(cbox)
+    ids, t, u, v = gpu_renderer.trace(g["rays"])
+    assert (ids == g["ids"]).all() and (bits(t) == bits(g["t"])).all()
+    assert (bits(u) == bits(g["u"])).all() and (bits(v) == bits(g["v"])).all()
+    # random rays, incl. shadow-style windows
+    r = np.random.default_rng(5)
+    n = 20000
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = np.stack([r.uniform(-0.95, 0.95, n), r.uniform(0.05, 1.5, n), r.uniform(-1.0, 0.95, n)], 1)
+    d = r.normal(size=(n, 3))
+    rays[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 6], rays[:, 7] = 2e-4, r.uniform(0.1, 3.0, n)
+    oi, ot, ou, ov = oracle.intersect(cbox, rays)
+    gi, gt, gu, gv = gpu_renderer.trace(rays)
+    assert (gi == oi).all() and (bits(gt) == bits(ot)).all() and (bits(gu) == bits(ou)).all() and (bits(gv) == bits(ov)).all()
+    # any-hit (the shadow kernel's walk) is boolean-equivalent to the reference's closest-hit shadow query
+    ai, *_ = gpu_renderer.trace(rays, any_hit=True)
+    assert ((ai >= 0) == (oi >= 0)).all()
+
+
+def test_rendering_is_deterministic_and_additive(gpu_renderer, cbox):
+    """Size-independent properties at a larger size: run-to-run bitwise determinism, and passes [0,a)+[a,b)
+    accumulated by two calls == one call (the framebuffer is a running sum)."""
+    W = H = 512
+    r = gpu_renderer
+    r.upload_scene(cbox)
+    r.create_framebuffer(W, H)
+    r.render_frame(16, 3)
+    a = r.read()
+    r.clear()
+    r.render_frame(16, 3, pass_begin=0, pass_end=5)
+    r.render_frame(16, 3, pass_begin=5, pass_end=16)
+    b = r.read()
+    assert (bits(a) == bits(b)).all()
+    assert np.isfinite(a).all() and (a[..., 3] > 0).all()
+
+
+def test_tile_sharding_sums_to_the_full_frame(gpu_renderer, cbox):
+    """N 'virtual ranks' on one device: the sum of the per-rank buffers equals the 1-GPU frame exactly away from
+    block borders and within a few ulp on the 2-pixel aprons (different association of the same addends)."""
+    W = H = 384
+    r = gpu_renderer
+    r.upload_scene(cbox)
+    r.create_framebuffer(W, H)
+    r.render_frame(6, 9)
+    full = r.read()
+    for world in (2, 3):
+        parts = []
+        for rank in range(world):
+            r.clear()
+            r.render_frame(6, 9, rank=rank, world=world)
+            parts.append(r.read().astype(np.float64))
+        total = np.sum(parts, axis=0)
+        interior = np.ones((H, W), bool)
+        for e in (128, 256):
+            interior[e - 2:e + 2, :] = False
+            interior[:, e - 2:e + 2] = False
+        assert (total[interior].astype(np.float32) == full[interior]).all()
+        np.testing.assert_allclose(total, full, rtol=3e-6, atol=1e-6)
+
+
+def test_error_paths(gpu_renderer, cbox_small):
+    r = device.Renderer(0)
+    blocks = host.make_blocks(128, 128, 1, 1)
+    with pytest.raises(abi.HijikiError) as e:
+        r.render_blocks(blocks)
+    assert e.value.status == abi.HJ_ERR_STATE                    # no scene yet
+    r.upload_scene(cbox_small)
+    with pytest.raises(abi.HijikiError) as e:
+        r.render_blocks(blocks)
+    assert e.value.status == abi.HJ_ERR_STATE                    # no framebuffer yet
+    r.create_framebuffer(256, 128)
+    with pytest.raises(abi.HijikiError) as e:
+        r.render_blocks(blocks)                                  # original_dimension != framebuffer
+    assert e.value.status == abi.HJ_ERR_INVALID
+    o = device.default_opts()
+    o.recon_radius = 3
+    with pytest.raises(abi.HijikiError) as e:
+        r.render_blocks(host.make_blocks(256, 128, 1, 1), o)
+    assert e.value.status == abi.HJ_ERR_UNSUPPORTED
+    # a scene whose BVH could loop forever is rejected at upload
+    bad = cbox_small.bvh.copy()
+    bad[5, 7] = 2
+    desc = abi.SceneDesc.from_buffer_copy(bytes(cbox_small.desc))
+    desc.bvh = bad.ctypes.data_as(C.POINTER(abi.BvhNode))
+    with pytest.raises(abi.HijikiError) as e:
+        r.upload_scene(desc)
+    assert e.value.status == abi.HJ_ERR_INVALID and "forward" in str(e.value)
+    r.close()
+
+
+def test_external_framebuffer_torch_tensor(cbox_small, oracle):
+    """The RCCL path accumulates straight into a torch CUDA tensor handed over as a raw device pointer."""
+    import torch
+    W = H = 128
+    fb = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    blocks = host.make_blocks(W, H, 2, 4)
+    with device.Renderer(0) as r:
+        r.upload_scene(cbox_small)
+        r.create_framebuffer(W, H, external_device_ptr=fb.data_ptr())
+        r.render_blocks(blocks)
+    want, _, _ = oracle.render_blocks(cbox_small, blocks, W, H)
+    assert (bits(fb.cpu().numpy()) == bits(want)).all()

@@ -1,0 +1,188 @@
+"""Scene compiler invariants (mirror of Scene::compile, reference src/main.rs:173-357) and the block generator."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from hijiki_amd import abi, host
+
+
+def check_bvh(cs):
+    bvh, f = cs.bvh, cs.bvh_f32
+    n_shapes = cs.num_shapes
+    N = len(bvh)
+    assert N == 2 * n_shapes - 1                                   # one shape per leaf
+    shape, ex = bvh[:, 3], bvh[:, 7]
+    leaves = shape != abi.BVH_INNER
+    assert leaves.sum() == n_shapes and sorted(shape[leaves].tolist()) == list(range(n_shapes))
+    assert (ex > np.arange(N)).all()                               # exits only move forward -> the walk terminates
+    root_exit = abi.BVH_ROOT_EXIT if N <= abi.BVH_ROOT_EXIT else N
+    assert ex[0] == root_exit and ex[N - 1] == root_exit
+    # pre-order structure: left child = i+1, right child = exit of the left child; a right child inherits the exit
+    stack = [(0, root_exit)]
+    seen = 0
+    while stack:
+        i, e = stack.pop()
+        seen += 1
+        assert ex[i] == e
+        if shape[i] == abi.BVH_INNER:
+            l = i + 1
+            r = ex[l]
+            assert i < l < r < N
+            stack.append((r, e))
+            stack.append((l, r))
+            # child boxes lie inside the parent's box
+            for c in (l, r):
+                assert (f[c, 0:3] >= f[i, 0:3] - 1e-6).all() and (f[c, 4:7] <= f[i, 4:7] + 1e-6).all()
+    assert seen == N
+    return leaves
+
+
+def shape_box(cs, g):
+    ns, nq = cs.desc.num_spheres, cs.desc.num_quads
+    if g < ns:
+        c = cs.spheres[g]
+        return c[:3] - c[3], c[:3] + c[3]
+    if g < ns + nq:
+        q = cs.quads[g - ns]
+        o, e1, e2 = q[0:3], q[4:7], q[8:11]
+        p = np.stack([o, o + e1, o + e2, o + e1 + e2])
+        return p.min(0), p.max(0)
+    p = cs.vertices[cs.triangles[g - ns - nq]][:, 0:3]
+    return p.min(0), p.max(0)
+
+
+def test_cbox_compile_counts_and_invariants(cbox):
+    d = cbox.desc
+    # 6332 triangles, 12663 nodes, 2 emitter triangles
+    assert (d.num_triangles, d.num_bvh_nodes, d.num_emitters, d.num_spheres, d.num_quads) == (6332, 12663, 2, 0, 0)
+    leaves = check_bvh(cbox)
+    f, b = cbox.bvh_f32, cbox.bvh
+    for i in np.flatnonzero(leaves)[::97]:
+        lo, hi = shape_box(cbox, int(b[i, 3]))
+        np.testing.assert_array_equal(f[i, 0:3], lo.astype(np.float32))     # leaf box = shape AABB (src/main.rs:74-79)
+        np.testing.assert_array_equal(f[i, 4:7], hi.astype(np.float32))
+
+
+def test_material_words_and_emitter_table(cbox_spheres):
+    cs = cbox_spheres
+    d = cs.desc
+    assert d.num_spheres == 2 and d.num_materials == d.num_spheres + d.num_triangles
+    mats = cs.materials
+    # spheres come first in the global index space (src/main.rs:278-287): mirror, then dielectric
+    assert mats[0] >> 24 == abi.MAT_MIRROR and mats[1] >> 24 == abi.MAT_DIELECTRIC
+    assert d.dielectric[0].eta == 1.5 and tuple(d.dielectric[0].extinction) == (0, 0, 0)   # DielectricMaterial::clear
+    em = cs.emitters
+    assert len(em) == 2
+    for e in em:
+        assert mats[e[0]] >> 24 == abi.MAT_EMISSIVE
+    pdf = em[:, 1].view(np.float32)
+    cdf = em[:, 2].view(np.float32)
+    assert (pdf == np.float32(0.5)).all() and cdf.tolist() == [0.5, 1.0]          # src/main.rs:300-307
+    check_bvh(cs)
+
+
+def test_packed_buffer_follows_reference_order(cbox_spheres):
+    cs = cbox_spheres
+    buf = cs.packed()
+    d = cs.desc
+    pad = lambda n: (n + 255) & ~255
+    sizes = [64, d.num_bvh_nodes * 32, d.num_spheres * 16, d.num_quads * 48, d.num_triangles * 12, d.num_vertices * 32,
+             d.num_materials * 4, d.num_emitters * 16, d.num_diffuse * 16, d.num_diffusecb * 32, d.num_dielectric * 16,
+             d.num_emissive * 16]                                                  # src/main.rs:314-326
+    assert len(buf) == sum(pad(s) for s in sizes)
+    info = abi.SceneInfo.from_buffer_copy(buf[:64].tobytes())
+    assert (info.num_spheres, info.num_triangles, info.num_emitters) == (2, d.num_triangles, 2)
+    assert abs(info.camera.fov - 27.7) < 1e-6 and abs(info.camera.position[2] - 5.41) < 1e-6
+    off = pad(64)
+    np.testing.assert_array_equal(buf[off:off + 32 * 3].view(np.uint32).reshape(3, 8), cs.bvh[:3])
+    off += pad(sizes[1])
+    np.testing.assert_array_equal(buf[off:off + 32].view(np.float32).reshape(2, 4), cs.spheres)
+
+
+def test_scene_api_errors():
+    s = host.Scene()
+    m = s.add_diffuse((1, 1, 1))
+    with pytest.raises(abi.HijikiError):
+        s.add_sphere((0, 0, 0), 1.0, m + 5)                 # unknown material
+    with pytest.raises(abi.HijikiError):
+        s.add_triangle(0, 1, 2, m)                          # unknown vertices
+    s.add_sphere((0, 0, 0), 1.0, m)
+    with pytest.raises(abi.HijikiError) as e:
+        s.compile()                                         # reference panics on a 1-shape scene (src/main.rs:230)
+    assert "2 shapes" in str(e.value)
+    s.add_sphere((3, 0, 0), 1.0, m)
+    cs = s.compile()
+    assert cs.desc.num_bvh_nodes == 3 and cs.desc.num_emitters == 0
+
+
+def test_mixed_shapes_global_index_space():
+    s = host.Scene()
+    d = s.add_diffuse((1, 1, 1))
+    e = s.add_emissive((1, 2, 3))
+    v0 = s.add_vertices([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 0, 1]] * 3)
+    s.add_triangle(v0, v0 + 1, v0 + 2, d)                   # object 0
+    s.add_quad((5, 0, 0), (1, 0, 0), (0, 1, 0), e)          # object 1
+    s.add_sphere((9, 0, 0), 0.5, d)                         # object 2
+    s.add_sphere((12, 0, 0), 0.5, e)                        # object 3
+    cs = s.compile()
+    # global order: spheres (obj 2, 3), quads (obj 1), triangles (obj 0)
+    tags = (cs.materials >> 24).tolist()
+    assert tags == [abi.MAT_DIFFUSE, abi.MAT_EMISSIVE, abi.MAT_EMISSIVE, abi.MAT_DIFFUSE]
+    assert cs.emitters[:, 0].tolist() == [1, 2]
+    check_bvh(cs)
+
+
+def test_degenerate_inputs_still_build():
+    s = host.Scene()
+    m = s.add_diffuse((1, 1, 1))
+    for _ in range(33):
+        s.add_sphere((1, 2, 3), 0.5, m)                     # identical centroids -> median splits
+    check_bvh(s.compile())
+
+
+def test_block_generator_semantics():
+    W, H, spp, seed = 300, 200, 3, 42
+    blocks = host.make_blocks(W, H, spp, seed)
+    per = host.blocks_per_pass(W, H)
+    assert per == 3 * 2 and len(blocks) == per * spp
+    offs = []
+    for k in range(spp + 1):
+        o = (C.c_float * 2)()
+        host.lib().hj_pass_offset(seed, k, o)
+        assert 0 <= o[0] < 1 and 0 <= o[1] < 1
+        offs.append((o[0], o[1]))
+    for i, b in enumerate(blocks):
+        p, j = divmod(i, per)
+        assert b.id == i                                                     # ids run on across passes (main.rs:660-662)
+        assert (b.origin[0], b.origin[1]) == ((j % 3) * 128, (j // 3) * 128)     # raster order
+        assert b.dimension[0] == min(128, W - b.origin[0]) and b.dimension[1] == min(128, H - b.origin[1])
+        assert (b.original_dimension[0], b.original_dimension[1]) == (W, H)
+        assert b.seed == host.lib().hj_block_seed(seed, p, j)
+        # the last block of a pass already carries the NEXT pass's offset (main.rs:664-680)
+        k = p + (1 if j == per - 1 else 0)
+        assert (b.sample_offset[0], b.sample_offset[1]) == offs[k]
+    assert len({b.seed for b in blocks}) == len(blocks)
+    again = host.make_blocks(W, H, spp, seed)
+    assert bytes(again) == bytes(blocks)
+    assert bytes(host.make_blocks(W, H, spp, seed + 1)) != bytes(blocks)
+    # pass sub-range == slice of the full list
+    assert bytes(host.make_blocks(W, H, spp, seed, 1, 2)) == bytes(blocks)[per * 40:2 * per * 40]
+
+
+def test_block_generator_matches_oracle_restatement(oracle):
+    for (W, H, spp, seed) in ((256, 256, 4, 1), (300, 200, 2, 7), (128, 128, 3, 9)):
+        assert bytes(host.make_blocks(W, H, spp, seed)) == bytes(oracle.make_blocks(W, H, spp, seed))
+
+
+def test_block_size_must_be_multiple_of_64():
+    with pytest.raises(abi.HijikiError):
+        host.make_blocks(256, 256, 1, 1, block_size=100)       # assert!(block_size & 63 == 0), main.rs:633
+
+
+def test_large_mesh_root_exit_terminates():
+    cs = host.Scene.synthetic(host.SYNTH_CBOX_MESH, mesh_triangles=600000).compile()
+    N = cs.desc.num_bvh_nodes
+    assert N > abi.BVH_ROOT_EXIT
+    ex = cs.bvh[:, 7]
+    assert (ex > np.arange(N)).all() and ex[0] == N      # the reference's constant 1 000 000 would point INTO the array
