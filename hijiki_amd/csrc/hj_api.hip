@@ -60,8 +60,9 @@ struct hj_context {
   hj::BatchState st{};
   std::vector<DevBuf> batch_bufs;
   DevBuf d_blocks, d_wtab;
-  uint32_t* h_count = nullptr;           // pinned read-back word
-  hj::BatchCounters* h_ctr = nullptr;    // pinned copy of the counters
+  uint32_t num_wg = 2048;                // grid size of every stage kernel (= queue segments)
+  uint32_t* h_counts = nullptr;          // pinned read-back: 4 arrays of num_wg words
+  hipEvent_t ev_count[2] = {nullptr, nullptr};
 
   // timing
   std::vector<EventPair> events;
@@ -198,12 +199,22 @@ int ensure_batch(hj_context* ctx, uint32_t num_blocks) {
   HJ_ALLOC(smp_nd, float4, n)
   HJ_ALLOC(sh_d, float4, n)
   HJ_ALLOC(sh_c, float4, n)
-  HJ_ALLOC(q_ray[0], uint32_t, n)
-  HJ_ALLOC(q_ray[1], uint32_t, n)
-  HJ_ALLOC(q_hit, uint32_t, n * hj::kNumTags)
-  HJ_ALLOC(q_shadow, uint32_t, n)
-  HJ_ALLOC(ctr, hj::BatchCounters, 1)
+  const uint32_t G = ctx->num_wg;
+  const uint32_t segcap = (((cap + 63u) / 64u + G - 1u) / G) * 64u;
+  const size_t qn = (size_t)G * segcap;
+  HJ_ALLOC(q_ray[0], uint32_t, qn)
+  HJ_ALLOC(q_ray[1], uint32_t, qn)
+  HJ_ALLOC(q_hit, uint32_t, qn * hj::kNumTags)
+  HJ_ALLOC(q_shadow, uint32_t, qn)
+  HJ_ALLOC(cnt_ray[0], uint32_t, G)
+  HJ_ALLOC(cnt_ray[1], uint32_t, G)
+  HJ_ALLOC(cnt_hit, uint32_t, (size_t)G * hj::kNumTags)
+  HJ_ALLOC(cnt_shadow, uint32_t, G)
+  HJ_ALLOC(acc_closest, uint32_t, G)
+  HJ_ALLOC(acc_shadow, uint32_t, G)
 #undef HJ_ALLOC
+  st.num_wg = G;
+  st.segcap = segcap;
   if (rc != HJ_OK) {
     release_batch(ctx);
     return rc;
@@ -246,12 +257,20 @@ int render_batch(hj_context* ctx, const hj_image_block* blocks, uint32_t nb, con
   st.num_blocks = nb;
   hipStream_t s = ctx->stream;
   HJ_HIP(ctx, hipMemcpyAsync(ctx->d_blocks.p, blocks, sizeof(hj_image_block) * nb, hipMemcpyHostToDevice, s));
-  HJ_HIP(ctx, hipMemsetAsync(st.ctr, 0, sizeof(hj::BatchCounters), s));
+  const uint32_t G = st.num_wg;
   const dim3 blk(hj::kBlockThreads);
-  const dim3 grid((unsigned)(ctx->num_cus * 8));
+  const dim3 grid(G);
   const bool bvh = o.use_bvh != 0;
   hipLaunchKernelGGL(hj::k_gen_camera, grid, blk, 0, s, st, ctx->scene);
   uint64_t rounds = 0;
+  // The host only needs to know when every queue is empty.  The per-workgroup counts of bounce b are copied
+  // back asynchronously and examined one bounce LATER, so the GPU always has the next round queued.
+  auto alive_after = [&](uint32_t b) -> uint64_t {
+    const uint32_t* c = ctx->h_counts + (size_t)(b & 1u) * G;
+    uint64_t sum = 0;
+    for (uint32_t i = 0; i < G; i++) sum += c[i];
+    return sum;
+  };
   for (uint32_t bounce = 0; bounce < o.max_bounces; bounce++) {
     const uint32_t parity = bounce & 1u;
     const float tmin = bounce == 0 ? hj::kEps : 2.0f * hj::kEps;   // render.glsl:33,132
@@ -266,11 +285,14 @@ int render_batch(hj_context* ctx, const hj_image_block* blocks, uint32_t nb, con
     if (bvh) hipLaunchKernelGGL(hj::k_trace_shadow<true>, grid, blk, 0, s, st, ctx->scene);
     else hipLaunchKernelGGL(hj::k_trace_shadow<false>, grid, blk, 0, s, st, ctx->scene);
     tm.end(ev);
-    hipLaunchKernelGGL(hj::k_advance, dim3(1), dim3(1), 0, s, st, parity);
     rounds++;
-    HJ_HIP(ctx, hipMemcpyAsync(ctx->h_count, &st.ctr->n_ray[parity ^ 1u], sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HJ_HIP(ctx, hipStreamSynchronize(s));
-    if (*ctx->h_count == 0) break;
+    HJ_HIP(ctx, hipMemcpyAsync(ctx->h_counts + (size_t)parity * G, st.cnt_ray[parity ^ 1u], sizeof(uint32_t) * G,
+                               hipMemcpyDeviceToHost, s));
+    HJ_HIP(ctx, hipEventRecord(ctx->ev_count[parity], s));
+    if (bounce >= 1) {
+      HJ_HIP(ctx, hipEventSynchronize(ctx->ev_count[parity ^ 1u]));
+      if (alive_after(bounce - 1) == 0) break;
+    }
   }
   int ev = -1;
   if (reconstruct) {
@@ -281,12 +303,16 @@ int render_batch(hj_context* ctx, const hj_image_block* blocks, uint32_t nb, con
                      static_cast<const float*>(ctx->d_wtab.p), ctx->accum, ctx->width, ctx->height);
   tm.end(ev);
   }
-  HJ_HIP(ctx, hipMemcpyAsync(ctx->h_ctr, st.ctr, sizeof(hj::BatchCounters), hipMemcpyDeviceToHost, s));
+  uint32_t* h_acc = ctx->h_counts + (size_t)2 * G;
+  HJ_HIP(ctx, hipMemcpyAsync(h_acc, st.acc_closest, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, s));
+  HJ_HIP(ctx, hipMemcpyAsync(h_acc + G, st.acc_shadow, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, s));
   HJ_HIP(ctx, hipStreamSynchronize(s));
   HJ_HIP(ctx, hipGetLastError());
   if (stats) {
-    stats->closest_rays += ctx->h_ctr->total_closest;
-    stats->shadow_rays += ctx->h_ctr->total_shadow;
+    for (uint32_t i = 0; i < G; i++) {
+      stats->closest_rays += h_acc[i];
+      stats->shadow_rays += h_acc[G + i];
+    }
     stats->batches += 1;
     stats->bounce_rounds += rounds;
   }
@@ -341,8 +367,10 @@ int hj_context_create(int device, hj_context** out) {
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail(e, "hipGetDeviceProperties");
   ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
-  if ((e = hipHostMalloc((void**)&ctx->h_count, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
-  if ((e = hipHostMalloc((void**)&ctx->h_ctr, sizeof(hj::BatchCounters), hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
+  ctx->num_wg = (uint32_t)ctx->num_cus * 8u;   // 8 workgroups of 4 waves per CU = the 32-wave CU limit
+  if ((e = hipHostMalloc((void**)&ctx->h_counts, sizeof(uint32_t) * 4 * ctx->num_wg, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
+  for (auto& ev : ctx->ev_count)
+    if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   *out = ctx;
   return HJ_OK;
 }
@@ -356,8 +384,9 @@ void hj_context_destroy(hj_context* ctx) {
   ctx->d_blocks.release();
   ctx->d_wtab.release();
   if (ctx->accum && ctx->accum_owned) (void)hipFree(ctx->accum);
-  if (ctx->h_count) (void)hipHostFree(ctx->h_count);
-  if (ctx->h_ctr) (void)hipHostFree(ctx->h_ctr);
+  if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+  for (auto& ev : ctx->ev_count)
+    if (ev) (void)hipEventDestroy(ev);
   for (auto& ep : ctx->events) {
     (void)hipEventDestroy(ep.a);
     (void)hipEventDestroy(ep.b);

@@ -37,18 +37,10 @@ struct DeviceScene {
   float tan_half_fov;           // (float)tan(radians(fov/2)) evaluated in double on the host
 };
 
-// Queue counters of one batch, in device memory (kernels read their trip
-// counts from here, the host only polls n_ray to stop the bounce loop).
-struct BatchCounters {
-  uint32_t n_ray[2];            // current / next ray queue lengths (index = bounce parity)
-  uint32_t n_hit[kNumTags];     // per-material-tag hit queues of the current bounce
-  uint32_t n_shadow;
-  uint32_t head_ray;            // work-fetch heads of the persistent kernels
-  uint32_t head_shadow;
-  uint32_t _pad[2];
-  unsigned long long total_closest, total_shadow, total_paths;
-};
-
+// Queues are partitioned into one private SEGMENT per workgroup: workgroup g of every stage kernel reads and
+// appends only segment g (counts in cnt_*[g], appends through LDS counters), so no stage touches a global
+// atomic.  (The first version used chip-wide queue counters: ~88 M same-address atomics/s bounded every kernel.)
+// Slot -> owner: 64-slot groups are dealt round-robin over the workgroups, so each one samples the whole image.
 struct BatchState {
   // per path slot (slot = block_in_batch * 16384 + ly * 128 + lx)
   float4* ray_o;      // origin.xyz
@@ -61,13 +53,19 @@ struct BatchState {
   float4* smp_nd;     // layer 1: (first-hit normal, first-hit t)
   float4* sh_d;       // shadow ray direction.xyz, tMax
   float4* sh_c;       // pending NEE contribution rgb
-  uint32_t* q_ray[2];
-  uint32_t* q_hit;    // kNumTags segments of `capacity` entries
-  uint32_t* q_shadow;
-  BatchCounters* ctr;
+  uint32_t* q_ray[2]; // [num_wg][segcap] ray queues (index = bounce parity)
+  uint32_t* q_hit;    // [kNumTags][num_wg][segcap] hits binned by material tag
+  uint32_t* q_shadow; // [num_wg][segcap]
+  uint32_t* cnt_ray[2];   // [num_wg]
+  uint32_t* cnt_hit;      // [num_wg][kNumTags]
+  uint32_t* cnt_shadow;   // [num_wg]
+  uint32_t* acc_closest;  // [num_wg] closest-hit rays traced by this workgroup over the batch (stats)
+  uint32_t* acc_shadow;   // [num_wg] shadow rays
   const hj_image_block* blocks;  // the batch's ImageBlocks
   uint32_t num_blocks;
-  uint32_t capacity;             // num slots allocated
+  uint32_t capacity;             // slots allocated
+  uint32_t num_wg;               // grid size of every stage kernel
+  uint32_t segcap;               // entries per queue segment
 };
 
 }  // namespace hj

@@ -12,8 +12,10 @@
 //                                                             roulette -> next ray queue + shadow queue
 //     k_trace_shadow   (shadow queue)    scene.glsl:92-96     any-hit walk (boolean-equivalent to the
 //                                                             reference's closest-hit), adds NEE radiance
-//     k_advance                                               queue bookkeeping (1 thread)
 //   k_recon_weights / k_reconstruct      reconstruction.glsl:22-66
+//
+// Queues are split into one private segment per workgroup (hj_device.h): appends go through LDS counters
+// (wave ballot + one ds_add per wave), never through global atomics.
 //
 // Every path owns its RNG state, so queue order never changes results; the
 // per-path order of radiance additions is the reference's (emission, then
@@ -29,18 +31,25 @@ constexpr int kBlockThreads = 256;
 
 // ---------------------------------------------------------------- helpers
 
-// Wave-aggregated queue append: one atomic per wave, lane order preserved.
+// Wave-aggregated append to a workgroup-private queue: ballot + one LDS atomic per wave, lane order kept.
 // Must be reached by all active lanes of the wave together.
-HJ_DEV uint32_t wave_push(uint32_t* counter, bool pred) {
+HJ_DEV uint32_t lds_push(uint32_t* lds_counter, bool pred) {
   const unsigned long long mask = __ballot(pred);
   if (mask == 0) return 0xFFFFFFFFu;
   const uint32_t lane = __lane_id();
   const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
   uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  if (lane == leader) base = atomicAdd(lds_counter, (uint32_t)__popcll(mask));
   base = __shfl(base, (int)leader);
   const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
   return pred ? base + prefix : 0xFFFFFFFFu;
+}
+
+// Next 64-entry chunk of the workgroup's segment (dynamic balance between its waves).
+HJ_DEV uint32_t lds_fetch_chunk(uint32_t* lds_head) {
+  uint32_t c = 0;
+  if (__lane_id() == 0) c = atomicAdd(lds_head, 64u);
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
 }
 
 struct Ray { v3 o, d; float tmin, tmax; };
@@ -249,11 +258,16 @@ HJ_DEV v3 checkerboard(const DeviceScene& sc, uint32_t idx, float u, float v) {
 
 // reference shader/render.glsl:26-36,149-162
 __global__ __launch_bounds__(kBlockThreads) void k_gen_camera(BatchState st, DeviceScene sc) {
+  __shared__ uint32_t s_cnt;
+  const uint32_t g = blockIdx.x, G = st.num_wg;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
   const uint32_t total = st.num_blocks * kSlotsPerBlock;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x;
-  for (uint32_t base = first - (threadIdx.x & 63u); base < total; base += stride) {
-    const uint32_t slot = base + (threadIdx.x & 63u);
+  uint32_t* __restrict__ q = st.q_ray[0] + (size_t)g * st.segcap;
+  // this workgroup owns the 64-slot groups g, g+G, g+2G, ...
+  for (uint32_t grp = g + wave * G; grp * 64u < total; grp += waves * G) {
+    const uint32_t slot = grp * 64u + lane;
     bool valid = slot < total;
     hj_image_block b;
     uint32_t lx = 0, ly = 0;
@@ -279,10 +293,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_gen_camera(BatchState st, Dev
       const float qw = sc.camera.rotation[3];
       const v3 vv = V(x, -y, -1.0f);
       const float tw = qw * 0.0f - dot3(qv, vv);
-      v3 c1 = cross3(qv, vv);
+      const v3 c1 = cross3(qv, vv);
       const v3 txyz = V((c1.x + qv.x * 0.0f) + vv.x * qw, (c1.y + qv.y * 0.0f) + vv.y * qw, (c1.z + qv.z * 0.0f) + vv.z * qw);
       const v3 cq = -qv;
-      v3 c2 = cross3(txyz, cq);
+      const v3 c2 = cross3(txyz, cq);
       const v3 rot = V((c2.x + txyz.x * qw) + cq.x * tw, (c2.y + txyz.y * qw) + cq.y * tw, (c2.z + txyz.z * qw) + cq.z * tw);
       const v3 d = normalize3(rot);
       st.ray_o[slot] = make_float4(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2], 0.f);
@@ -293,20 +307,32 @@ __global__ __launch_bounds__(kBlockThreads) void k_gen_camera(BatchState st, Dev
       st.smp_rgb[slot] = make_float4(0.f, 0.f, 0.f, 1.f);
       st.smp_nd[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const uint32_t qi = wave_push(&st.ctr->n_ray[0], valid);
-    if (valid) st.q_ray[0][qi] = slot;
+    const uint32_t qi = lds_push(&s_cnt, valid);
+    if (valid) q[qi] = slot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st.cnt_ray[0][g] = s_cnt;
+    st.acc_closest[g] = 0;
+    st.acc_shadow[g] = 0;
   }
 }
 
 template <bool USE_BVH>
 __global__ __launch_bounds__(kBlockThreads) void k_trace_closest(BatchState st, DeviceScene sc, uint32_t parity,
                                                                  float tmin) {
-  const uint32_t n = st.ctr->n_ray[parity];
-  const uint32_t* __restrict__ q = st.q_ray[parity];
-  const uint32_t stride = gridDim.x * blockDim.x;
+  __shared__ uint32_t s_head, s_cnt[kNumTags];
+  const uint32_t g = blockIdx.x, G = st.num_wg;
   const uint32_t lane = threadIdx.x & 63u;
-  for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < n; base += stride) {
-    const uint32_t i = base + lane;
+  const uint32_t n = st.cnt_ray[parity][g];
+  if (threadIdx.x == 0) s_head = 0;
+  if (threadIdx.x < kNumTags) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t* __restrict__ q = st.q_ray[parity] + (size_t)g * st.segcap;
+  for (;;) {
+    const uint32_t c = lds_fetch_chunk(&s_head);
+    if (c >= n) break;
+    const uint32_t i = c + lane;
     const bool valid = i < n;
     uint32_t slot = 0, tag = 0xFFu;
     if (valid) {
@@ -319,29 +345,42 @@ __global__ __launch_bounds__(kBlockThreads) void k_trace_closest(BatchState st, 
         tag = sc.materials[h.id] >> HJ_MATERIAL_TAG_SHIFT;
       }
     }
-    // bin hits by material tag (divergent BSDF sort): one ballot + one atomic per tag per wave
+    // bin hits by material tag (divergent-BSDF sort): one ballot + one LDS atomic per tag per wave
 #pragma unroll
     for (uint32_t k = 0; k < kNumTags; k++) {
-      const uint32_t qi = wave_push(&st.ctr->n_hit[k], tag == k);
-      if (tag == k) st.q_hit[(size_t)k * st.capacity + qi] = slot;
+      const uint32_t qi = lds_push(&s_cnt[k], tag == k);
+      if (tag == k) st.q_hit[((size_t)k * G + g) * st.segcap + qi] = slot;
     }
   }
+  __syncthreads();
+  if (threadIdx.x < kNumTags) st.cnt_hit[g * kNumTags + threadIdx.x] = s_cnt[threadIdx.x];
+  if (threadIdx.x == 0) st.acc_closest[g] += n;
 }
 
 template <bool USE_BVH>
 __global__ __launch_bounds__(kBlockThreads) void k_trace_shadow(BatchState st, DeviceScene sc) {
-  const uint32_t n = st.ctr->n_shadow;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const uint32_t slot = st.q_shadow[i];
-    const float4 o = st.ray_o[slot], d = st.sh_d[slot];
-    Ray r; r.o = xyz(o); r.d = xyz(d); r.tmin = 2.0f * kEps; r.tmax = d.w;
-    RawHit h;
-    if (!traverse<USE_BVH, true>(sc, r, h)) {
-      const float4 c = st.sh_c[slot];
-      float4 s = st.smp_rgb[slot];
-      s.x += c.x; s.y += c.y; s.z += c.z;      // render.glsl:123
-      st.smp_rgb[slot] = s;
+  __shared__ uint32_t s_head;
+  const uint32_t g = blockIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t n = st.cnt_shadow[g];
+  if (threadIdx.x == 0) s_head = 0;
+  __syncthreads();
+  const uint32_t* __restrict__ q = st.q_shadow + (size_t)g * st.segcap;
+  for (;;) {
+    const uint32_t c = lds_fetch_chunk(&s_head);
+    if (c >= n) break;
+    const uint32_t i = c + lane;
+    if (i < n) {
+      const uint32_t slot = q[i];
+      const float4 o = st.ray_o[slot], d = st.sh_d[slot];
+      Ray r; r.o = xyz(o); r.d = xyz(d); r.tmin = 2.0f * kEps; r.tmax = d.w;
+      RawHit h;
+      if (!traverse<USE_BVH, true>(sc, r, h)) {
+        const float4 cc = st.sh_c[slot];
+        float4 s = st.smp_rgb[slot];
+        s.x += cc.x; s.y += cc.y; s.z += cc.z;      // render.glsl:123
+        st.smp_rgb[slot] = s;
+      }
     }
   }
 }
@@ -349,27 +388,24 @@ __global__ __launch_bounds__(kBlockThreads) void k_trace_shadow(BatchState st, D
 // reference shader/scene.glsl:160-175 (populate), render.glsl:102-144, material.glsl:18-91
 __global__ __launch_bounds__(kBlockThreads) void k_shade(BatchState st, DeviceScene sc, uint32_t parity,
                                                          uint32_t bounce, uint32_t max_bounces, uint32_t rr_start) {
-  // virtual wave index -> (tag segment, first entry): every wave shades ONE material tag
-  uint32_t cnt[kNumTags], wbase[kNumTags + 1];
-  wbase[0] = 0;
-#pragma unroll
-  for (uint32_t k = 0; k < kNumTags; k++) {
-    cnt[k] = st.ctr->n_hit[k];
-    wbase[k + 1] = wbase[k] + (cnt[k] + 63u) / 64u;
-  }
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t waves_per_grid = gridDim.x * (blockDim.x / 64u);
-  uint32_t* __restrict__ q_next = st.q_ray[parity ^ 1u];
-  for (uint32_t w = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; w < wbase[kNumTags]; w += waves_per_grid) {
-    uint32_t tag = 0;
-#pragma unroll
-    for (uint32_t k = 1; k < kNumTags; k++) tag += (w >= wbase[k]) ? 1u : 0u;
-    const uint32_t i = (w - wbase[tag]) * 64u + lane;
-    const bool valid = i < cnt[tag];
+  __shared__ uint32_t s_next, s_shadow;
+  const uint32_t g = blockIdx.x, G = st.num_wg;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  if (threadIdx.x == 0) { s_next = 0; s_shadow = 0; }
+  __syncthreads();
+  uint32_t* __restrict__ q_next = st.q_ray[parity ^ 1u] + (size_t)g * st.segcap;
+  uint32_t* __restrict__ q_sh = st.q_shadow + (size_t)g * st.segcap;
+  // one material tag at a time: every wave shades ONE tag (no divergent BSDF switch)
+  for (uint32_t tag = 0; tag < kNumTags; tag++) {
+    const uint32_t n = st.cnt_hit[g * kNumTags + tag];
+    const uint32_t* __restrict__ q = st.q_hit + ((size_t)tag * G + g) * st.segcap;
+    for (uint32_t base = wave * 64u; base < n; base += waves * 64u) {
+    const uint32_t i = base + lane;
+    const bool valid = i < n;
     bool alive = false, want_shadow = false;
     uint32_t slot = 0;
     if (valid) {
-      slot = st.q_hit[(size_t)tag * st.capacity + i];
+      slot = q[i];
       const float4 hr = st.hit[slot];
       const float4 ro4 = st.ray_o[slot], rd4 = st.ray_d[slot];
       const float4 th4 = st.thr[slot];
@@ -472,23 +508,18 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(BatchState st, DeviceSc
       }
       st.ray_o[slot] = make_float4(its.p.x, its.p.y, its.p.z, 0.f);   // next origin == shadow-ray origin
     }
-    const uint32_t qn = wave_push(&st.ctr->n_ray[parity ^ 1u], alive);
+    const uint32_t qn = lds_push(&s_next, alive);
     if (alive) q_next[qn] = slot;
-    const uint32_t qs = wave_push(&st.ctr->n_shadow, want_shadow);
-    if (want_shadow) st.q_shadow[qs] = slot;
+    const uint32_t qs = lds_push(&s_shadow, want_shadow);
+    if (want_shadow) q_sh[qs] = slot;
+    }
   }
-}
-
-// queue bookkeeping between bounces (1 thread)
-__global__ void k_advance(BatchState st, uint32_t parity) {
-  BatchCounters* c = st.ctr;
-  c->total_closest += c->n_ray[parity];
-  c->total_shadow += c->n_shadow;
-  c->n_ray[parity] = 0;
-  for (uint32_t k = 0; k < kNumTags; k++) c->n_hit[k] = 0;
-  c->n_shadow = 0;
-  c->head_ray = 0;
-  c->head_shadow = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st.cnt_ray[parity ^ 1u][g] = s_next;
+    st.cnt_shadow[g] = s_shadow;
+    st.acc_shadow[g] += s_shadow;
+  }
 }
 
 // Probe kernel behind hj_debug_trace: arbitrary rays -> raw hit records.
