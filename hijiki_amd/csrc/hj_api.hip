@@ -441,7 +441,37 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
   static_assert(sizeof(hj_quad) == 3 * sizeof(float4) && sizeof(hj_sphere) == sizeof(float4), "shape records");
   static_assert(sizeof(hj_diffuse_cb) == 2 * sizeof(float4), "checkerboard record");
 #define HJ_UP(expr) do { rc = (expr); if (rc != HJ_OK) { release_scene(ctx); return rc; } } while (0)
-  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->bvh), 2 * s->num_bvh_nodes, &d.nodes));
+  // device node array: hottest (largest surface area) nodes first, explicit left/exit links (kernels/hj_device.h)
+  {
+    const size_t N = s->num_bvh_nodes;
+    std::vector<uint32_t> order(N), map(N);
+    std::vector<float> sa(N);
+    for (size_t i = 0; i < N; i++) {
+      order[i] = (uint32_t)i;
+      const float dx = s->bvh[i].aabb_max[0] - s->bvh[i].aabb_min[0], dy = s->bvh[i].aabb_max[1] - s->bvh[i].aabb_min[1],
+                  dz = s->bvh[i].aabb_max[2] - s->bvh[i].aabb_min[2];
+      sa[i] = (dx >= 0 && dy >= 0 && dz >= 0) ? dx * dy + dy * dz + dz * dx : 0.f;
+    }
+    const size_t hot = std::min<size_t>(hj::kHotNodes, N);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return sa[a] > sa[b]; });
+    std::vector<char> is_hot(N, 0);
+    for (size_t k = 0; k < hot; k++) { map[order[k]] = (uint32_t)k; is_hot[order[k]] = 1; }
+    uint32_t next = (uint32_t)hot;
+    for (size_t i = 0; i < N; i++) if (!is_hot[i]) map[i] = next++;
+    std::vector<float4> dev(2 * N);
+    for (size_t i = 0; i < N; i++) {
+      const hj_bvh_node& nd = s->bvh[i];
+      uint32_t a;
+      if (nd.shape_index != HJ_BVH_INNER) a = nd.shape_index;
+      else a = hj::kInnerFlag | (i + 1 < N ? map[i + 1] : (uint32_t)N);          // left child = next pre-order record
+      const uint32_t b = nd.exit_index < N ? map[nd.exit_index] : (uint32_t)N;    // >= N ends the walk
+      dev[2 * map[i] + 0] = make_float4(nd.aabb_min[0], nd.aabb_min[1], nd.aabb_min[2], __builtin_bit_cast(float, a));
+      dev[2 * map[i] + 1] = make_float4(nd.aabb_max[0], nd.aabb_max[1], nd.aabb_max[2], __builtin_bit_cast(float, b));
+    }
+    d.root = N ? map[0] : 0u;
+    d.num_hot = (uint32_t)hot;
+    HJ_UP(upload(ctx, dev.data(), dev.size(), &d.nodes));
+  }
   HJ_UP(upload(ctx, isect.data(), isect.size(), &d.tri_isect));
   HJ_UP(upload(ctx, shade.data(), shade.size(), &d.tri_shade));
   HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->spheres), s->num_spheres, &d.spheres));

@@ -105,6 +105,25 @@ HJ_DEV bool intersect_shape(const DeviceScene& sc, const Ray& r, uint32_t shape,
   return intersect_triangle(sc, r, shape - sc.ns - sc.nq, h);
 }
 
+// One node of the walk (scene.glsl:103-131).  Both 16-byte halves are consumed and the box test is evaluated
+// BEFORE the leaf/inner decision, with selects only (no branch for the compiler to sink the loads behind): one
+// memory round trip per node.  For a leaf the box result is ignored (leaf boxes are never tested upstream).
+// Returns true when `cur` is a leaf (a = shape index); otherwise advances cur to the left child or the exit.
+HJ_DEV bool node_step(float4 n0, float4 n1, v3 inv, v3 off, const Ray& r, uint32_t& cur, uint32_t& a, uint32_t& ex) {
+  const float tnx = fmaf(n0.x, inv.x, off.x), tpx = fmaf(n1.x, inv.x, off.x);
+  const float tny = fmaf(n0.y, inv.y, off.y), tpy = fmaf(n1.y, inv.y, off.y);
+  const float tnz = fmaf(n0.z, inv.z, off.z), tpz = fmaf(n1.z, inv.z, off.z);
+  const float t0 = f_max(f_max(f_min(tnx, tpx), f_min(tny, tpy)), f_min(tnz, tpz));
+  const float t1 = f_min(f_min(f_max(tnx, tpx), f_max(tny, tpy)), f_max(tnz, tpz));
+  const bool enter = (t0 < t1 + kEps && t0 < r.tmax && t1 > r.tmin);
+  a = __float_as_uint(n0.w);
+  ex = __float_as_uint(n1.w);
+  const bool leaf = (a & kInnerFlag) == 0u;
+  const uint32_t nxt = enter ? (a & ~kInnerFlag) : ex;
+  cur = leaf ? cur : nxt;
+  return leaf;
+}
+
 // reference shader/scene.glsl:97-158.  ANYHIT: stop at the first accepted hit
 // (the shadow overload scene.glsl:92-96 only uses the boolean, and the first
 // accepted hit in visiting order is the same with or without tMax shrinking).
@@ -114,25 +133,25 @@ HJ_DEV bool traverse(const DeviceScene& sc, Ray r, RawHit& h) {
   if (USE_BVH) {
     const v3 inv = V(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     const v3 off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
-    uint32_t cur = 0;
-    while (cur < sc.num_nodes) {
-      const float4 n0 = sc.nodes[2 * cur], n1 = sc.nodes[2 * cur + 1];
-      const uint32_t shape = __float_as_uint(n0.w), ex = __float_as_uint(n1.w);
-      if (shape != HJ_BVH_INNER) {
-        if (intersect_shape(sc, r, shape, h)) {
-          h.id = (int)shape;
-          if (ANYHIT) return true;
-          r.tmax = h.t - kEps;
-        }
-        cur = ex;
-      } else {
-        const float tnx = fmaf(n0.x, inv.x, off.x), tpx = fmaf(n1.x, inv.x, off.x);
-        const float tny = fmaf(n0.y, inv.y, off.y), tpy = fmaf(n1.y, inv.y, off.y);
-        const float tnz = fmaf(n0.z, inv.z, off.z), tpz = fmaf(n1.z, inv.z, off.z);
-        const float t0 = f_max(f_max(f_min(tnx, tpx), f_min(tny, tpy)), f_min(tnz, tpz));
-        const float t1 = f_min(f_min(f_max(tnx, tpx), f_max(tny, tpy)), f_max(tnz, tpz));
-        cur = (t0 < t1 + kEps && t0 < r.tmax && t1 > r.tmin) ? cur + 1 : ex;
+    const uint32_t nn = sc.num_nodes;
+    uint32_t cur = sc.root;
+    // "while-while": every lane first walks inner nodes until it stands on a leaf (or leaves the tree), then the
+    // lanes that reached a leaf run the (much longer) shape test TOGETHER instead of interleaved with box tests.
+    // Visiting order per ray is exactly the reference's pre-order skip-link walk.
+    for (;;) {
+      uint32_t a = 0, ex = 0;
+      bool at_leaf = false;
+      while (cur < nn && !at_leaf) {
+        const float4 n0 = sc.nodes[2 * cur], n1 = sc.nodes[2 * cur + 1];
+        at_leaf = node_step(n0, n1, inv, off, r, cur, a, ex);
       }
+      if (!at_leaf) break;
+      if (intersect_shape(sc, r, a, h)) {   // leaf boxes are never tested (scene.glsl:105-119)
+        h.id = (int)a;
+        if (ANYHIT) return true;
+        r.tmax = h.t - kEps;
+      }
+      cur = ex;
     }
   } else {
     if (sc.ns > 100 || sc.nq > 100) return false;  // scene.glsl:135-138
@@ -146,6 +165,73 @@ HJ_DEV bool traverse(const DeviceScene& sc, Ray r, RawHit& h) {
     }
   }
   return h.id != -1;
+}
+
+// Persistent "while-while" walk with in-wave ray replacement (BVH mode): a lane whose ray has left the tree
+// does not idle until the slowest lane of its wave is done - as soon as kRefillMin lanes are free the wave
+// pulls that many new rays from its workgroup's queue segment (one LDS atomic) and the walk continues.
+// Measured need: with one ray per lane for the lifetime of a wave, VALU instructions of the bounce-ray
+// traversal ran with 9.6 of 64 lanes active (rocprofv3 SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU).
+// Each ray still performs exactly the reference's pre-order skip-link walk (scene.glsl:97-133).
+//   fetch(i, slot, ray)   loads queue entry i
+//   finish(done, slot, h) wave-convergent: called when some lanes are done; `done` lanes have a final result
+constexpr uint32_t kRefillMin = 16;
+
+template <bool ANYHIT, class Fetch, class Finish>
+HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head, const float4* s_n0,
+                             const float4* s_n1, Fetch fetch, Finish finish) {
+  const uint32_t lane = __lane_id();
+  const uint32_t nn = sc.num_nodes, nhot = sc.num_hot;
+  bool active = false, pending = false, exhausted = false;
+  uint32_t slot = 0, cur = 0;
+  Ray r; r.o = V(0, 0, 0); r.d = V(0, 0, 0); r.tmin = 0.f; r.tmax = 0.f;
+  v3 inv = V(0, 0, 0), off = V(0, 0, 0);
+  RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
+  for (;;) {
+    // Service phase: only when enough lanes are free.  Finished lanes keep their result in registers until
+    // then, so that result STORES and new-ray LOADS are issued together, once per phase: vmcnt counts loads and
+    // stores in one in-order counter on gfx950, and a store between two node fetches would stall the walk for
+    // a full write acknowledgement.
+    const unsigned long long idle = __ballot(!active);
+    const uint32_t nidle = (uint32_t)__popcll(idle);
+    if (nidle >= kRefillMin || nidle == 64u) {
+      if (__ballot(pending) != 0) finish(pending, slot, h);
+      pending = false;
+      if (!exhausted) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(s_head, nidle);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (!active) {
+          const uint32_t my = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+          if (my < n) {
+            fetch(my, slot, r);
+            inv = V(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+            off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
+            cur = sc.root; h.id = -1; active = true;
+          }
+        }
+        exhausted = base + nidle >= n;
+      }
+    }
+    if (__ballot(active) == 0) break;
+    uint32_t shape = 0, ex = 0;
+    bool at_leaf = false;
+    while (active && cur < nn && !at_leaf) {
+      float4 n0, n1;
+      if (cur < nhot) { n0 = s_n0[cur]; n1 = s_n1[cur]; }                 // hot node: LDS copy
+      else { n0 = sc.nodes[2 * cur]; n1 = sc.nodes[2 * cur + 1]; }
+      at_leaf = node_step(n0, n1, inv, off, r, cur, shape, ex);
+    }
+    if (active && !at_leaf) { active = false; pending = true; }           // walked off the end of the tree
+    if (at_leaf) {
+      if (intersect_shape(sc, r, shape, h)) {
+        h.id = (int)shape;
+        if (ANYHIT) active = false;           // occluded: nothing to add
+        else r.tmax = h.t - kEps;
+      }
+      cur = ex;
+    }
+  }
 }
 
 // ------------------------------------------------------------ populate (its)
@@ -322,34 +408,51 @@ template <bool USE_BVH>
 __global__ __launch_bounds__(kBlockThreads) void k_trace_closest(BatchState st, DeviceScene sc, uint32_t parity,
                                                                  float tmin) {
   __shared__ uint32_t s_head, s_cnt[kNumTags];
+  __shared__ float4 s_n0[kHotNodes], s_n1[kHotNodes];
   const uint32_t g = blockIdx.x, G = st.num_wg;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t n = st.cnt_ray[parity][g];
   if (threadIdx.x == 0) s_head = 0;
   if (threadIdx.x < kNumTags) s_cnt[threadIdx.x] = 0;
+  if (USE_BVH && n != 0)
+    for (uint32_t i = threadIdx.x; i < sc.num_hot; i += blockDim.x) { s_n0[i] = sc.nodes[2 * i]; s_n1[i] = sc.nodes[2 * i + 1]; }
   __syncthreads();
   const uint32_t* __restrict__ q = st.q_ray[parity] + (size_t)g * st.segcap;
-  for (;;) {
-    const uint32_t c = lds_fetch_chunk(&s_head);
-    if (c >= n) break;
-    const uint32_t i = c + lane;
-    const bool valid = i < n;
-    uint32_t slot = 0, tag = 0xFFu;
-    if (valid) {
-      slot = q[i];
-      const float4 o = st.ray_o[slot], d = st.ray_d[slot];
-      Ray r; r.o = xyz(o); r.d = xyz(d); r.tmin = tmin; r.tmax = kInf;
-      RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f;
-      if (traverse<USE_BVH, false>(sc, r, h)) {
-        st.hit[slot] = make_float4(h.t, __int_as_float(h.id), h.u, h.v);
-        tag = sc.materials[h.id] >> HJ_MATERIAL_TAG_SHIFT;
-      }
+  // bin finished rays by material tag (divergent-BSDF sort): one ballot + one LDS atomic per tag per wave
+  auto finish = [&](bool done, uint32_t slot, const RawHit& h) {
+    uint32_t tag = 0xFFu;
+    if (done && h.id != -1) {
+      st.hit[slot] = make_float4(h.t, __int_as_float(h.id), h.u, h.v);
+      tag = sc.materials[h.id] >> HJ_MATERIAL_TAG_SHIFT;
     }
-    // bin hits by material tag (divergent-BSDF sort): one ballot + one LDS atomic per tag per wave
 #pragma unroll
     for (uint32_t k = 0; k < kNumTags; k++) {
       const uint32_t qi = lds_push(&s_cnt[k], tag == k);
       if (tag == k) st.q_hit[((size_t)k * G + g) * st.segcap + qi] = slot;
+    }
+  };
+  if (USE_BVH) {
+    auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r) {
+      slot = q[i];
+      const float4 o = st.ray_o[slot], d = st.ray_d[slot];
+      r.o = xyz(o); r.d = xyz(d); r.tmin = tmin; r.tmax = kInf;
+    };
+    trace_persistent<false>(sc, n, &s_head, s_n0, s_n1, fetch, finish);
+  } else {
+    for (;;) {
+      const uint32_t c = lds_fetch_chunk(&s_head);
+      if (c >= n) break;
+      const uint32_t i = c + lane;
+      const bool valid = i < n;
+      uint32_t slot = 0;
+      RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
+      if (valid) {
+        slot = q[i];
+        const float4 o = st.ray_o[slot], d = st.ray_d[slot];
+        Ray r; r.o = xyz(o); r.d = xyz(d); r.tmin = tmin; r.tmax = kInf;
+        traverse<false, false>(sc, r, h);
+      }
+      finish(valid, slot, h);
     }
   }
   __syncthreads();
@@ -360,26 +463,41 @@ __global__ __launch_bounds__(kBlockThreads) void k_trace_closest(BatchState st, 
 template <bool USE_BVH>
 __global__ __launch_bounds__(kBlockThreads) void k_trace_shadow(BatchState st, DeviceScene sc) {
   __shared__ uint32_t s_head;
+  __shared__ float4 s_n0[kHotNodes], s_n1[kHotNodes];
   const uint32_t g = blockIdx.x;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t n = st.cnt_shadow[g];
   if (threadIdx.x == 0) s_head = 0;
+  if (USE_BVH && n != 0)
+    for (uint32_t i = threadIdx.x; i < sc.num_hot; i += blockDim.x) { s_n0[i] = sc.nodes[2 * i]; s_n1[i] = sc.nodes[2 * i + 1]; }
   __syncthreads();
   const uint32_t* __restrict__ q = st.q_shadow + (size_t)g * st.segcap;
-  for (;;) {
-    const uint32_t c = lds_fetch_chunk(&s_head);
-    if (c >= n) break;
-    const uint32_t i = c + lane;
-    if (i < n) {
-      const uint32_t slot = q[i];
+  auto add_unoccluded = [&](bool done, uint32_t slot, const RawHit&) {
+    if (done) {
+      const float4 cc = st.sh_c[slot];
+      float4 s = st.smp_rgb[slot];
+      s.x += cc.x; s.y += cc.y; s.z += cc.z;      // render.glsl:123
+      st.smp_rgb[slot] = s;
+    }
+  };
+  if (USE_BVH) {
+    auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r) {
+      slot = q[i];
       const float4 o = st.ray_o[slot], d = st.sh_d[slot];
-      Ray r; r.o = xyz(o); r.d = xyz(d); r.tmin = 2.0f * kEps; r.tmax = d.w;
-      RawHit h;
-      if (!traverse<USE_BVH, true>(sc, r, h)) {
-        const float4 cc = st.sh_c[slot];
-        float4 s = st.smp_rgb[slot];
-        s.x += cc.x; s.y += cc.y; s.z += cc.z;      // render.glsl:123
-        st.smp_rgb[slot] = s;
+      r.o = xyz(o); r.d = xyz(d); r.tmin = 2.0f * kEps; r.tmax = d.w;
+    };
+    trace_persistent<true>(sc, n, &s_head, s_n0, s_n1, fetch, add_unoccluded);
+  } else {
+    for (;;) {
+      const uint32_t c = lds_fetch_chunk(&s_head);
+      if (c >= n) break;
+      const uint32_t i = c + lane;
+      if (i < n) {
+        const uint32_t slot = q[i];
+        const float4 o = st.ray_o[slot], d = st.sh_d[slot];
+        Ray r; r.o = xyz(o); r.d = xyz(d); r.tmin = 2.0f * kEps; r.tmax = d.w;
+        RawHit h;
+        if (!traverse<false, true>(sc, r, h)) add_unoccluded(true, slot, h);
       }
     }
   }

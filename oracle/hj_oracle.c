@@ -237,10 +237,10 @@ typedef struct {
   hjo_counters* ctr;
 } scene_t;
 
-typedef struct { uint64_t *nodes, *tri, *sphere, *quad; } walk_ctr;
-static inline walk_ctr closest_ctr(hjo_counters* c) { walk_ctr w = {&c->nodes, &c->tri_tests, &c->sphere_tests, &c->quad_tests}; return w; }
+typedef struct { uint64_t *nodes, *tri, *sphere, *quad; uint32_t* hist; } walk_ctr;
+static inline walk_ctr closest_ctr(hjo_counters* c) { walk_ctr w = {&c->nodes, &c->tri_tests, &c->sphere_tests, &c->quad_tests, NULL}; return w; }
 static inline walk_ctr shadow_ctr(hjo_counters* c) {
-  walk_ctr w = {&c->shadow_nodes, &c->shadow_tri_tests, &c->shadow_sphere_tests, &c->shadow_quad_tests}; return w;
+  walk_ctr w = {&c->shadow_nodes, &c->shadow_tri_tests, &c->shadow_sphere_tests, &c->shadow_quad_tests, NULL}; return w;
 }
 
 static inline v3 ld3(const float* p) { return V(p[0], p[1], p[2]); }
@@ -353,6 +353,7 @@ static int intersect_scene(const scene_t* S, ray_t ray, its_t* its, walk_ctr c) 
     for (uint32_t cur = 0; cur < nn;) {
       const hj_bvh_node* nd = &bvh[cur];
       (*c.nodes)++;
+      if (c.hist) c.hist[cur]++;
       uint32_t shape = nd->shape_index, ex = nd->exit_index;
       if (shape != HJ_BVH_INNER) {
         int hit;
@@ -878,6 +879,9 @@ HJO_EXPORT void hjo_uniform_sphere(uint32_t* state, float* out3) {
 
 /* rays: n x 8 floats (o.xyz, d.xyz, tmin, tmax).  hits: n x 4 (id as int bits, t, u, v of the
  * raw hit BEFORE populate).  full (optional): n x 16 floats (p3, n3, uv2, t3(frame t), b3, pad2). */
+static uint32_t* g_node_hist = NULL;   /* probe: per-node visit counts of hjo_intersect (single-threaded) */
+HJO_EXPORT void hjo_set_node_histogram(uint32_t* hist) { g_node_hist = hist; }
+
 HJO_EXPORT int hjo_intersect(const hj_scene_desc* sc, int use_bvh, const float* rays, size_t n, float* hits,
                              float* full) {
   hjo_counters c; memset(&c, 0, sizeof c);
@@ -887,7 +891,8 @@ HJO_EXPORT int hjo_intersect(const hj_scene_desc* sc, int use_bvh, const float* 
     const float* r = &rays[i * 8];
     ray_t ray; ray.o = V(r[0], r[1], r[2]); ray.d = V(r[3], r[4], r[5]); ray.tmin = r[6]; ray.tmax = r[7];
     its_t its; memset(&its, 0, sizeof its);
-    int hit = intersect_scene(&S, ray, &its, closest_ctr(&c));
+    walk_ctr wc = closest_ctr(&c); wc.hist = g_node_hist;
+    int hit = intersect_scene(&S, ray, &its, wc);
     int32_t id = hit ? its.id : -1;
     memcpy(&hits[i * 4], &id, 4);
     hits[i * 4 + 1] = hit ? its.t : 0.0f;
