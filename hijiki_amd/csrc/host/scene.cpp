@@ -77,7 +77,8 @@ Aabb Scene::shape_aabb(const Shape& s) const {
 
 namespace {
 
-constexpr int kBins = 16;
+constexpr int kMaxBins = 16;
+constexpr int kBins = 16;   // 32 bins, and ordering the children by surface area or size, measured no better on cbox
 
 struct Builder {
   const std::vector<Aabb>& boxes;
@@ -124,58 +125,63 @@ struct Builder {
         cmax[a] = std::max(cmax[a], c[a]);
       }
     }
+    // binned SAH, all three axes; fall back to a median split of the widest axis
+    size_t mid = lo + (hi - lo) / 2;
+    bool have_split = false;
     int axis = 0;
     float ext = cmax[0] - cmin[0];
     for (int a = 1; a < 3; a++)
       if (cmax[a] - cmin[a] > ext) ext = cmax[a] - cmin[a], axis = a;
-
-    size_t mid = lo + (hi - lo) / 2;
-    bool have_split = false;
-    if (ext > 1e-7f && hi - lo > 2) {
-      // binned SAH along `axis`
-      Aabb bin_box[kBins];
-      size_t bin_cnt[kBins] = {};
-      for (auto& b : bin_box) b = Aabb::empty();
-      float scale = (float)kBins / ext;
-      auto bin_of = [&](uint32_t s) {
-        int b = (int)((centroid(s, axis) - cmin[axis]) * scale);
-        return std::min(std::max(b, 0), kBins - 1);
-      };
-      for (size_t i = lo; i < hi; i++) {
-        int b = bin_of(order[i]);
-        bin_cnt[b]++;
-        bin_box[b].join(boxes[order[i]]);
-      }
-      float right_area[kBins];
-      size_t right_cnt[kBins];
-      Aabb acc = Aabb::empty();
-      size_t cnt = 0;
-      for (int b = kBins - 1; b > 0; b--) {
-        acc.join(bin_box[b]);
-        cnt += bin_cnt[b];
-        right_area[b] = acc.half_area();
-        right_cnt[b] = cnt;
-      }
-      acc = Aabb::empty();
-      cnt = 0;
+    if (hi - lo > 2) {
       float best = INFINITY;
-      int best_split = -1;
-      for (int b = 0; b < kBins - 1; b++) {
-        acc.join(bin_box[b]);
-        cnt += bin_cnt[b];
-        if (cnt == 0 || right_cnt[b + 1] == 0) continue;
-        float cost = acc.half_area() * (float)cnt + right_area[b + 1] * (float)right_cnt[b + 1];
-        if (cost < best) best = cost, best_split = b;
+      int best_axis = -1, best_split = -1;
+      for (int ax = 0; ax < 3; ax++) {
+        const float e = cmax[ax] - cmin[ax];
+        if (!(e > 1e-7f)) continue;
+        Aabb bin_box[kMaxBins];
+        size_t bin_cnt[kMaxBins] = {};
+        for (auto& bb : bin_box) bb = Aabb::empty();
+        const float scale = (float)kBins / e;
+        for (size_t i = lo; i < hi; i++) {
+          int bi = (int)((centroid(order[i], ax) - cmin[ax]) * scale);
+          bi = std::min(std::max(bi, 0), kBins - 1);
+          bin_cnt[bi]++;
+          bin_box[bi].join(boxes[order[i]]);
+        }
+        float right_area[kMaxBins];
+        size_t right_cnt[kMaxBins];
+        Aabb acc = Aabb::empty();
+        size_t cnt = 0;
+        for (int bi = kBins - 1; bi > 0; bi--) {
+          acc.join(bin_box[bi]);
+          cnt += bin_cnt[bi];
+          right_area[bi] = acc.half_area();
+          right_cnt[bi] = cnt;
+        }
+        acc = Aabb::empty();
+        cnt = 0;
+        for (int bi = 0; bi < kBins - 1; bi++) {
+          acc.join(bin_box[bi]);
+          cnt += bin_cnt[bi];
+          if (cnt == 0 || right_cnt[bi + 1] == 0) continue;
+          const float cost = acc.half_area() * (float)cnt + right_area[bi + 1] * (float)right_cnt[bi + 1];
+          if (cost < best) best = cost, best_axis = ax, best_split = bi;
+        }
       }
-      if (best_split >= 0) {
+      if (best_axis >= 0) {
+        const float scale = (float)kBins / (cmax[best_axis] - cmin[best_axis]);
+        auto bin_of = [&](uint32_t sh) {
+          int bi = (int)((centroid(sh, best_axis) - cmin[best_axis]) * scale);
+          return std::min(std::max(bi, 0), kBins - 1);
+        };
         auto it = std::stable_partition(order.begin() + lo, order.begin() + hi,
-                                        [&](uint32_t s) { return bin_of(s) <= best_split; });
+                                        [&](uint32_t sh) { return bin_of(sh) <= best_split; });
         mid = (size_t)(it - order.begin());
         have_split = mid > lo && mid < hi;
       }
     }
     if (!have_split) {
-      // median split along the axis (stable for equal keys)
+      // median split along the widest axis (stable for equal keys)
       mid = lo + (hi - lo) / 2;
       std::stable_sort(order.begin() + lo, order.begin() + hi,
                        [&](uint32_t a, uint32_t b) { return centroid(a, axis) < centroid(b, axis); });
