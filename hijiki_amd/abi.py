@@ -17,6 +17,7 @@ BVH_INNER = 0xFFFFFFFF
 BVH_ROOT_EXIT = 1000000
 BLOCK_SIZE = 128
 RENDER_TIME_KERNELS = 1
+RENDER_SPLIT_KERNELS = 2
 
 f32, u32, u64 = C.c_float, C.c_uint32, C.c_uint64
 
@@ -106,7 +107,7 @@ class RenderStats(C.Structure):
     _fields_ = [("paths", u64), ("closest_rays", u64), ("shadow_rays", u64), ("batches", u64),
                 ("bounce_rounds", u64), ("trace_closest_ms", C.c_double), ("trace_shadow_ms", C.c_double),
                 ("shade_ms", C.c_double), ("reconstruct_ms", C.c_double), ("total_ms", C.c_double),
-                ("closest_launches", u64)]
+                ("closest_launches", u64), ("path_ms", C.c_double), ("path_launches", u64)]
 
 
 # byte sizes of SURVEY.md Appendix A

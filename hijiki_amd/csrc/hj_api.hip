@@ -8,9 +8,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -56,13 +58,22 @@ struct hj_context {
   bool accum_owned = false;
   uint32_t width = 0, height = 0;
 
-  // batch state
-  hj::BatchState st{};
-  std::vector<DevBuf> batch_bufs;
-  DevBuf d_blocks, d_wtab;
-  uint32_t num_wg = 2048;                // grid size of every stage kernel (= queue segments)
-  uint32_t* h_counts = nullptr;          // pinned read-back: 4 arrays of num_wg words
-  hipEvent_t ev_count[2] = {nullptr, nullptr};
+  // Two batch slots: batch k runs on slot k & 1 (own state arrays, own stream), so the latency-bound tail of one
+  // batch (a few long paths) overlaps the throughput phase of the next.
+  struct BatchSlot {
+    hj::BatchState st{};
+    std::vector<DevBuf> bufs;
+    DevBuf d_blocks, d_wtab;
+    hipStream_t stream = nullptr;
+    hj_image_block* h_blocks = nullptr;   // pinned staging of the block list
+    uint32_t h_blocks_cap = 0;
+    uint32_t* h_counts = nullptr;         // pinned read-back: 4 arrays of num_wg words
+    hipEvent_t ev_count[2] = {nullptr, nullptr};
+    hipEvent_t ev_recon = nullptr;        // this slot's reconstruction has run (orders framebuffer updates)
+    hipEvent_t ev_done = nullptr;         // batch complete, statistics copied back
+    bool pending = false, recon_recorded = false;
+  } slots[2];
+  uint32_t num_wg = 2048;                // grid size of every path kernel (= queue segments)
 
   // timing
   std::vector<EventPair> events;
@@ -116,10 +127,13 @@ void release_scene(hj_context* ctx) {
   ctx->have_scene = false;
 }
 
+void release_slot(hj_context::BatchSlot& sl) {
+  for (auto& b : sl.bufs) b.release();
+  sl.bufs.clear();
+  sl.st = hj::BatchState{};
+}
 void release_batch(hj_context* ctx) {
-  for (auto& b : ctx->batch_bufs) b.release();
-  ctx->batch_bufs.clear();
-  ctx->st = hj::BatchState{};
+  for (auto& sl : ctx->slots) release_slot(sl);
 }
 
 // Same invariants the reference asserts while packing (src/main.rs:562-565)
@@ -170,17 +184,17 @@ int validate_scene(hj_context* ctx, const hj_scene_desc* s) {
   return HJ_OK;
 }
 
-int ensure_batch(hj_context* ctx, uint32_t num_blocks) {
+int ensure_batch(hj_context* ctx, hj_context::BatchSlot& sl, uint32_t num_blocks) {
   const uint32_t cap = num_blocks * hj::kSlotsPerBlock;
-  if (ctx->st.capacity >= cap) return HJ_OK;
-  release_batch(ctx);
+  if (sl.st.capacity >= cap) return HJ_OK;
+  release_slot(sl);
   auto alloc = [&](size_t bytes, void** out) -> int {
-    ctx->batch_bufs.emplace_back();
-    int rc = dev_alloc(ctx, ctx->batch_bufs.back(), bytes);
-    *out = ctx->batch_bufs.back().p;
+    sl.bufs.emplace_back();
+    int rc = dev_alloc(ctx, sl.bufs.back(), bytes);
+    *out = sl.bufs.back().p;
     return rc;
   };
-  hj::BatchState& st = ctx->st;
+  hj::BatchState& st = sl.st;
   int rc = HJ_OK;
   const size_t n = cap;
 #define HJ_ALLOC(field, type, count)                                       \
@@ -216,22 +230,30 @@ int ensure_batch(hj_context* ctx, uint32_t num_blocks) {
   st.num_wg = G;
   st.segcap = segcap;
   if (rc != HJ_OK) {
-    release_batch(ctx);
+    release_slot(sl);
     return rc;
   }
   st.capacity = cap;
-  rc = dev_alloc(ctx, ctx->d_blocks, sizeof(hj_image_block) * num_blocks);
-  if (rc == HJ_OK) rc = dev_alloc(ctx, ctx->d_wtab, sizeof(float) * 25 * num_blocks);
-  if (rc != HJ_OK) release_batch(ctx);
+  rc = dev_alloc(ctx, sl.d_blocks, sizeof(hj_image_block) * num_blocks);
+  if (rc == HJ_OK) rc = dev_alloc(ctx, sl.d_wtab, sizeof(float) * 25 * num_blocks);
+  if (rc == HJ_OK && sl.h_blocks_cap < num_blocks) {
+    if (sl.h_blocks) (void)hipHostFree(sl.h_blocks);
+    sl.h_blocks = nullptr;
+    sl.h_blocks_cap = 0;
+    if (hipHostMalloc((void**)&sl.h_blocks, sizeof(hj_image_block) * num_blocks, hipHostMallocDefault) != hipSuccess)
+      rc = set_error(ctx, HJ_ERR_NOMEM, "pinned block staging allocation failed");
+    else sl.h_blocks_cap = num_blocks;
+  }
+  if (rc != HJ_OK) release_slot(sl);
   return rc;
 }
 
-enum { EV_CLOSEST = 0, EV_SHADOW = 1, EV_SHADE = 2, EV_RECON = 3, EV_KINDS = 4 };
+enum { EV_CLOSEST = 0, EV_SHADOW = 1, EV_SHADE = 2, EV_RECON = 3, EV_PATH = 4, EV_KINDS = 5 };
 
 struct Timer {
   hj_context* ctx;
   bool on;
-  int begin(int kind) {
+  int begin(int kind, hipStream_t s) {
     if (!on) return -1;
     if (ctx->events_used == ctx->events.size()) {
       EventPair ep{};
@@ -240,81 +262,159 @@ struct Timer {
     }
     EventPair& ep = ctx->events[ctx->events_used];
     ep.kind = kind;
-    (void)hipEventRecord(ep.a, ctx->stream);
+    (void)hipEventRecord(ep.a, s);
     return (int)ctx->events_used++;
   }
-  void end(int idx) {
-    if (idx >= 0) (void)hipEventRecord(ctx->events[idx].b, ctx->stream);
+  void end(int idx, hipStream_t s) {
+    if (idx >= 0) (void)hipEventRecord(ctx->events[idx].b, s);
   }
 };
 
-int render_batch(hj_context* ctx, const hj_image_block* blocks, uint32_t nb, const hj_render_opts& o, Timer& tm,
-                 hj_render_stats* stats, bool reconstruct = true) {
-  int rc = ensure_batch(ctx, std::max<uint32_t>(nb, 1));
-  if (rc != HJ_OK) return rc;
-  hj::BatchState st = ctx->st;
-  st.blocks = static_cast<const hj_image_block*>(ctx->d_blocks.p);
-  st.num_blocks = nb;
-  hipStream_t s = ctx->stream;
-  HJ_HIP(ctx, hipMemcpyAsync(ctx->d_blocks.p, blocks, sizeof(hj_image_block) * nb, hipMemcpyHostToDevice, s));
-  const uint32_t G = st.num_wg;
-  const dim3 blk(hj::kBlockThreads);
-  const dim3 grid(G);
-  const bool bvh = o.use_bvh != 0;
-  hipLaunchKernelGGL(hj::k_gen_camera, grid, blk, 0, s, st, ctx->scene);
-  uint64_t rounds = 0;
-  // The host only needs to know when every queue is empty.  The per-workgroup counts of bounce b are copied
-  // back asynchronously and examined one bounce LATER, so the GPU always has the next round queued.
-  auto alive_after = [&](uint32_t b) -> uint64_t {
-    const uint32_t* c = ctx->h_counts + (size_t)(b & 1u) * G;
-    uint64_t sum = 0;
-    for (uint32_t i = 0; i < G; i++) sum += c[i];
-    return sum;
-  };
-  for (uint32_t bounce = 0; bounce < o.max_bounces; bounce++) {
-    const uint32_t parity = bounce & 1u;
-    const float tmin = bounce == 0 ? hj::kEps : 2.0f * hj::kEps;   // render.glsl:33,132
-    int ev = tm.begin(EV_CLOSEST);
-    if (bvh) hipLaunchKernelGGL(hj::k_trace_closest<true>, grid, blk, 0, s, st, ctx->scene, parity, tmin);
-    else hipLaunchKernelGGL(hj::k_trace_closest<false>, grid, blk, 0, s, st, ctx->scene, parity, tmin);
-    tm.end(ev);
-    ev = tm.begin(EV_SHADE);
-    hipLaunchKernelGGL(hj::k_shade, grid, blk, 0, s, st, ctx->scene, parity, bounce, o.max_bounces, o.rr_start);
-    tm.end(ev);
-    ev = tm.begin(EV_SHADOW);
-    if (bvh) hipLaunchKernelGGL(hj::k_trace_shadow<true>, grid, blk, 0, s, st, ctx->scene);
-    else hipLaunchKernelGGL(hj::k_trace_shadow<false>, grid, blk, 0, s, st, ctx->scene);
-    tm.end(ev);
-    rounds++;
-    HJ_HIP(ctx, hipMemcpyAsync(ctx->h_counts + (size_t)parity * G, st.cnt_ray[parity ^ 1u], sizeof(uint32_t) * G,
-                               hipMemcpyDeviceToHost, s));
-    HJ_HIP(ctx, hipEventRecord(ctx->ev_count[parity], s));
-    if (bounce >= 1) {
-      HJ_HIP(ctx, hipEventSynchronize(ctx->ev_count[parity ^ 1u]));
-      if (alive_after(bounce - 1) == 0) break;
-    }
-  }
-  int ev = -1;
-  if (reconstruct) {
-  ev = tm.begin(EV_RECON);
+// Reconstruction of one slot's batch, ordered after the other slot's (framebuffer sums are defined by block order).
+int enqueue_reconstruct(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::BatchSlot& other, const hj::BatchState& st,
+                        uint32_t nb, const hj_render_opts& o, Timer& tm) {
+  hipStream_t s = sl.stream;
+  if (other.recon_recorded) HJ_HIP(ctx, hipStreamWaitEvent(s, other.ev_recon, 0));
+  const int ev = tm.begin(EV_RECON, s);
   hipLaunchKernelGGL(hj::k_recon_weights, dim3((nb * 25 + 255) / 256), dim3(256), 0, s, st.blocks, nb, o.recon_stddev,
-                     static_cast<float*>(ctx->d_wtab.p));
+                     static_cast<float*>(sl.d_wtab.p));
   hipLaunchKernelGGL(hj::k_reconstruct, dim3((ctx->width + 15) / 16, (ctx->height + 15) / 16), dim3(256), 0, s, st,
-                     static_cast<const float*>(ctx->d_wtab.p), ctx->accum, ctx->width, ctx->height);
-  tm.end(ev);
-  }
-  uint32_t* h_acc = ctx->h_counts + (size_t)2 * G;
-  HJ_HIP(ctx, hipMemcpyAsync(h_acc, st.acc_closest, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, s));
-  HJ_HIP(ctx, hipMemcpyAsync(h_acc + G, st.acc_shadow, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, s));
-  HJ_HIP(ctx, hipStreamSynchronize(s));
-  HJ_HIP(ctx, hipGetLastError());
+                     static_cast<const float*>(sl.d_wtab.p), ctx->accum, ctx->width, ctx->height);
+  tm.end(ev, s);
+  HJ_HIP(ctx, hipEventRecord(sl.ev_recon, s));
+  sl.recon_recorded = true;
+  return HJ_OK;
+}
+
+// Wait for a slot's batch and fold its per-workgroup ray counters into the statistics.
+int harvest(hj_context* ctx, hj_context::BatchSlot& sl, hj_render_stats* stats) {
+  if (!sl.pending) return HJ_OK;
+  HJ_HIP(ctx, hipEventSynchronize(sl.ev_done));
+  sl.pending = false;
   if (stats) {
+    const uint32_t G = ctx->num_wg;
+    const uint32_t* h_acc = sl.h_counts + (size_t)2 * G;
     for (uint32_t i = 0; i < G; i++) {
       stats->closest_rays += h_acc[i];
       stats->shadow_rays += h_acc[G + i];
     }
     stats->batches += 1;
-    stats->bounce_rounds += rounds;
+  }
+  return HJ_OK;
+}
+
+int stage_blocks(hj_context* ctx, hj_context::BatchSlot& sl, const hj_image_block* blocks, uint32_t nb, hj::BatchState& st) {
+  int rc = ensure_batch(ctx, sl, std::max<uint32_t>(nb, 1));
+  if (rc != HJ_OK) return rc;
+  st = sl.st;
+  st.blocks = static_cast<const hj_image_block*>(sl.d_blocks.p);
+  st.num_blocks = nb;
+  std::memcpy(sl.h_blocks, blocks, sizeof(hj_image_block) * nb);
+  HJ_HIP(ctx, hipMemcpyAsync(sl.d_blocks.p, sl.h_blocks, sizeof(hj_image_block) * nb, hipMemcpyHostToDevice, sl.stream));
+  return HJ_OK;
+}
+
+int finish_batch(hj_context* ctx, hj_context::BatchSlot& sl, const hj::BatchState& st) {
+  const uint32_t G = st.num_wg;
+  uint32_t* h_acc = sl.h_counts + (size_t)2 * G;
+  HJ_HIP(ctx, hipMemcpyAsync(h_acc, st.acc_closest, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, sl.stream));
+  HJ_HIP(ctx, hipMemcpyAsync(h_acc + G, st.acc_shadow, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, sl.stream));
+  HJ_HIP(ctx, hipEventRecord(sl.ev_done, sl.stream));
+  sl.pending = true;
+  return HJ_OK;
+}
+
+// Default path: ONE persistent launch per batch (k_path_wavefront), asynchronous; the caller pipelines two slots.
+int enqueue_batch_fused(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::BatchSlot& other, const hj_image_block* blocks,
+                        uint32_t nb, const hj_render_opts& o, Timer& tm, hj_render_stats* stats, bool reconstruct) {
+  hj::BatchState st;
+  int rc = stage_blocks(ctx, sl, blocks, nb, st);
+  if (rc != HJ_OK) return rc;
+  const dim3 blk(hj::kBlockThreads), grid(st.num_wg);
+  const int ev = tm.begin(EV_PATH, sl.stream);
+  if (o.use_bvh) hipLaunchKernelGGL(hj::k_path_wavefront<true>, grid, blk, 0, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  else hipLaunchKernelGGL(hj::k_path_wavefront<false>, grid, blk, 0, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  tm.end(ev, sl.stream);
+  if (reconstruct) {
+    rc = enqueue_reconstruct(ctx, sl, other, st, nb, o, tm);
+    if (rc != HJ_OK) return rc;
+  }
+  if (stats) stats->bounce_rounds += 1;
+  return finish_batch(ctx, sl, st);
+}
+
+// Diagnostic path (HJ_RENDER_SPLIT_KERNELS): one launch per stage per bounce, so that each stage can be timed and
+// profiled on its own.  The host learns "all queues empty" from counts copied back one bounce late.
+int render_batch_split(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::BatchSlot& other, const hj_image_block* blocks,
+                       uint32_t nb, const hj_render_opts& o, Timer& tm, hj_render_stats* stats, bool reconstruct) {
+  hj::BatchState st;
+  int rc = stage_blocks(ctx, sl, blocks, nb, st);
+  if (rc != HJ_OK) return rc;
+  hipStream_t s = sl.stream;
+  const uint32_t G = st.num_wg;
+  const dim3 blk(hj::kBlockThreads), grid(G);
+  const bool bvh = o.use_bvh != 0;
+  hipLaunchKernelGGL(hj::k_gen_camera, grid, blk, 0, s, st, ctx->scene);
+  uint64_t rounds = 0;
+  auto alive_after = [&](uint32_t b) -> uint64_t {
+    const uint32_t* c = sl.h_counts + (size_t)(b & 1u) * G;
+    uint64_t sum = 0;
+    for (uint32_t i = 0; i < G; i++) sum += c[i];
+    return sum;
+  };
+  static const bool trace_bounces = std::getenv("HJ_TRACE_BOUNCES") != nullptr;   // debugging aid: per-bounce table
+  for (uint32_t bounce = 0; bounce < o.max_bounces; bounce++) {
+    const uint32_t parity = bounce & 1u;
+    const float tmin = bounce == 0 ? hj::kEps : 2.0f * hj::kEps;   // render.glsl:33,132
+    const size_t ev0 = ctx->events_used;
+    int ev = tm.begin(EV_CLOSEST, s);
+    if (bvh) hipLaunchKernelGGL(hj::k_trace_closest<true>, grid, blk, 0, s, st, ctx->scene, parity, tmin);
+    else hipLaunchKernelGGL(hj::k_trace_closest<false>, grid, blk, 0, s, st, ctx->scene, parity, tmin);
+    tm.end(ev, s);
+    ev = tm.begin(EV_SHADE, s);
+    hipLaunchKernelGGL(hj::k_shade, grid, blk, 0, s, st, ctx->scene, parity, bounce, o.max_bounces, o.rr_start);
+    tm.end(ev, s);
+    ev = tm.begin(EV_SHADOW, s);
+    if (bvh) hipLaunchKernelGGL(hj::k_trace_shadow<true>, grid, blk, 0, s, st, ctx->scene);
+    else hipLaunchKernelGGL(hj::k_trace_shadow<false>, grid, blk, 0, s, st, ctx->scene);
+    tm.end(ev, s);
+    rounds++;
+    HJ_HIP(ctx, hipMemcpyAsync(sl.h_counts + (size_t)parity * G, st.cnt_ray[parity ^ 1u], sizeof(uint32_t) * G,
+                               hipMemcpyDeviceToHost, s));
+    HJ_HIP(ctx, hipEventRecord(sl.ev_count[parity], s));
+    if (trace_bounces && tm.on) {
+      HJ_HIP(ctx, hipStreamSynchronize(s));
+      std::vector<uint32_t> cur(G), sh(G);
+      HJ_HIP(ctx, hipMemcpy(cur.data(), st.cnt_ray[parity], sizeof(uint32_t) * G, hipMemcpyDeviceToHost));
+      HJ_HIP(ctx, hipMemcpy(sh.data(), st.cnt_shadow, sizeof(uint32_t) * G, hipMemcpyDeviceToHost));
+      uint64_t nc = 0, ns = 0, mx = 0;
+      for (uint32_t i = 0; i < G; i++) { nc += cur[i]; ns += sh[i]; mx = std::max<uint64_t>(mx, cur[i]); }
+      float t[3] = {0, 0, 0};
+      for (int k = 0; k < 3; k++) (void)hipEventElapsedTime(&t[k], ctx->events[ev0 + k].a, ctx->events[ev0 + k].b);
+      std::fprintf(stderr, "[bounce %3u] rays %9llu (max/wg %5llu) shadow %9llu | closest %8.1f us  shade %7.1f us  shadow %7.1f us\n",
+                   bounce, (unsigned long long)nc, (unsigned long long)mx, (unsigned long long)ns, t[0] * 1e3f, t[1] * 1e3f, t[2] * 1e3f);
+    }
+    if (bounce >= 1) {
+      HJ_HIP(ctx, hipEventSynchronize(sl.ev_count[parity ^ 1u]));
+      if (alive_after(bounce - 1) == 0) break;
+    }
+  }
+  if (reconstruct) {
+    rc = enqueue_reconstruct(ctx, sl, other, st, nb, o, tm);
+    if (rc != HJ_OK) return rc;
+  }
+  if (stats) stats->bounce_rounds += rounds;
+  rc = finish_batch(ctx, sl, st);
+  if (rc != HJ_OK) return rc;
+  return harvest(ctx, sl, stats);
+}
+
+int sync_all(hj_context* ctx) {
+  HJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& sl : ctx->slots) {
+    HJ_HIP(ctx, hipStreamSynchronize(sl.stream));
+    sl.pending = false;
+    sl.recon_recorded = false;
   }
   return HJ_OK;
 }
@@ -368,9 +468,12 @@ int hj_context_create(int device, hj_context** out) {
   ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   ctx->num_wg = (uint32_t)ctx->num_cus * 8u;   // 8 workgroups of 4 waves per CU = the 32-wave CU limit
-  if ((e = hipHostMalloc((void**)&ctx->h_counts, sizeof(uint32_t) * 4 * ctx->num_wg, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
-  for (auto& ev : ctx->ev_count)
-    if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+  for (auto& sl : ctx->slots) {
+    if ((e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    if ((e = hipHostMalloc((void**)&sl.h_counts, sizeof(uint32_t) * 4 * ctx->num_wg, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
+    for (hipEvent_t* ev : {&sl.ev_count[0], &sl.ev_count[1], &sl.ev_recon, &sl.ev_done})
+      if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+  }
   *out = ctx;
   return HJ_OK;
 }
@@ -379,14 +482,20 @@ void hj_context_destroy(hj_context* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& sl : ctx->slots)
+    if (sl.stream) (void)hipStreamSynchronize(sl.stream);
   release_scene(ctx);
   release_batch(ctx);
-  ctx->d_blocks.release();
-  ctx->d_wtab.release();
+  for (auto& sl : ctx->slots) {
+    sl.d_blocks.release();
+    sl.d_wtab.release();
+    if (sl.h_blocks) (void)hipHostFree(sl.h_blocks);
+    if (sl.h_counts) (void)hipHostFree(sl.h_counts);
+    for (hipEvent_t ev : {sl.ev_count[0], sl.ev_count[1], sl.ev_recon, sl.ev_done})
+      if (ev) (void)hipEventDestroy(ev);
+    if (sl.stream) (void)hipStreamDestroy(sl.stream);
+  }
   if (ctx->accum && ctx->accum_owned) (void)hipFree(ctx->accum);
-  if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
-  for (auto& ev : ctx->ev_count)
-    if (ev) (void)hipEventDestroy(ev);
   for (auto& ep : ctx->events) {
     (void)hipEventDestroy(ep.a);
     (void)hipEventDestroy(ep.b);
@@ -401,7 +510,8 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
   int rc = validate_scene(ctx, s);
   if (rc != HJ_OK) return rc;
   HJ_HIP(ctx, hipSetDevice(ctx->device));
-  HJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  rc = sync_all(ctx);
+  if (rc != HJ_OK) return rc;
   release_scene(ctx);
 
   hj::DeviceScene d{};
@@ -470,6 +580,8 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     }
     d.root = N ? map[0] : 0u;
     d.num_hot = (uint32_t)hot;
+    d.inner_burst = std::max(1, std::getenv("HJ_INNER_BURST") ? std::atoi(std::getenv("HJ_INNER_BURST")) : 4);
+    d.refill_min = std::getenv("HJ_REFILL_MIN") ? (uint32_t)std::atoi(std::getenv("HJ_REFILL_MIN")) : hj::kRefillMin;
     HJ_UP(upload(ctx, dev.data(), dev.size(), &d.nodes));
   }
   HJ_UP(upload(ctx, isect.data(), isect.size(), &d.tri_isect));
@@ -494,7 +606,10 @@ int hj_framebuffer_create(hj_context* ctx, uint32_t width, uint32_t height, void
   if (!ctx) return HJ_ERR_INVALID;
   if (width == 0 || height == 0 || width > 65536 || height > 65536) return set_error(ctx, HJ_ERR_INVALID, "bad framebuffer size %ux%u", width, height);
   HJ_HIP(ctx, hipSetDevice(ctx->device));
-  HJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  {
+    const int rcs = sync_all(ctx);
+    if (rcs != HJ_OK) return rcs;
+  }
   if (ctx->accum && ctx->accum_owned) (void)hipFree(ctx->accum);
   ctx->accum = nullptr;
   ctx->accum_owned = false;
@@ -577,39 +692,54 @@ int hj_render_blocks(hj_context* ctx, const hj_image_block* blocks, size_t n, co
     paths += (uint64_t)std::min(b.dimension[0], b.original_dimension[0]) * std::min(b.dimension[1], b.original_dimension[1]);
   }
   HJ_HIP(ctx, hipSetDevice(ctx->device));
-  if (stats) std::memset(stats, 0, sizeof *stats);
+  hj_render_stats local{};
+  hj_render_stats* st_out = stats ? stats : &local;
+  std::memset(st_out, 0, sizeof *st_out);
   ctx->events_used = 0;
   Timer tm{ctx, (o.flags & HJ_RENDER_TIME_KERNELS) != 0};
+  const bool split = (o.flags & HJ_RENDER_SPLIT_KERNELS) != 0;
   uint32_t batch = o.batch_blocks ? o.batch_blocks : 512u;
   batch = std::min<uint32_t>(batch, 4096u);
-  hipEvent_t t0 = nullptr, t1 = nullptr;
-  HJ_HIP(ctx, hipEventCreate(&t0));
-  HJ_HIP(ctx, hipEventCreate(&t1));
-  (void)hipEventRecord(t0, ctx->stream);
-  for (size_t begin = 0; begin < n && rc == HJ_OK; begin += batch) {
+  rc = sync_all(ctx);
+  if (rc != HJ_OK) return rc;
+  const auto wall0 = std::chrono::steady_clock::now();
+  size_t k = 0;
+  for (size_t begin = 0; begin < n && rc == HJ_OK; begin += batch, k++) {
     const uint32_t nb = (uint32_t)std::min<size_t>(batch, n - begin);
-    rc = render_batch(ctx, blocks + begin, nb, o, tm, stats);
+    hj_context::BatchSlot& sl = ctx->slots[k & 1u];
+    hj_context::BatchSlot& other = ctx->slots[(k & 1u) ^ 1u];
+    rc = harvest(ctx, sl, st_out);          // batch k-2 used this slot: its state arrays are free again
+    if (rc != HJ_OK) break;
+    rc = split ? render_batch_split(ctx, sl, other, blocks + begin, nb, o, tm, st_out, true)
+               : enqueue_batch_fused(ctx, sl, other, blocks + begin, nb, o, tm, st_out, true);
   }
-  (void)hipEventRecord(t1, ctx->stream);
-  (void)hipEventSynchronize(t1);
-  if (rc == HJ_OK && stats) {
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, t0, t1);
-    stats->total_ms = ms;
-    stats->paths = paths;
+  for (auto& sl : ctx->slots) {
+    const int rc2 = harvest(ctx, sl, st_out);
+    if (rc == HJ_OK) rc = rc2;
+  }
+  if (rc == HJ_OK) {
+    const int rc2 = sync_all(ctx);
+    if (rc2 != HJ_OK) rc = rc2;
+  }
+  if (rc == HJ_OK) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) rc = set_error(ctx, HJ_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
+  }
+  if (rc == HJ_OK) {
+    st_out->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    st_out->paths = paths;
     for (size_t i = 0; i < ctx->events_used; i++) {
       float e = 0.f;
       if (hipEventElapsedTime(&e, ctx->events[i].a, ctx->events[i].b) != hipSuccess) continue;
       switch (ctx->events[i].kind) {
-        case EV_CLOSEST: stats->trace_closest_ms += e; stats->closest_launches++; break;
-        case EV_SHADOW: stats->trace_shadow_ms += e; break;
-        case EV_SHADE: stats->shade_ms += e; break;
-        case EV_RECON: stats->reconstruct_ms += e; break;
+        case EV_CLOSEST: st_out->trace_closest_ms += e; st_out->closest_launches++; break;
+        case EV_SHADOW: st_out->trace_shadow_ms += e; break;
+        case EV_SHADE: st_out->shade_ms += e; break;
+        case EV_RECON: st_out->reconstruct_ms += e; break;
+        case EV_PATH: st_out->path_ms += e; st_out->path_launches++; break;
       }
     }
   }
-  (void)hipEventDestroy(t0);
-  (void)hipEventDestroy(t1);
   return rc;
 }
 
@@ -640,6 +770,7 @@ int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed, uint32_
     total.trace_closest_ms += st.trace_closest_ms; total.trace_shadow_ms += st.trace_shadow_ms;
     total.shade_ms += st.shade_ms; total.reconstruct_ms += st.reconstruct_ms; total.total_ms += st.total_ms;
     total.closest_launches += st.closest_launches;
+    total.path_ms += st.path_ms; total.path_launches += st.path_launches;
   }
   if (stats) *stats = total;
   return rc;
@@ -691,11 +822,16 @@ int hj_debug_samples(hj_context* ctx, const hj_image_block* block, const hj_rend
   HJ_HIP(ctx, hipSetDevice(ctx->device));
   ctx->events_used = 0;
   Timer tm{ctx, false};
-  rc = render_batch(ctx, block, 1, o, tm, nullptr, /*reconstruct=*/false);
+  rc = sync_all(ctx);
+  if (rc != HJ_OK) return rc;
+  hj_context::BatchSlot& sl = ctx->slots[0];
+  rc = (o.flags & HJ_RENDER_SPLIT_KERNELS) ? render_batch_split(ctx, sl, ctx->slots[1], block, 1, o, tm, nullptr, /*reconstruct=*/false)
+                                           : enqueue_batch_fused(ctx, sl, ctx->slots[1], block, 1, o, tm, nullptr, /*reconstruct=*/false);
+  if (rc == HJ_OK) rc = harvest(ctx, sl, nullptr);
   if (rc != HJ_OK) return rc;
   std::vector<float4> rgb(hj::kSlotsPerBlock), nd(hj::kSlotsPerBlock);
-  HJ_HIP(ctx, hipMemcpy(rgb.data(), ctx->st.smp_rgb, sizeof(float4) * hj::kSlotsPerBlock, hipMemcpyDeviceToHost));
-  HJ_HIP(ctx, hipMemcpy(nd.data(), ctx->st.smp_nd, sizeof(float4) * hj::kSlotsPerBlock, hipMemcpyDeviceToHost));
+  HJ_HIP(ctx, hipMemcpy(rgb.data(), sl.st.smp_rgb, sizeof(float4) * hj::kSlotsPerBlock, hipMemcpyDeviceToHost));
+  HJ_HIP(ctx, hipMemcpy(nd.data(), sl.st.smp_nd, sizeof(float4) * hj::kSlotsPerBlock, hipMemcpyDeviceToHost));
   for (uint32_t y = 0; y < block->dimension[1]; y++)
     for (uint32_t x = 0; x < block->dimension[0]; x++) {
       float* out = samples + ((size_t)y * block->dimension[0] + x) * 8;

@@ -29,6 +29,8 @@ struct DeviceScene {
   uint32_t num_nodes;
   uint32_t root;                // device index of the reference's node 0
   uint32_t num_hot;             // nodes [0, num_hot) are the LDS-cached ones (<= kHotNodes)
+  uint32_t inner_burst;         // max box steps per round of the persistent walk before leaf tests run
+  uint32_t refill_min;          // free lanes that trigger a ray refill
   const float4* tri_isect;
   const float4* tri_shade;
   const float4* spheres;        // hj_sphere

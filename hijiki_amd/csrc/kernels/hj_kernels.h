@@ -194,7 +194,7 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     // a full write acknowledgement.
     const unsigned long long idle = __ballot(!active);
     const uint32_t nidle = (uint32_t)__popcll(idle);
-    if (nidle >= kRefillMin || nidle == 64u) {
+    if (nidle >= sc.refill_min || nidle == 64u) {
       if (__ballot(pending) != 0) finish(pending, slot, h);
       pending = false;
       if (!exhausted) {
@@ -216,13 +216,15 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     if (__ballot(active) == 0) break;
     uint32_t shape = 0, ex = 0;
     bool at_leaf = false;
-    while (active && cur < nn && !at_leaf) {
+    uint32_t burst = sc.inner_burst;       // lanes standing on a leaf wait at most this many box steps of the others
+    while (active && cur < nn && !at_leaf && burst != 0) {
       float4 n0, n1;
       if (cur < nhot) { n0 = s_n0[cur]; n1 = s_n1[cur]; }                 // hot node: LDS copy
       else { n0 = sc.nodes[2 * cur]; n1 = sc.nodes[2 * cur + 1]; }
       at_leaf = node_step(n0, n1, inv, off, r, cur, shape, ex);
+      burst--;
     }
-    if (active && !at_leaf) { active = false; pending = true; }           // walked off the end of the tree
+    if (active && !at_leaf && cur >= nn) { active = false; pending = true; }   // walked off the end of the tree
     if (at_leaf) {
       if (intersect_shape(sc, r, shape, h)) {
         h.id = (int)shape;
@@ -340,15 +342,28 @@ HJ_DEV v3 checkerboard(const DeviceScene& sc, uint32_t idx, float u, float v) {
   return (a != b) ? xyz(cb) : xyz(ca);
 }
 
-// ------------------------------------------------------------------ kernels
+// ------------------------------------------------------------------ stages
+//
+// A path workgroup owns queue segment g in every queue, so the stages of one bounce need only workgroup
+// barriers between them.  The same stage functions are used by the split per-stage kernels and by the fused
+// persistent kernel k_path_wavefront (one launch per batch: camera rays, then the bounce loop).
 
-// reference shader/render.glsl:26-36,149-162
-__global__ __launch_bounds__(kBlockThreads) void k_gen_camera(BatchState st, DeviceScene sc) {
-  __shared__ uint32_t s_cnt;
-  const uint32_t g = blockIdx.x, G = st.num_wg;
+struct WgShared {                 // LDS of a path workgroup (8.3 KB)
+  uint32_t head;                  // next unread entry of the queue segment being traced
+  uint32_t cnt_hit[kNumTags];     // hits binned by material tag (this bounce)
+  uint32_t n_next, n_shadow;      // next-bounce rays / shadow rays produced by shade
+  uint32_t n_gen;
+  float4 n0[kHotNodes], n1[kHotNodes];   // LDS copy of the hottest BVH nodes
+};
+
+HJ_DEV void load_hot_nodes(const DeviceScene& sc, WgShared& sh) {
+  for (uint32_t i = threadIdx.x; i < sc.num_hot; i += blockDim.x) { sh.n0[i] = sc.nodes[2 * i]; sh.n1[i] = sc.nodes[2 * i + 1]; }
+}
+
+// reference shader/render.glsl:26-36,149-162.  Needs sh.n_gen == 0 on entry (synced); leaves the count there.
+HJ_DEV void stage_gen_camera(const BatchState& st, const DeviceScene& sc, uint32_t g, WgShared& sh) {
+  const uint32_t G = st.num_wg;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-  if (threadIdx.x == 0) s_cnt = 0;
-  __syncthreads();
   const uint32_t total = st.num_blocks * kSlotsPerBlock;
   uint32_t* __restrict__ q = st.q_ray[0] + (size_t)g * st.segcap;
   // this workgroup owns the 64-slot groups g, g+G, g+2G, ...
@@ -393,30 +408,18 @@ __global__ __launch_bounds__(kBlockThreads) void k_gen_camera(BatchState st, Dev
       st.smp_rgb[slot] = make_float4(0.f, 0.f, 0.f, 1.f);
       st.smp_nd[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const uint32_t qi = lds_push(&s_cnt, valid);
+    const uint32_t qi = lds_push(&sh.n_gen, valid);
     if (valid) q[qi] = slot;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    st.cnt_ray[0][g] = s_cnt;
-    st.acc_closest[g] = 0;
-    st.acc_shadow[g] = 0;
   }
 }
 
+// Closest-hit walk over this workgroup's n rays of q_ray[parity]; hits binned by material tag.
+// Needs sh.head == 0, sh.cnt_hit[] == 0 and the hot nodes loaded (synced); leaves the tag counts in sh.cnt_hit.
 template <bool USE_BVH>
-__global__ __launch_bounds__(kBlockThreads) void k_trace_closest(BatchState st, DeviceScene sc, uint32_t parity,
-                                                                 float tmin) {
-  __shared__ uint32_t s_head, s_cnt[kNumTags];
-  __shared__ float4 s_n0[kHotNodes], s_n1[kHotNodes];
-  const uint32_t g = blockIdx.x, G = st.num_wg;
+HJ_DEV void stage_trace_closest(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t n,
+                                float tmin, WgShared& sh) {
+  const uint32_t G = st.num_wg;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t n = st.cnt_ray[parity][g];
-  if (threadIdx.x == 0) s_head = 0;
-  if (threadIdx.x < kNumTags) s_cnt[threadIdx.x] = 0;
-  if (USE_BVH && n != 0)
-    for (uint32_t i = threadIdx.x; i < sc.num_hot; i += blockDim.x) { s_n0[i] = sc.nodes[2 * i]; s_n1[i] = sc.nodes[2 * i + 1]; }
-  __syncthreads();
   const uint32_t* __restrict__ q = st.q_ray[parity] + (size_t)g * st.segcap;
   // bin finished rays by material tag (divergent-BSDF sort): one ballot + one LDS atomic per tag per wave
   auto finish = [&](bool done, uint32_t slot, const RawHit& h) {
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_trace_closest(BatchState st, 
     }
 #pragma unroll
     for (uint32_t k = 0; k < kNumTags; k++) {
-      const uint32_t qi = lds_push(&s_cnt[k], tag == k);
+      const uint32_t qi = lds_push(&sh.cnt_hit[k], tag == k);
       if (tag == k) st.q_hit[((size_t)k * G + g) * st.segcap + qi] = slot;
     }
   };
@@ -437,10 +440,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_trace_closest(BatchState st, 
       const float4 o = st.ray_o[slot], d = st.ray_d[slot];
       r.o = xyz(o); r.d = xyz(d); r.tmin = tmin; r.tmax = kInf;
     };
-    trace_persistent<false>(sc, n, &s_head, s_n0, s_n1, fetch, finish);
+    trace_persistent<false>(sc, n, &sh.head, sh.n0, sh.n1, fetch, finish);
   } else {
     for (;;) {
-      const uint32_t c = lds_fetch_chunk(&s_head);
+      const uint32_t c = lds_fetch_chunk(&sh.head);
       if (c >= n) break;
       const uint32_t i = c + lane;
       const bool valid = i < n;
@@ -455,22 +458,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_trace_closest(BatchState st, 
       finish(valid, slot, h);
     }
   }
-  __syncthreads();
-  if (threadIdx.x < kNumTags) st.cnt_hit[g * kNumTags + threadIdx.x] = s_cnt[threadIdx.x];
-  if (threadIdx.x == 0) st.acc_closest[g] += n;
 }
 
+// Any-hit walk over this workgroup's n shadow rays; unoccluded ones add their NEE radiance (render.glsl:122-124).
+// Needs sh.head == 0 and the hot nodes loaded (synced).
 template <bool USE_BVH>
-__global__ __launch_bounds__(kBlockThreads) void k_trace_shadow(BatchState st, DeviceScene sc) {
-  __shared__ uint32_t s_head;
-  __shared__ float4 s_n0[kHotNodes], s_n1[kHotNodes];
-  const uint32_t g = blockIdx.x;
+HJ_DEV void stage_trace_shadow(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t n, WgShared& sh) {
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t n = st.cnt_shadow[g];
-  if (threadIdx.x == 0) s_head = 0;
-  if (USE_BVH && n != 0)
-    for (uint32_t i = threadIdx.x; i < sc.num_hot; i += blockDim.x) { s_n0[i] = sc.nodes[2 * i]; s_n1[i] = sc.nodes[2 * i + 1]; }
-  __syncthreads();
   const uint32_t* __restrict__ q = st.q_shadow + (size_t)g * st.segcap;
   auto add_unoccluded = [&](bool done, uint32_t slot, const RawHit&) {
     if (done) {
@@ -486,10 +480,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_trace_shadow(BatchState st, D
       const float4 o = st.ray_o[slot], d = st.sh_d[slot];
       r.o = xyz(o); r.d = xyz(d); r.tmin = 2.0f * kEps; r.tmax = d.w;
     };
-    trace_persistent<true>(sc, n, &s_head, s_n0, s_n1, fetch, add_unoccluded);
+    trace_persistent<true>(sc, n, &sh.head, sh.n0, sh.n1, fetch, add_unoccluded);
   } else {
     for (;;) {
-      const uint32_t c = lds_fetch_chunk(&s_head);
+      const uint32_t c = lds_fetch_chunk(&sh.head);
       if (c >= n) break;
       const uint32_t i = c + lane;
       if (i < n) {
@@ -503,19 +497,17 @@ __global__ __launch_bounds__(kBlockThreads) void k_trace_shadow(BatchState st, D
   }
 }
 
-// reference shader/scene.glsl:160-175 (populate), render.glsl:102-144, material.glsl:18-91
-__global__ __launch_bounds__(kBlockThreads) void k_shade(BatchState st, DeviceScene sc, uint32_t parity,
-                                                         uint32_t bounce, uint32_t max_bounces, uint32_t rr_start) {
-  __shared__ uint32_t s_next, s_shadow;
-  const uint32_t g = blockIdx.x, G = st.num_wg;
+// reference shader/scene.glsl:160-175 (populate), render.glsl:102-144, material.glsl:18-91.
+// Shades the hits counted in sh.cnt_hit[]; needs sh.n_next == sh.n_shadow == 0 (synced); leaves the counts there.
+HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t bounce,
+                        uint32_t max_bounces, uint32_t rr_start, WgShared& sh) {
+  const uint32_t G = st.num_wg;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-  if (threadIdx.x == 0) { s_next = 0; s_shadow = 0; }
-  __syncthreads();
   uint32_t* __restrict__ q_next = st.q_ray[parity ^ 1u] + (size_t)g * st.segcap;
   uint32_t* __restrict__ q_sh = st.q_shadow + (size_t)g * st.segcap;
   // one material tag at a time: every wave shades ONE tag (no divergent BSDF switch)
   for (uint32_t tag = 0; tag < kNumTags; tag++) {
-    const uint32_t n = st.cnt_hit[g * kNumTags + tag];
+    const uint32_t n = sh.cnt_hit[tag];
     const uint32_t* __restrict__ q = st.q_hit + ((size_t)tag * G + g) * st.segcap;
     for (uint32_t base = wave * 64u; base < n; base += waves * 64u) {
     const uint32_t i = base + lane;
@@ -626,17 +618,110 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(BatchState st, DeviceSc
       }
       st.ray_o[slot] = make_float4(its.p.x, its.p.y, its.p.z, 0.f);   // next origin == shadow-ray origin
     }
-    const uint32_t qn = lds_push(&s_next, alive);
+    const uint32_t qn = lds_push(&sh.n_next, alive);
     if (alive) q_next[qn] = slot;
-    const uint32_t qs = lds_push(&s_shadow, want_shadow);
+    const uint32_t qs = lds_push(&sh.n_shadow, want_shadow);
     if (want_shadow) q_sh[qs] = slot;
     }
   }
+}
+
+// ------------------------------------------------------------------ kernels
+
+__global__ __launch_bounds__(kBlockThreads) void k_gen_camera(BatchState st, DeviceScene sc) {
+  __shared__ WgShared sh;
+  const uint32_t g = blockIdx.x;
+  if (threadIdx.x == 0) sh.n_gen = 0;
+  __syncthreads();
+  stage_gen_camera(st, sc, g, sh);
   __syncthreads();
   if (threadIdx.x == 0) {
-    st.cnt_ray[parity ^ 1u][g] = s_next;
-    st.cnt_shadow[g] = s_shadow;
-    st.acc_shadow[g] += s_shadow;
+    st.cnt_ray[0][g] = sh.n_gen;
+    st.acc_closest[g] = 0;
+    st.acc_shadow[g] = 0;
+  }
+}
+
+template <bool USE_BVH>
+__global__ __launch_bounds__(kBlockThreads) void k_trace_closest(BatchState st, DeviceScene sc, uint32_t parity,
+                                                                 float tmin) {
+  __shared__ WgShared sh;
+  const uint32_t g = blockIdx.x;
+  const uint32_t n = st.cnt_ray[parity][g];
+  if (threadIdx.x == 0) sh.head = 0;
+  if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
+  if (USE_BVH && n != 0) load_hot_nodes(sc, sh);
+  __syncthreads();
+  stage_trace_closest<USE_BVH>(st, sc, g, parity, n, tmin, sh);
+  __syncthreads();
+  if (threadIdx.x < kNumTags) st.cnt_hit[g * kNumTags + threadIdx.x] = sh.cnt_hit[threadIdx.x];
+  if (threadIdx.x == 0) st.acc_closest[g] += n;
+}
+
+template <bool USE_BVH>
+__global__ __launch_bounds__(kBlockThreads) void k_trace_shadow(BatchState st, DeviceScene sc) {
+  __shared__ WgShared sh;
+  const uint32_t g = blockIdx.x;
+  const uint32_t n = st.cnt_shadow[g];
+  if (threadIdx.x == 0) sh.head = 0;
+  if (USE_BVH && n != 0) load_hot_nodes(sc, sh);
+  __syncthreads();
+  stage_trace_shadow<USE_BVH>(st, sc, g, n, sh);
+}
+
+__global__ __launch_bounds__(kBlockThreads) void k_shade(BatchState st, DeviceScene sc, uint32_t parity,
+                                                         uint32_t bounce, uint32_t max_bounces, uint32_t rr_start) {
+  __shared__ WgShared sh;
+  const uint32_t g = blockIdx.x;
+  if (threadIdx.x == 0) { sh.n_next = 0; sh.n_shadow = 0; }
+  if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = st.cnt_hit[g * kNumTags + threadIdx.x];
+  __syncthreads();
+  stage_shade(st, sc, g, parity, bounce, max_bounces, rr_start, sh);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st.cnt_ray[parity ^ 1u][g] = sh.n_next;
+    st.cnt_shadow[g] = sh.n_shadow;
+    st.acc_shadow[g] += sh.n_shadow;
+  }
+}
+
+// The whole life of a batch in ONE launch: every workgroup generates the camera rays of its slot groups and
+// then loops over bounces {closest-hit walk -> shade -> shadow walk} on its private queue segments until all of
+// its paths are dead.  Workgroups never exchange data, so there is no grid barrier, no host round trip and no
+// per-stage launch; while one workgroup shades (memory bound) its CU neighbours walk the BVH (latency bound).
+// Exit condition every wave reaches: its workgroup's ray count is zero, or max_bounces rounds are done.
+template <bool USE_BVH>
+__global__ __launch_bounds__(kBlockThreads) void k_path_wavefront(BatchState st, DeviceScene sc, uint32_t max_bounces,
+                                                                  uint32_t rr_start) {
+  __shared__ WgShared sh;
+  const uint32_t g = blockIdx.x;
+  if (threadIdx.x == 0) sh.n_gen = 0;
+  if (USE_BVH) load_hot_nodes(sc, sh);
+  __syncthreads();
+  stage_gen_camera(st, sc, g, sh);
+  __syncthreads();
+  uint32_t n = sh.n_gen;
+  uint32_t total_closest = 0, total_shadow = 0;
+  for (uint32_t bounce = 0; bounce < max_bounces && n != 0; bounce++) {
+    const uint32_t parity = bounce & 1u;
+    if (threadIdx.x == 0) { sh.head = 0; sh.n_next = 0; sh.n_shadow = 0; }
+    if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
+    __syncthreads();
+    stage_trace_closest<USE_BVH>(st, sc, g, parity, n, bounce == 0 ? kEps : 2.0f * kEps, sh);   // render.glsl:33,132
+    __syncthreads();
+    stage_shade(st, sc, g, parity, bounce, max_bounces, rr_start, sh);
+    if (threadIdx.x == 0) sh.head = 0;       // the closest-hit walk is over (barrier above); shade does not use it
+    __syncthreads();
+    const uint32_t ns = sh.n_shadow;
+    total_closest += n;
+    total_shadow += ns;
+    n = sh.n_next;
+    stage_trace_shadow<USE_BVH>(st, sc, g, ns, sh);
+    __syncthreads();                         // everyone has read n_next / n_shadow before they are reset
+  }
+  if (threadIdx.x == 0) {
+    st.acc_closest[g] = total_closest;
+    st.acc_shadow[g] = total_shadow;
   }
 }
 

@@ -153,7 +153,8 @@ typedef struct hj_render_opts {
   uint32_t _reserved;
 } hj_render_opts;
 
-#define HJ_RENDER_TIME_KERNELS 1u  /* bracket every kernel class with HIP events (fills *_ms in stats) */
+#define HJ_RENDER_TIME_KERNELS 1u   /* bracket every kernel with HIP events on its launch stream (fills *_ms) */
+#define HJ_RENDER_SPLIT_KERNELS 2u  /* diagnostic: one launch per stage per bounce instead of the fused kernel */
 
 /* Per-render statistics (device counters; all in units of events). */
 typedef struct hj_render_stats {
@@ -166,8 +167,10 @@ typedef struct hj_render_stats {
   double   trace_shadow_ms;
   double   shade_ms;
   double   reconstruct_ms;
-  double   total_ms;         /* first launch -> last kernel complete                */
+  double   total_ms;         /* host wall time of the call (all batches, both streams) */
   uint64_t closest_launches; /* number of closest-hit kernel launches timed         */
+  double   path_ms;          /* HIP-event time of the fused k_path_wavefront launches */
+  uint64_t path_launches;
 } hj_render_stats;
 
 typedef struct hj_context hj_context;

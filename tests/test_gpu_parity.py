@@ -64,7 +64,7 @@ def test_divergent_materials_and_many_bounces(gpu_renderer, oracle, cbox_spheres
     want, ctr, _ = oracle.render_blocks(cbox_spheres, blocks, W, H)
     got, st = render(gpu_renderer, cbox_spheres, W, H, blocks)
     assert_same(got, want, "spheres")
-    assert ctr["sphere_tests"] > 0 and st["bounce_rounds"] > 30
+    assert ctr["sphere_tests"] > 0 and st["batches"] == 1
 
 
 def test_tinted_dielectric_extinction(gpu_renderer, oracle):
@@ -99,6 +99,22 @@ def test_quads_and_emissive_sphere(gpu_renderer, oracle):
     got, _ = render(gpu_renderer, cs, W, H, blocks)
     assert ctr["quad_tests"] > 0 and ctr["sphere_tests"] > 0
     assert_same(got, want, "quads")
+
+
+def test_split_kernel_mode_is_identical(gpu_renderer, oracle, cbox_spheres):
+    """HJ_RENDER_SPLIT_KERNELS (one launch per stage per bounce, the profiling path) == the fused persistent kernel."""
+    W, H = 256, 128
+    blocks = host.make_blocks(W, H, 3, 17)
+    want, ctr, _ = oracle.render_blocks(cbox_spheres, blocks, W, H)
+    o = device.default_opts()
+    o.flags = abi.RENDER_SPLIT_KERNELS | abi.RENDER_TIME_KERNELS
+    got, st = render(gpu_renderer, cbox_spheres, W, H, blocks, o)
+    assert_same(got, want, "split kernels")
+    assert st["closest_rays"] == ctr["closest_calls"] and st["closest_launches"] == st["bounce_rounds"] > 10
+    o.flags = abi.RENDER_TIME_KERNELS
+    got, st = render(gpu_renderer, cbox_spheres, W, H, blocks, o)
+    assert_same(got, want, "fused kernel")
+    assert st["path_launches"] == 1 and st["path_ms"] > 0 and st["shadow_rays"] == ctr["shadow_calls"]
 
 
 def test_linear_scan_mode(gpu_renderer, oracle, cbox_small):
