@@ -27,19 +27,35 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def algorithmic_bytes(ctr):
-    """bytes the reference algorithm touches per intersectScene call of the closest-hit kind:
-    32 B per BVH node visited, 108 B per triangle test (3 x 4 B indices + 3 x 32 B vertices), 16 B per sphere test,
-    48 B per quad test.  Counters come from the CPU oracle on the same scene/seed (properties of algorithm + tree)."""
-    calls = max(1, ctr["closest_calls"])
-    return (32.0 * ctr["nodes"] + 108.0 * ctr["tri_tests"] + 16.0 * ctr["sphere_tests"] + 48.0 * ctr["quad_tests"]) / calls
+def algorithmic_bytes_per_path(ctr):
+    """SURVEY.md §8(d), B_path: bytes the REFERENCE algorithm touches per camera path =
+    S*(32*N_n + 108*N_t + 16*N_s [+48*N_q]) over all intersectScene calls (closest AND shadow: the reference walks
+    the full closest-hit query for shadow rays, scene.glsl:92-96) + H*(108+4+16) populate re-fetch + material word
+    + record + E*(16+108+4+16) emitter record + light triangle + its material + 128 for the sample write,
+    the reconstruction read and the accumulation read-modify-write.  Counters come from the CPU oracle on the same
+    scene/seed (properties of algorithm + tree, not of the GPU)."""
+    walk = 32.0 * (ctr["nodes"] + ctr["shadow_nodes"]) + 108.0 * (ctr["tri_tests"] + ctr["shadow_tri_tests"]) \
+        + 16.0 * (ctr["sphere_tests"] + ctr["shadow_sphere_tests"]) + 48.0 * (ctr["quad_tests"] + ctr["shadow_quad_tests"])
+    return (walk + 128.0 * ctr["hits"] + 144.0 * ctr["nee_evals"]) / max(1, ctr["paths"]) + 128.0
+
+
+def host_cores():
+    """Threads the CPU baseline may really use: the cgroup CPU quota when there is one, else the CPU count."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def cpu_baseline(cs, width, height, seed, budget_s=12.0):
     """Oracle timed on the host cores of this box on whole passes of the same workload (cost is linear in passes)."""
     from hijiki_amd import host
     from oracle import hj_oracle
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     _, ctr, secs = hj_oracle.render_blocks(cs, host.make_blocks(width, height, 1, seed), width, height, nthreads=cores)
     rate1 = width * height / max(secs, 1e-9)
     spp = int(max(1, min(64, budget_s * rate1 / (width * height))))
@@ -126,21 +142,24 @@ def main():
         else:
             from oracle import hj_oracle
             _, ctr, _ = hj_oracle.render_blocks(cs, host.make_blocks(W, H, 1, args.seed), W, H)
-        # dominant kernel: k_trace_closest.  achieved = algorithmic bytes per launch / average launch duration,
-        # both over the timed region of THIS run (rank 0's launches, HIP events on the launch stream).
-        bpr = algorithmic_bytes(ctr)
-        launches = max(1, agg["closest_launches"])
-        bytes_per_launch = bpr * agg["closest_rays"] / launches
-        avg_ms = agg["trace_closest_ms"] / launches
+        # dominant kernel: k_path_wavefront (the whole wavefront loop of a batch is ONE persistent launch).
+        # achieved = algorithmic bytes per launch / average launch duration, both over the timed region of THIS
+        # run (rank 0's launches, HIP events on the launch streams).  Two batches are in flight on two streams, so
+        # launches overlap in time: `achieved_wall` divides the same bytes by the wall time of the region instead.
+        bpp = algorithmic_bytes_per_path(ctr)
+        launches = max(1, agg["path_launches"])
+        bytes_per_launch = bpp * agg["paths"] / launches
+        avg_ms = agg["path_ms"] / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                           "kernel": "k_trace_closest", "bytes_per_ray": round(bpr, 1),
+                           "kernel": "k_path_wavefront", "bytes_per_path": round(bpp, 1),
                            "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
-                           "note": "algorithmic bytes (32 B/node + 108 B/triangle test); the 0.6 MB scene is L2-resident, "
-                                   "so physical HBM traffic is far lower (profiles/)"}
-        out["kernel_ms_per_step"] = {k: round(agg[k] / args.steps, 3) for k in
-                                     ("trace_closest_ms", "trace_shadow_ms", "shade_ms", "reconstruct_ms", "total_ms")}
+                           "achieved_wall": round(bpp * agg["paths"] / elapsed / 1e9 * world, 1),
+                           "note": "algorithmic bytes of the reference algorithm (SURVEY 8d B_path); the 0.6 MB scene is "
+                                   "L1/L2-resident, so physical HBM traffic is far lower: the kernel is bound by "
+                                   "dependent-fetch latency and lane utilisation (DESIGN.md 6, profiles/)"}
+        out["kernel_ms_per_step"] = {k: round(agg[k] / args.steps, 3) for k in ("path_ms", "reconstruct_ms", "total_ms")}
         out["rays_per_path"] = round((agg["closest_rays"] + agg["shadow_rays"]) / max(1, agg["paths"]), 3)
         print(json.dumps(out), flush=True)
     sr.close()

@@ -690,8 +690,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(BatchState st, DeviceSc
 // its paths are dead.  Workgroups never exchange data, so there is no grid barrier, no host round trip and no
 // per-stage launch; while one workgroup shades (memory bound) its CU neighbours walk the BVH (latency bound).
 // Exit condition every wave reaches: its workgroup's ray count is zero, or max_bounces rounds are done.
+#ifndef HJ_PATH_WAVES
+#define HJ_PATH_WAVES 6   // 80 VGPRs (9 spilled): measured 3-4 % faster than 5 (96 VGPRs) and than 8 (64 VGPRs, 33 spilled)
+#endif
 template <bool USE_BVH>
-__global__ __launch_bounds__(kBlockThreads) void k_path_wavefront(BatchState st, DeviceScene sc, uint32_t max_bounces,
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(HJ_PATH_WAVES, 8))) void k_path_wavefront(BatchState st, DeviceScene sc, uint32_t max_bounces,
                                                                   uint32_t rr_start) {
   __shared__ WgShared sh;
   const uint32_t g = blockIdx.x;
