@@ -11,7 +11,7 @@ full-frame RGBA32F buffer and one RCCL sum-reduce brings the frame to rank 0 (st
 Scene, BVH and block lists are resident/derived before the timed region; nothing is read back inside it.
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline     — dominant kernel (closest-hit BVH traversal): algorithmic bytes per launch / HIP-event duration
+  roofline     — dominant kernel (k_path_wavefront): algorithmic bytes per launch / HIP-event duration
   cpu_baseline — the CPU oracle ("Nori-style" port) timed on this host on a bounded sample of the same workload
 """
 import argparse
@@ -151,8 +151,20 @@ def main():
         bytes_per_launch = bpp * agg["paths"] / launches
         avg_ms = agg["path_ms"] / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+        # WRITE_SIZE in separate runs of this command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); only
+        # quoted when the launch shape is the one that was profiled (1024x1024, 512-block batches).
+        traffic = traffic_bytes = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v2_pmc_hbm_traffic.json")))
+            if (W, H) == (1024, 1024) and world == 1 and agg["paths"] / launches == pmc["paths_per_launch"]:
+                traffic_bytes = pmc["traffic_bytes_per_launch_corrected"]
+                traffic = round(traffic_bytes / (avg_ms * 1e-3) / 1e9, 1)
+        except (OSError, ValueError, KeyError):
+            pass
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "traffic_bytes_per_launch": traffic_bytes, "algorithmic_bytes_per_launch": round(bytes_per_launch),
                            "kernel": "k_path_wavefront", "bytes_per_path": round(bpp, 1),
                            "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
                            "achieved_wall": round(bpp * agg["paths"] / elapsed / 1e9 * world, 1),
