@@ -42,6 +42,8 @@ struct EventPair { hipEvent_t a, b; int kind; };
 
 }  // namespace
 
+constexpr uint32_t kMaxSlots = 4;
+
 struct hj_context {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -72,7 +74,8 @@ struct hj_context {
     hipEvent_t ev_recon = nullptr;        // this slot's reconstruction has run (orders framebuffer updates)
     hipEvent_t ev_done = nullptr;         // batch complete, statistics copied back
     bool pending = false, recon_recorded = false;
-  } slots[2];
+  } slots[kMaxSlots];
+  uint32_t num_slots = 2;
   uint32_t num_wg = 2048;                // grid size of every path kernel (= queue segments)
 
   // timing
@@ -467,7 +470,8 @@ int hj_context_create(int device, hj_context** out) {
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail(e, "hipGetDeviceProperties");
   ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
-  ctx->num_wg = (uint32_t)ctx->num_cus * 8u;   // 8 workgroups of 4 waves per CU = the 32-wave CU limit
+  ctx->num_wg = (uint32_t)ctx->num_cus * (std::getenv("HJ_WG_PER_CU") ? (uint32_t)std::atoi(std::getenv("HJ_WG_PER_CU")) : 8u);   // 8 workgroups of 4 waves per CU = the 32-wave CU limit
+  if (std::getenv("HJ_SLOTS")) ctx->num_slots = std::min<uint32_t>(kMaxSlots, std::max(1, std::atoi(std::getenv("HJ_SLOTS"))));
   for (auto& sl : ctx->slots) {
     if ((e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     if ((e = hipHostMalloc((void**)&sl.h_counts, sizeof(uint32_t) * 4 * ctx->num_wg, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
@@ -706,9 +710,9 @@ int hj_render_blocks(hj_context* ctx, const hj_image_block* blocks, size_t n, co
   size_t k = 0;
   for (size_t begin = 0; begin < n && rc == HJ_OK; begin += batch, k++) {
     const uint32_t nb = (uint32_t)std::min<size_t>(batch, n - begin);
-    hj_context::BatchSlot& sl = ctx->slots[k & 1u];
-    hj_context::BatchSlot& other = ctx->slots[(k & 1u) ^ 1u];
-    rc = harvest(ctx, sl, st_out);          // batch k-2 used this slot: its state arrays are free again
+    hj_context::BatchSlot& sl = ctx->slots[k % ctx->num_slots];
+    hj_context::BatchSlot& other = ctx->slots[(k + ctx->num_slots - 1) % ctx->num_slots];   // the previous batch's slot
+    rc = harvest(ctx, sl, st_out);          // an older batch used this slot: its state arrays are free again
     if (rc != HJ_OK) break;
     rc = split ? render_batch_split(ctx, sl, other, blocks + begin, nb, o, tm, st_out, true)
                : enqueue_batch_fused(ctx, sl, other, blocks + begin, nb, o, tm, st_out, true);

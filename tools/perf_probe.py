@@ -11,10 +11,11 @@ ap.add_argument("--kind", type=int, default=host.SYNTH_CBOX)
 ap.add_argument("--tris", type=int, default=0)
 ap.add_argument("--time-kernels", type=int, default=1)
 ap.add_argument("--split", type=int, default=0)
+ap.add_argument("--batch", type=int, default=0)
 a = ap.parse_args()
 cs = host.Scene.synthetic(a.kind, mesh_triangles=a.tris).compile()
 r = device.Renderer(0); r.upload_scene(cs); r.create_framebuffer(a.size, a.size)
-o = device.default_opts(); o.flags = (abi.RENDER_TIME_KERNELS if a.time_kernels else 0) | (abi.RENDER_SPLIT_KERNELS if a.split else 0)
+o = device.default_opts(); o.batch_blocks = a.batch; o.flags = (abi.RENDER_TIME_KERNELS if a.time_kernels else 0) | (abi.RENDER_SPLIT_KERNELS if a.split else 0)
 for i in range(a.reps):
     r.clear(); t = time.time(); st = r.render_frame(a.spp, 1, opts=o); dt = time.time() - t
     print(f"[perf] {a.size}x{a.size}x{a.spp}: {dt*1e3:.2f} ms  {a.size*a.size*a.spp/dt/1e6:.1f} Mpaths/s",
