@@ -214,6 +214,45 @@ int hjh_scene_make_synthetic(int kind, uint32_t mesh_triangles, uint32_t gen_see
   });
 }
 
+int hjh_scene_from_obj(const char* path, hjh_scene** out) {
+  if (!path || !out) return fail(HJ_ERR_INVALID, "null argument");
+  return guarded([&] {
+    auto* s = new hjh_scene();
+    try {
+      s->scene = scene_from_obj(path);
+    } catch (...) {
+      delete s;
+      throw;
+    }
+    *out = s;
+    return (int)HJ_OK;
+  });
+}
+
+int hjh_scene_put_cbox_spheres(hjh_scene* s) {
+  if (!s) return fail(HJ_ERR_INVALID, "null scene");
+  return guarded([&] {
+    put_cbox_spheres(s->scene);
+    return (int)HJ_OK;
+  });
+}
+
+int hjh_write_exr(const char* path, uint32_t w, uint32_t h, const float* rgb) {
+  if (!path || !rgb || !w || !h) return fail(HJ_ERR_INVALID, "bad argument");
+  return guarded([&] {
+    write_exr(path, w, h, rgb);
+    return (int)HJ_OK;
+  });
+}
+
+int hjh_write_pfm(const char* path, uint32_t w, uint32_t h, const float* rgb) {
+  if (!path || !rgb || !w || !h) return fail(HJ_ERR_INVALID, "bad argument");
+  return guarded([&] {
+    write_pfm(path, w, h, rgb);
+    return (int)HJ_OK;
+  });
+}
+
 // hj_block_seed / hj_pass_offset are declared in hijiki_hip.h; the host
 // library exports them too so that a CPU-only host can build block lists.
 uint32_t hj_block_seed(uint64_t master, uint32_t pass, uint32_t j) { return block_seed(master, pass, j); }

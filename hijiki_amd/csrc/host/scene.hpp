@@ -81,4 +81,12 @@ std::vector<BuildNode> build_bvh(const std::vector<Aabb>& boxes);  // node 0 is 
 // Synthetic bench scenes.
 Scene make_synthetic(int kind, uint32_t mesh_triangles, uint32_t gen_seed);
 
+// `Scene::from_obj` (src/main.rs:414-530) and `--put-cbox-spheres` (src/main.rs:1463-1483).
+Scene scene_from_obj(const std::string& path);
+void put_cbox_spheres(Scene& scene);
+
+// Image output (src/main.rs:1395-1419): rgb = W*H*3 floats, row 0 on top.
+void write_pfm(const std::string& path, uint32_t w, uint32_t h, const float* rgb);
+void write_exr(const std::string& path, uint32_t w, uint32_t h, const float* rgb);
+
 }  // namespace hijiki

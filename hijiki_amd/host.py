@@ -56,6 +56,10 @@ def lib():
         L.hjh_make_blocks.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
                                       C.POINTER(abi.ImageBlock), C.c_size_t]
         L.hjh_make_blocks.restype = C.c_size_t
+        L.hjh_scene_from_obj.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.hjh_scene_put_cbox_spheres.argtypes = [vp]
+        L.hjh_write_exr.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, f3]
+        L.hjh_write_pfm.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, f3]
         L.hjh_scene_make_synthetic.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(vp)]
         L.hj_block_seed.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         L.hj_block_seed.restype = C.c_uint32
@@ -101,6 +105,17 @@ class Scene:
         h = C.c_void_p()
         _check(lib().hjh_scene_make_synthetic(kind, mesh_triangles, gen_seed, C.byref(h)))
         return Scene(_handle=h)
+
+    @staticmethod
+    def from_obj(path):
+        """`Scene::from_obj` (src/main.rs:414-530)."""
+        h = C.c_void_p()
+        _check(lib().hjh_scene_from_obj(os.fsencode(path), C.byref(h)))
+        return Scene(_handle=h)
+
+    def put_cbox_spheres(self):
+        """`--put-cbox-spheres` (src/main.rs:1463-1483)."""
+        _check(lib().hjh_scene_put_cbox_spheres(self._h))
 
     def set_camera(self, position, rotation_xyzw, fov_deg):
         _check(lib().hjh_scene_set_camera(self._h, _f3(position), _f3(rotation_xyzw, 4), fov_deg))
@@ -226,6 +241,14 @@ class CompiledScene:
         buf = np.zeros(n, np.uint8)
         _check(lib().hjh_compiled_pack(self._h, buf.ctypes.data, n))
         return buf
+
+
+def write_image(path, rgb):
+    """`Renderer::save_image` tail (src/main.rs:1402-1419): (H, W, 3) float32 -> .exr (3 x FLOAT) or .pfm."""
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    h, w = rgb.shape[:2]
+    fn = lib().hjh_write_pfm if str(path).lower().endswith(".pfm") else lib().hjh_write_exr
+    _check(fn(os.fsencode(path), w, h, rgb.ctypes.data_as(C.POINTER(C.c_float))))
 
 
 def blocks_per_pass(width, height, block_size=abi.BLOCK_SIZE):

@@ -77,6 +77,21 @@ size_t hjh_num_blocks_per_pass(uint32_t width, uint32_t height, uint32_t block_s
 size_t hjh_make_blocks(uint32_t width, uint32_t height, uint32_t block_size, uint64_t master_seed,
                        uint32_t pass_begin, uint32_t pass_end, hj_image_block* out, size_t cap);
 
+/* --- Scene::from_obj, src/main.rs:414-530 ----------------------------------- */
+/* OBJ/MTL load with the semantics of the `tobj` 0.1.11 crate the reference calls (one model per o/g, (v,vt,vn)
+ * re-indexing, fan triangulation, unknown MTL statements kept as strings), material kind by NAME PREFIX
+ * (`light*` -> emissive with `Ke`, `glass*` -> dielectric 1.5, `mirror*` -> mirror, else diffuse `Kd`), every
+ * vertex needs a normal, models without material contribute vertices only, hard-coded camera. */
+int hjh_scene_from_obj(const char* path, hjh_scene** out);
+/* `--put-cbox-spheres`, src/main.rs:1463-1483. */
+int hjh_scene_put_cbox_spheres(hjh_scene* s);
+
+/* --- Renderer::save_image, src/main.rs:1395-1419 ----------------------------- */
+/* rgb = width*height*3 floats (row 0 on top), e.g. from hj_framebuffer_resolve.  EXR: three FLOAT channels
+ * R,G,B, scan-line, uncompressed.  PFM: little-endian "PF". */
+int hjh_write_exr(const char* path, uint32_t width, uint32_t height, const float* rgb);
+int hjh_write_pfm(const char* path, uint32_t width, uint32_t height, const float* rgb);
+
 /* --- Synthetic scenes (bench inputs) ---------- */
 enum hjh_synth_kind {
   HJH_SYNTH_CBOX = 0,         /* Cornell-box-shaped: 12 wall/light triangles + 6320-triangle smooth object */
