@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256) void k_reconstruct(BatchState st, const float*
   const int x = tx0 + (int)(threadIdx.x & 15u), y = ty0 + (int)(threadIdx.x >> 4);
   const bool inimg = x < (int)W && y < (int)H;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (inimg) acc = accum[(size_t)y * W + x];
+  bool touched = false;     // pixels no block of this batch reaches are neither read nor written
   for (uint32_t bi = 0; bi < st.num_blocks; bi++) {
     const hj_image_block b = st.blocks[bi];
     const int ox = (int)b.origin[0], oy = (int)b.origin[1], Dx = (int)b.dimension[0], Dy = (int)b.dimension[1];
@@ -778,6 +778,7 @@ __global__ __launch_bounds__(256) void k_reconstruct(BatchState st, const float*
     if (tx0 + 15 < ox - 2 || tx0 >= ox + Dx + 2 || ty0 + 15 < oy - 2 || ty0 >= oy + Dy + 2) continue;
     const int lx = x - ox, ly = y - oy;
     if (!inimg || lx < -2 || lx >= Dx + 2 || ly < -2 || ly >= Dy + 2) continue;
+    if (!touched) { acc = accum[(size_t)y * W + x]; touched = true; }   // reconstruction.glsl:26
     const uint32_t sbase = bi * kSlotsPerBlock;
     v3 nc = V(0, 0, 0);
     if (lx >= 0 && lx < Dx && ly >= 0 && ly < Dy) nc = xyz(st.smp_nd[sbase + (uint32_t)ly * HJ_BLOCK_SIZE + (uint32_t)lx]);
@@ -798,7 +799,7 @@ __global__ __launch_bounds__(256) void k_reconstruct(BatchState st, const float*
       }
     }
   }
-  if (inimg) accum[(size_t)y * W + x] = acc;
+  if (touched) accum[(size_t)y * W + x] = acc;
 }
 
 }  // namespace hj

@@ -228,6 +228,69 @@ def test_tile_sharding_sums_to_the_full_frame(gpu_renderer, cbox):
         np.testing.assert_allclose(total, full, rtol=3e-6, atol=1e-6)
 
 
+def test_config2_full_size_properties(gpu_renderer, cbox):
+    """BASELINE.json configs[1] at FULL size (cbox 1024x1024, 512 spp = 537 M paths), through size-independent
+    properties: run-to-run bitwise determinism, invariance to the wavefront batch size, additivity over pass
+    ranges, and 8-way tile sharding summing to the 1-GPU frame."""
+    W = H = 1024
+    spp = 512
+    r = gpu_renderer
+    r.upload_scene(cbox)
+    r.create_framebuffer(W, H)
+    st = r.render_frame(spp, 1)
+    a = r.read()
+    assert st["paths"] == W * H * spp and st["closest_rays"] > 3 * st["paths"] and st["shadow_rays"] > st["paths"]
+    assert np.isfinite(a).all() and (a[..., 3] > 0).all()
+    rgb = a[..., :3] / a[..., 3:4]
+    assert 0.05 < rgb.mean() < 1.0 and rgb.min() >= 0
+    o = device.default_opts()
+    o.batch_blocks = 320                      # cuts passes in pieces: 5 blocks of the next pass ride along
+    r.clear()
+    r.render_frame(spp, 1, opts=o)
+    assert (bits(r.read()) == bits(a)).all()
+    r.clear()
+    r.render_frame(spp, 1, pass_begin=0, pass_end=200)
+    r.render_frame(spp, 1, pass_begin=200, pass_end=512)
+    assert (bits(r.read()) == bits(a)).all()
+    total = np.zeros((H, W, 4), np.float64)
+    for rank in range(8):
+        r.clear()
+        r.render_frame(spp, 1, rank=rank, world=8)
+        total += r.read()
+    interior = np.ones((H, W), bool)
+    for e in range(128, 1024, 128):
+        interior[e - 2:e + 2, :] = False
+        interior[:, e - 2:e + 2] = False
+    assert (total[interior].astype(np.float32) == a[interior]).all()
+    np.testing.assert_allclose(total, a, rtol=2e-5, atol=1e-5)
+
+
+def test_large_mesh_and_large_frame(gpu_renderer, oracle):
+    """configs[3]/[4] shapes at reduced sample counts: a 200 k-triangle mesh (deep tree) bit-exact against the oracle,
+    and a 4096 x 4096 frame (1024 blocks per pass, 268 MB framebuffer) sharded 8 ways."""
+    cs = host.Scene.synthetic(host.SYNTH_CBOX_MESH, mesh_triangles=200000).compile()
+    W = H = 256
+    blocks = host.make_blocks(W, H, 1, 3)
+    want, ctr, _ = oracle.render_blocks(cs, blocks, W, H)
+    got, _ = render(gpu_renderer, cs, W, H, blocks)
+    assert_same(got, want, "200k mesh")
+    assert ctr["nodes"] / ctr["closest_calls"] > 40
+    r = gpu_renderer
+    cbox = host.Scene.synthetic(host.SYNTH_CBOX).compile()
+    r.upload_scene(cbox)
+    r.create_framebuffer(4096, 4096)
+    st = r.render_frame(1, 2)
+    full = r.read()
+    assert st["paths"] == 4096 * 4096
+    total = np.zeros_like(full, dtype=np.float64)
+    for rank in range(8):
+        r.clear()
+        r.render_frame(1, 2, rank=rank, world=8)
+        total += r.read()
+    np.testing.assert_allclose(total, full, rtol=2e-6, atol=1e-6)
+    r.create_framebuffer(64, 64)              # release the 268 MB buffer for the tests that follow
+
+
 def test_error_paths(gpu_renderer, cbox_small):
     r = device.Renderer(0)
     blocks = host.make_blocks(128, 128, 1, 1)
