@@ -219,12 +219,8 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     uint32_t burst = sc.inner_burst;       // lanes standing on a leaf wait at most this many box steps of the others
     while (active && cur < nn && !at_leaf && burst != 0) {
       float4 n0, n1;
-#ifdef HJ_NO_LDS_NODES
-      n0 = sc.nodes[2 * cur]; n1 = sc.nodes[2 * cur + 1];
-#else
       if (cur < nhot) { n0 = s_n0[cur]; n1 = s_n1[cur]; }                 // hot node: LDS copy
       else { n0 = sc.nodes[2 * cur]; n1 = sc.nodes[2 * cur + 1]; }
-#endif
       at_leaf = node_step(n0, n1, inv, off, r, cur, shape, ex);
       burst--;
     }
