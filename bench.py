@@ -153,12 +153,12 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
         # WRITE_SIZE in separate runs of this command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); only
-        # quoted when the launch shape is the one that was profiled (1024x1024, 512-block batches).
+        # quoted for the workload that was profiled (cbox 1024x1024, 512 spp, 1 GPU).
         traffic = traffic_bytes = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v2_pmc_hbm_traffic.json")))
-            if (W, H) == (1024, 1024) and world == 1 and agg["paths"] / launches == pmc["paths_per_launch"]:
-                traffic_bytes = pmc["traffic_bytes_per_launch_corrected"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v3_pmc_hbm_traffic.json")))
+            if (W, H, spp) == (1024, 1024, 512) and world == 1:
+                traffic_bytes = round(pmc["traffic_bytes_per_path_corrected"] * agg["paths"] / launches)
                 traffic = round(traffic_bytes / (avg_ms * 1e-3) / 1e9, 1)
         except (OSError, ValueError, KeyError):
             pass
