@@ -85,6 +85,12 @@ struct hj_context {
 
 namespace {
 
+int env_int(const char* name, int dflt, int lo, int hi) {
+  const char* v = std::getenv(name);
+  if (!v || !*v) return dflt;
+  return std::min(hi, std::max(lo, std::atoi(v)));
+}
+
 int set_error(hj_context* ctx, int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -470,8 +476,9 @@ int hj_context_create(int device, hj_context** out) {
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail(e, "hipGetDeviceProperties");
   ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
-  ctx->num_wg = (uint32_t)ctx->num_cus * (std::getenv("HJ_WG_PER_CU") ? (uint32_t)std::atoi(std::getenv("HJ_WG_PER_CU")) : 8u);   // 8 workgroups of 4 waves per CU = the 32-wave CU limit
-  if (std::getenv("HJ_SLOTS")) ctx->num_slots = std::min<uint32_t>(kMaxSlots, std::max(1, std::atoi(std::getenv("HJ_SLOTS"))));
+  // Tuning knobs (environment overrides exist only for sweeps; the defaults are the measured optima).
+  ctx->num_wg = (uint32_t)ctx->num_cus * (uint32_t)env_int("HJ_WG_PER_CU", 8, 1, 32);   // 8 x 4 waves = the 32-wave CU limit
+  ctx->num_slots = (uint32_t)env_int("HJ_SLOTS", 3, 1, (int)kMaxSlots);
   for (auto& sl : ctx->slots) {
     if ((e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     if ((e = hipHostMalloc((void**)&sl.h_counts, sizeof(uint32_t) * 4 * ctx->num_wg, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
@@ -584,8 +591,8 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     }
     d.root = N ? map[0] : 0u;
     d.num_hot = (uint32_t)hot;
-    d.inner_burst = std::max(1, std::getenv("HJ_INNER_BURST") ? std::atoi(std::getenv("HJ_INNER_BURST")) : 4);
-    d.refill_min = std::getenv("HJ_REFILL_MIN") ? (uint32_t)std::atoi(std::getenv("HJ_REFILL_MIN")) : hj::kRefillMin;
+    d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", 4, 1, 1 << 20);   // >= 1, or the walk would never advance
+    d.refill_min = (uint32_t)env_int("HJ_REFILL_MIN", (int)hj::kRefillMin, 1, 64);
     HJ_UP(upload(ctx, dev.data(), dev.size(), &d.nodes));
   }
   HJ_UP(upload(ctx, isect.data(), isect.size(), &d.tri_isect));

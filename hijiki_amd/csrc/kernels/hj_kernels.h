@@ -1,25 +1,26 @@
 // Wavefront path-tracing kernels for gfx950 (wave64).
 //
-// One batch = up to `capacity` camera paths (many ImageBlocks of many passes)
-// advanced one bounce per round:
+// One batch = up to `capacity` camera paths (many ImageBlocks of many passes).  Every path workgroup owns one
+// private segment of every queue (hj_device.h) and advances ITS paths one bounce per round:
 //
-//   k_gen_camera                         render.glsl:149-162  seed, camera ray, queue
+//   stage_gen_camera     render.glsl:149-162                 seed, camera ray, queue
 //   per bounce:
-//     k_trace_closest  (ray queue)       scene.glsl:97-133    skip-link BVH walk -> hit record,
-//                                                             hits binned by MATERIAL TAG (wave ballot)
-//     k_shade          (hit queues)      scene.glsl:160-175, render.glsl:102-144, material.glsl
-//                                                             populate, emission, NEE sample, BSDF sample,
-//                                                             roulette -> next ray queue + shadow queue
-//     k_trace_shadow   (shadow queue)    scene.glsl:92-96     any-hit walk (boolean-equivalent to the
-//                                                             reference's closest-hit), adds NEE radiance
-//   k_recon_weights / k_reconstruct      reconstruction.glsl:22-66
+//     stage_trace_closest  scene.glsl:97-133                 skip-link BVH walk -> hit record, hits binned by
+//                                                            MATERIAL TAG (wave ballot + LDS counters)
+//     stage_shade          scene.glsl:160-175, render.glsl:102-144, material.glsl
+//                                                            populate, emission, NEE sample, BSDF sample,
+//                                                            roulette -> next ray queue + shadow queue
+//     stage_trace_shadow   scene.glsl:92-96                  any-hit walk (boolean-equivalent to the reference's
+//                                                            closest-hit), adds NEE radiance
+//   k_recon_weights / k_reconstruct   reconstruction.glsl:22-66
 //
-// Queues are split into one private segment per workgroup (hj_device.h): appends go through LDS counters
-// (wave ballot + one ds_add per wave), never through global atomics.
+// k_path_wavefront runs all stages of a batch in ONE persistent launch (workgroup barriers only);
+// k_gen_camera / k_trace_closest / k_shade / k_trace_shadow launch them one by one (diagnostic path).
+// No stage uses a global atomic: appends are wave ballot + one LDS atomic.
 //
-// Every path owns its RNG state, so queue order never changes results; the
-// per-path order of radiance additions is the reference's (emission, then
-// NEE, bounce by bounce) because each bounce's kernels run in stream order.
+// Every path owns its RNG state, so queue order never changes results; the per-path order of radiance
+// additions is the reference's (emission, then NEE, bounce by bounce) because a workgroup's stages are
+// separated by barriers (fused) or kernel boundaries (split).
 #pragma once
 #include "hj_device.h"
 
