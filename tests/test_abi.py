@@ -78,3 +78,16 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".h", ".hpp", ".cpp", ".hip")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "hj_oracle" not in text and "oracle/" not in text and "from oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_headers_are_plain_c99_and_layouts_hold(tmp_path):
+    """The boundary is a C ABI: both public headers compile as C99 (-pedantic) and the example host, whose static
+    asserts restate SURVEY.md Appendix A's sizes/offsets, links against the two libraries."""
+    import subprocess
+    exe = str(tmp_path / "render_cbox")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "render_cbox.c"), "-L" + os.path.join(ROOT, "hijiki_amd", "lib"),
+           "-lhijiki_hip", "-lhijiki_host", "-Wl,-rpath," + os.path.join(ROOT, "hijiki_amd", "lib"),
+           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -333,3 +333,18 @@ def test_external_framebuffer_torch_tensor(cbox_small, oracle):
         r.render_blocks(blocks)
     want, _, _ = oracle.render_blocks(cbox_small, blocks, W, H)
     assert (bits(fb.cpu().numpy()) == bits(want)).all()
+
+
+def test_pure_c_host_example(tmp_path):
+    """examples/render_cbox.c: a C99 program drives scene build -> upload -> render -> EXR through the two C ABIs."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe, out = str(tmp_path / "render_cbox"), str(tmp_path / "o.exr")
+    cmd = ["gcc", "-std=c99", "-Wall", "-pedantic", "-I" + os.path.join(root, "include"),
+           os.path.join(root, "examples", "render_cbox.c"), "-L" + os.path.join(root, "hijiki_amd", "lib"),
+           "-lhijiki_hip", "-lhijiki_host", "-Wl,-rpath," + os.path.join(root, "hijiki_amd", "lib"),
+           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-o", exe]
+    assert subprocess.run(cmd, capture_output=True, text=True).returncode == 0
+    r = subprocess.run([exe, out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "8388608 paths" in r.stdout and os.path.getsize(out) > 512 * 512 * 12
