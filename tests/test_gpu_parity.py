@@ -348,3 +348,45 @@ def test_pure_c_host_example(tmp_path):
     r = subprocess.run([exe, out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "8388608 paths" in r.stdout and os.path.getsize(out) > 512 * 512 * 12
+
+
+def test_edge_inputs(gpu_renderer, oracle):
+    """Empty block list, 1x1 blocks, a scene without emitters, a camera that sees nothing."""
+    r = gpu_renderer
+    # no emitters: NEE draws its 3 numbers and contributes nothing (the reference reads emitters[0] out of bounds)
+    s = host.Scene()
+    s.set_camera_cbox()
+    d = s.add_diffuse((0.8, 0.7, 0.6))
+    s.add_quad((-1, 0, 1), (2, 0, 0), (0, 0, -2), d)
+    s.add_quad((-1, 0, -1), (2, 0, 0), (0, 1.6, 0), d)
+    cs = s.compile()
+    W = H = 128
+    r.upload_scene(cs)
+    r.create_framebuffer(W, H)
+    st = r.render_blocks((abi.ImageBlock * 0)())
+    assert st["paths"] == 0 and (r.read() == 0).all()
+    blocks = host.make_blocks(W, H, 2, 1)
+    want, ctr, _ = oracle.render_blocks(cs, blocks, W, H)
+    r.render_blocks(blocks)
+    got = r.read()
+    assert_same(got, want, "no emitters")
+    assert ctr["shadow_calls"] == 0 and (got[..., :3] == 0).all() and (got[..., 3] > 0).all()
+    # 1x1 and 3x2 blocks anywhere in the image
+    mk = lambda i, ox, oy, dx, dy: abi.ImageBlock(id=i, seed=100 + i, origin=(ox, oy), dimension=(dx, dy),
+                                                  original_dimension=(W, H), sample_offset=(0.25, 0.75))
+    tiny = (abi.ImageBlock * 3)(mk(0, 0, 0, 1, 1), mk(1, 127, 127, 1, 1), mk(2, 60, 61, 3, 2))
+    want, _, _ = oracle.render_blocks(cs, tiny, W, H)
+    r.clear()
+    r.render_blocks(tiny)
+    assert_same(r.read(), want, "tiny blocks")
+    # a camera looking away from everything: every path misses at bounce 0
+    s2 = host.Scene()
+    s2.set_camera((0, 0.9, 5.4), (0, 1, 0, 0), 27.7)      # rotated 180 deg about +y: looks along +z, away from the box
+    e = s2.add_emissive((5, 5, 5))
+    s2.add_quad((-1, 0, 1), (2, 0, 0), (0, 0, -2), e)
+    s2.add_quad((-1, 0, -1), (2, 0, 0), (0, 1.6, 0), e)
+    cs2 = s2.compile()
+    want, ctr, _ = oracle.render_blocks(cs2, blocks, W, H)
+    got, st = render(r, cs2, W, H, blocks)
+    assert_same(got, want, "all miss")
+    assert ctr["hits"] == 0 and st["closest_rays"] == st["paths"] and st["shadow_rays"] == 0
