@@ -29,7 +29,7 @@ hijiki_amd/lib/libhijiki_host.so: $(HOST_SRC) $(HOST_HDR)
 hijiki_amd/lib/libhijiki_hip.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p hijiki_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -shared $(FP_STRICT) -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden \
-	  -Wall -Wno-unused-function hijiki_amd/csrc/hj_api.hip hijiki_amd/csrc/host/blockgen.cpp -o $@ \
+	  -Wall -Wno-unused-function hijiki_amd/csrc/hj_api.hip hijiki_amd/csrc/host/blockgen.cpp -ldl -o $@ \
 	  -Rpass-analysis=kernel-resource-usage 2> hijiki_amd/lib/resource_usage.txt || (cat hijiki_amd/lib/resource_usage.txt; false)
 	@strings $@ | grep -q 'amdgcn-amd-amdhsa--$(ARCH)' || (echo 'ERROR: no $(ARCH) code object in $@'; rm -f $@; false)
 

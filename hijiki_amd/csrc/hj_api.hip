@@ -6,6 +6,7 @@
 // entry point that computes needs a HIP device and fails with HJ_ERR_DEVICE
 // otherwise.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -788,6 +789,79 @@ int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed, uint32_
   }
   if (stats) *stats = total;
   return rc;
+}
+
+// RCCL through dlopen: the library itself has no link-time dependency on librccl (and a process that already
+// carries PyTorch's copy keeps using that one).
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  int (*CommInitAll)(void**, int, const int*) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool load() {
+    if (lib) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) return false;
+    CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+    Reduce = reinterpret_cast<decltype(Reduce)>(dlsym(lib, "ncclReduce"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    return CommInitAll && CommDestroy && GroupStart && GroupEnd && Reduce && GetErrorString;
+  }
+};
+Rccl g_rccl;
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;   // ncclFloat / ncclSum of rccl.h
+}  // namespace
+
+int hj_reduce_framebuffers(hj_context* const* ctxs, int n, int root) {
+  if (!ctxs || n < 1 || root < 0 || root >= n) return HJ_ERR_INVALID;
+  hj_context* r = ctxs[root];
+  if (!r) return HJ_ERR_INVALID;
+  for (int i = 0; i < n; i++) {
+    if (!ctxs[i] || !ctxs[i]->accum) return set_error(r, HJ_ERR_STATE, "context %d has no framebuffer", i);
+    if (ctxs[i]->width != r->width || ctxs[i]->height != r->height) return set_error(r, HJ_ERR_INVALID, "framebuffer sizes differ");
+    for (int j = 0; j < i; j++)
+      if (ctxs[j]->device == ctxs[i]->device) return set_error(r, HJ_ERR_INVALID, "contexts %d and %d share GPU %d", j, i, ctxs[i]->device);
+  }
+  for (int i = 0; i < n; i++) {
+    HJ_HIP(r, hipSetDevice(ctxs[i]->device));
+    const int rc = sync_all(ctxs[i]);
+    if (rc != HJ_OK) return rc;
+  }
+  if (n == 1) return HJ_OK;
+  if (!g_rccl.load()) return set_error(r, HJ_ERR_UNSUPPORTED, "librccl.so could not be loaded: %s", dlerror());
+  std::vector<void*> comms((size_t)n, nullptr);
+  std::vector<int> devs((size_t)n);
+  for (int i = 0; i < n; i++) devs[(size_t)i] = ctxs[i]->device;
+  int nrc = g_rccl.CommInitAll(comms.data(), n, devs.data());
+  if (nrc != 0) return set_error(r, HJ_ERR_DEVICE, "ncclCommInitAll: %s", g_rccl.GetErrorString(nrc));
+  const size_t count = (size_t)r->width * r->height * 4;
+  nrc = g_rccl.GroupStart();
+  for (int i = 0; i < n && nrc == 0; i++) {
+    (void)hipSetDevice(ctxs[i]->device);
+    nrc = g_rccl.Reduce(ctxs[i]->accum, ctxs[i]->accum, count, kNcclFloat32, kNcclSum, root, comms[(size_t)i], ctxs[i]->stream);
+  }
+  const int erc = g_rccl.GroupEnd();
+  if (nrc == 0) nrc = erc;
+  int rc = HJ_OK;
+  for (int i = 0; i < n; i++) {
+    (void)hipSetDevice(ctxs[i]->device);
+    if (hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) rc = HJ_ERR_DEVICE;
+  }
+  for (void* c : comms)
+    if (c) (void)g_rccl.CommDestroy(c);
+  if (nrc != 0) return set_error(r, HJ_ERR_DEVICE, "ncclReduce: %s", g_rccl.GetErrorString(nrc));
+  if (rc != HJ_OK) return set_error(r, rc, "stream synchronisation after the reduce failed");
+  return HJ_OK;
 }
 
 int hj_debug_trace(hj_context* ctx, const float* rays, size_t n, uint32_t use_bvh, uint32_t any_hit, float* hits) {

@@ -19,7 +19,7 @@ _LIB = None
 EXPORTS = ("hj_context_create", "hj_context_destroy", "hj_last_error", "hj_version", "hj_default_render_opts",
            "hj_scene_upload", "hj_framebuffer_create", "hj_framebuffer_clear", "hj_framebuffer_device_ptr",
            "hj_framebuffer_read", "hj_framebuffer_resolve", "hj_render_blocks", "hj_render_frame", "hj_block_seed",
-           "hj_pass_offset", "hj_debug_trace", "hj_debug_samples")
+           "hj_pass_offset", "hj_debug_trace", "hj_debug_samples", "hj_reduce_framebuffers")
 
 
 def lib():
@@ -49,6 +49,7 @@ def lib():
                                        C.POINTER(abi.RenderStats)]
         L.hj_render_frame.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.POINTER(abi.RenderOpts), C.POINTER(abi.RenderStats)]
+        L.hj_reduce_framebuffers.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
         L.hj_debug_trace.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
         L.hj_debug_samples.argtypes = [vp, C.POINTER(abi.ImageBlock), C.POINTER(abi.RenderOpts), C.POINTER(C.c_float)]
         L.hj_block_seed.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
@@ -57,6 +58,14 @@ def lib():
         L.hj_pass_offset.restype = None
         _LIB = L
     return _LIB
+
+
+def reduce_framebuffers(renderers, root=0):
+    """hj_reduce_framebuffers: RCCL sum of the framebuffers of several in-process renderers (one per GPU) into `root`."""
+    arr = (C.c_void_p * len(renderers))(*[r._h for r in renderers])
+    rc = lib().hj_reduce_framebuffers(arr, len(renderers), root)
+    if rc != abi.HJ_OK:
+        raise abi.HijikiError(rc, lib().hj_last_error(renderers[root]._h).decode())
 
 
 def default_opts():

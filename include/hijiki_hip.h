@@ -237,6 +237,15 @@ int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed,
                     uint32_t rank, uint32_t world,
                     const hj_render_opts* opts, hj_render_stats* stats);
 
+/* ---------------------------------------------------------------- multi-GPU */
+
+/* New with the multi-GPU tile sharding (no counterpart in the reference): element-wise SUM of the framebuffers of
+ * `n` contexts of THIS process (one per GPU, equal sizes) into ctxs[root], with one ncclReduce per GPU inside a
+ * group call over xGMI (RCCL is loaded with dlopen on first use; n == 1 needs no RCCL).  Hosts that run one
+ * process per GPU reduce the external framebuffer themselves instead (hijiki_amd/dist.py does, through
+ * torch.distributed).  Resolve rgb/w only after the reduce. */
+int hj_reduce_framebuffers(hj_context* const* ctxs, int n, int root);
+
 /* ------------------------------------------------------------------- probes */
 
 /* Function-level probes used by the parity tests (no counterpart in the

@@ -390,3 +390,18 @@ def test_edge_inputs(gpu_renderer, oracle):
     got, st = render(r, cs2, W, H, blocks)
     assert_same(got, want, "all miss")
     assert ctr["hits"] == 0 and st["closest_rays"] == st["paths"] and st["shadow_rays"] == 0
+
+
+def test_in_process_reduce_entry_point(gpu_renderer, cbox_small):
+    """hj_reduce_framebuffers: with one context it is a no-op that leaves the frame intact (several GPUs are not
+    available to this test; argument checking is)."""
+    r = gpu_renderer
+    r.upload_scene(cbox_small)
+    r.create_framebuffer(128, 128)
+    r.render_frame(1, 1)
+    before = r.read()
+    device.reduce_framebuffers([r], root=0)
+    assert (bits(r.read()) == bits(before)).all()
+    with pytest.raises(abi.HijikiError) as e:
+        device.reduce_framebuffers([r, r], root=0)            # two contexts on one GPU
+    assert e.value.status == abi.HJ_ERR_INVALID
