@@ -604,6 +604,39 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
   HJ_UP(upload(ctx, s->vertices, s->num_vertices, &d.vertices));
   HJ_UP(upload(ctx, s->materials, s->num_materials, &d.materials));
   HJ_UP(upload(ctx, s->emitters, s->num_emitters, &d.emitters));
+  {
+    std::vector<float4> rec((size_t)hj::kEmitRecF4 * s->num_emitters, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (size_t i = 0; i < s->num_emitters; i++) {
+      float4* r = &rec[(size_t)hj::kEmitRecF4 * i];
+      const uint32_t shape = s->emitters[i].shape;
+      const hj_emissive& em = s->emissive[s->materials[shape] & HJ_MATERIAL_INDEX_MASK];
+      uint32_t kind;
+      if (shape < s->num_spheres) {
+        kind = 0;
+        const hj_sphere& sp = s->spheres[shape];
+        r[1] = make_float4(sp.center[0], sp.center[1], sp.center[2], 0.f);
+        r[0].z = sp.radius;
+      } else if (shape < s->num_spheres + s->num_quads) {
+        kind = 1;
+        const hj_quad& q = s->quads[shape - s->num_spheres];
+        r[1] = make_float4(q.origin[0], q.origin[1], q.origin[2], 0.f);
+        r[2] = make_float4(q.edge1[0], q.edge1[1], q.edge1[2], 0.f);
+        r[3] = make_float4(q.edge2[0], q.edge2[1], q.edge2[2], 0.f);
+      } else {
+        kind = 2;
+        const hj_triangle& t = s->triangles[shape - s->num_spheres - s->num_quads];
+        for (int k = 0; k < 3; k++) {
+          const hj_vertex& v = s->vertices[t.v[k]];
+          r[1 + k] = make_float4(v.pos[0], v.pos[1], v.pos[2], 0.f);
+          r[4 + k] = make_float4(v.normal[0], v.normal[1], v.normal[2], 0.f);
+        }
+      }
+      r[0].x = s->emitters[i].pdf;
+      r[0].y = __builtin_bit_cast(float, kind);
+      r[1].w = em.power[0]; r[2].w = em.power[1]; r[3].w = em.power[2];
+    }
+    HJ_UP(upload(ctx, rec.data(), rec.size(), &d.emit_rec));
+  }
   HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->diffuse), s->num_diffuse, &d.diffuse));
   HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->diffusecb), 2 * s->num_diffusecb, &d.diffusecb));
   HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->dielectric), s->num_dielectric, &d.dielectric));

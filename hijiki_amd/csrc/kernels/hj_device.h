@@ -8,6 +8,11 @@ namespace hj {
 
 constexpr uint32_t kSlotsPerBlock = HJ_BLOCK_SIZE * HJ_BLOCK_SIZE;  // fixed 128x128 slot grid per ImageBlock
 constexpr uint32_t kNumTags = 5;
+// Pre-gathered emitter record, 7 x float4 (every value copied verbatim from the reference arrays):
+//   r0 = (emitter.pdf, kind bits [0 sphere, 1 quad, 2 triangle], sphere radius, -)
+//   r1..r3 = (sphere centre | quad origin, edge1, edge2 | triangle a, b, c).xyz, w = emissive power r, g, b
+//   r4..r6 = triangle vertex normals
+constexpr uint32_t kEmitRecF4 = 7;
 constexpr uint32_t kHotNodes = 256;     // 8 KB of LDS per workgroup
 constexpr uint32_t kInnerFlag = 0x80000000u;
 
@@ -39,6 +44,7 @@ struct DeviceScene {
   const hj_vertex* vertices;    // original vertices (emitter sampling)
   const uint32_t* materials;
   const hj_emitter* emitters;
+  const float4* emit_rec;       // kEmitRecF4 float4 per emitter, pre-gathered (see below)
   const float4* diffuse;
   const float4* diffusecb;      // 2 x float4 per record
   const float4* dielectric;

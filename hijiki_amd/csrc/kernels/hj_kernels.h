@@ -289,20 +289,23 @@ HJ_DEV v3 sample_emitter(const DeviceScene& sc, v3 ref, uint32_t& rng, v3& sh_di
   }
   uint32_t e = 0;
   for (uint32_t i = 0; i < sc.num_emitters; i++) {
-    xi -= sc.emitters[i].pdf;
+    xi -= __uint_as_float(__float_as_uint(sc.emit_rec[kEmitRecF4 * i].x));   // emitters[i].pdf
     if (xi < 0.0f) { e = i; break; }
   }
-  const hj_emitter em = sc.emitters[e];
-  const uint32_t shape = em.shape;
+  // one pre-gathered record per emitter (hj_device.h) instead of emitter -> indices -> 3 vertices -> material word
+  // -> material: the values are the ones those arrays hold, the chain of dependent fetches is gone
+  const float4* __restrict__ er = sc.emit_rec + (size_t)kEmitRecF4 * e;
+  const float4 r0 = er[0], r1 = er[1], r2 = er[2], r3 = er[3];
+  const float em_pdf = r0.x;
+  const uint32_t kind = __float_as_uint(r0.y);
+  const v3 power = V(r1.w, r2.w, r3.w);
   SRec sr;
-  if (shape < sc.ns) {                       // sphere.glsl:54-58
-    const float4 sp = sc.spheres[shape];
+  if (kind == 0u) {                          // sphere.glsl:54-58
     sr.n = rand_uniform_sphere(rng);
-    sr.p = xyz(sp) + sr.n * sp.w;
-    sr.pdf = 1.0f / (((sp.w * sp.w) * 4.0f) * kPi);
-  } else if (shape < sc.ns + sc.nq) {        // quad.glsl:34-45
-    const uint32_t ix = shape - sc.ns;
-    const v3 o = xyz(sc.quads[3 * ix]), e1 = xyz(sc.quads[3 * ix + 1]), e2 = xyz(sc.quads[3 * ix + 2]);
+    sr.p = xyz(r1) + sr.n * r0.z;
+    sr.pdf = 1.0f / (((r0.z * r0.z) * 4.0f) * kPi);
+  } else if (kind == 1u) {                   // quad.glsl:34-45
+    const v3 o = xyz(r1), e1 = xyz(r2), e2 = xyz(r3);
     const v3 n = cross3(e1, e2);
     const float area = len3(n);
     sr.n = divs(n, area);
@@ -310,27 +313,22 @@ HJ_DEV v3 sample_emitter(const DeviceScene& sc, v3 ref, uint32_t& rng, v3& sh_di
     sr.p = (o + e1 * u) + e2 * v;
     sr.pdf = 1.0f / area;
   } else {                                   // triangle.glsl:81-102
-    const hj_triangle T = sc.triangles[shape - sc.ns - sc.nq];
-    const hj_vertex* A = &sc.vertices[T.v[0]];
-    const hj_vertex* B = &sc.vertices[T.v[1]];
-    const hj_vertex* C = &sc.vertices[T.v[2]];
-    const v3 a = ld3(A->pos), b = ld3(B->pos), c = ld3(C->pos);
+    const float4 r4 = er[4], r5 = er[5], r6 = er[6];
+    const v3 a = xyz(r1), b = xyz(r2), c = xyz(r3);
     const v3 n = cross3(b - a, c - a);
     const float area = len3(n) * 0.5f;
     const v3 l = rand_barycentric(rng);
-    sr.n = normalize3((ld3(A->normal) * l.x + ld3(B->normal) * l.y) + ld3(C->normal) * l.z);
+    sr.n = normalize3((xyz(r4) * l.x + xyz(r5) * l.y) + xyz(r6) * l.z);
     sr.p = (a * l.x + b * l.y) + c * l.z;
     sr.pdf = 1.0f / area;
   }
-  const uint32_t mat = sc.materials[shape];
-  const v3 power = xyz(sc.emissive[mat & HJ_MATERIAL_INDEX_MASK]);
   v3 dir = sr.p - ref;
   const float dist = len3(dir);
   dir = divs(dir, dist);
   sh_dir = dir; sh_tmax = dist - kEps;
   const float cosT = -dot3(dir, sr.n);
   if (cosT < 0.0f) return V(0, 0, 0);
-  const float pdf = (((em.pdf * sr.pdf) * dist) * dist) / cosT;
+  const float pdf = (((em_pdf * sr.pdf) * dist) * dist) / cosT;
   return divs(power, pdf);
 }
 
