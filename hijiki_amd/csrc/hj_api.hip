@@ -66,7 +66,9 @@ struct hj_context {
   struct BatchSlot {
     hj::BatchState st{};
     std::vector<DevBuf> bufs;
-    DevBuf d_blocks, d_wtab;
+    DevBuf d_blocks, d_wtab, d_tiles;
+    uint32_t* h_tiles = nullptr;          // pinned staging of the per-tile block lists
+    size_t h_tiles_cap = 0;
     hipStream_t stream = nullptr;
     hj_image_block* h_blocks = nullptr;   // pinned staging of the block list
     uint32_t h_blocks_cap = 0;
@@ -284,12 +286,62 @@ struct Timer {
 int enqueue_reconstruct(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::BatchSlot& other, const hj::BatchState& st,
                         uint32_t nb, const hj_render_opts& o, Timer& tm) {
   hipStream_t s = sl.stream;
+  // Per 16x16 pixel tile, the blocks of this batch whose extended rectangle touches it, in list order (CSR).
+  // Built here on the host, which is idle while the path kernel of this batch runs.
+  const uint32_t tw = (ctx->width + 15) / 16, th = (ctx->height + 15) / 16, ntiles = tw * th;
+  const int R = 2;
+  auto tile_range = [&](const hj_image_block& b, uint32_t& x0, uint32_t& x1, uint32_t& y0, uint32_t& y1) -> bool {
+    const long px0 = std::max<long>(0, (long)b.origin[0] - R), py0 = std::max<long>(0, (long)b.origin[1] - R);
+    const long px1 = std::min<long>(ctx->width, (long)b.origin[0] + b.dimension[0] + R);
+    const long py1 = std::min<long>(ctx->height, (long)b.origin[1] + b.dimension[1] + R);
+    if (px0 >= px1 || py0 >= py1) return false;
+    x0 = (uint32_t)(px0 / 16); x1 = (uint32_t)((px1 - 1) / 16); y0 = (uint32_t)(py0 / 16); y1 = (uint32_t)((py1 - 1) / 16);
+    return true;
+  };
+  size_t entries = 0;
+  for (uint32_t bi = 0; bi < nb; bi++) {
+    uint32_t x0, x1, y0, y1;
+    if (tile_range(sl.h_blocks[bi], x0, x1, y0, y1)) entries += (size_t)(x1 - x0 + 1) * (y1 - y0 + 1);
+  }
+  const size_t words = (size_t)ntiles + 1 + entries;
+  if (sl.h_tiles_cap < words) {
+    if (sl.h_tiles) (void)hipHostFree(sl.h_tiles);
+    sl.h_tiles = nullptr;
+    sl.h_tiles_cap = 0;
+    HJ_HIP(ctx, hipHostMalloc((void**)&sl.h_tiles, sizeof(uint32_t) * words * 2, hipHostMallocDefault));
+    sl.h_tiles_cap = words * 2;
+  }
+  {
+    const int rc = dev_alloc(ctx, sl.d_tiles, sizeof(uint32_t) * words);
+    if (rc != HJ_OK) return rc;
+  }
+  uint32_t* off = sl.h_tiles;
+  uint32_t* blk = sl.h_tiles + ntiles + 1;
+  std::memset(off, 0, sizeof(uint32_t) * (ntiles + 1));
+  for (uint32_t bi = 0; bi < nb; bi++) {
+    uint32_t x0, x1, y0, y1;
+    if (!tile_range(sl.h_blocks[bi], x0, x1, y0, y1)) continue;
+    for (uint32_t ty = y0; ty <= y1; ty++)
+      for (uint32_t tx = x0; tx <= x1; tx++) off[ty * tw + tx + 1]++;
+  }
+  for (uint32_t t = 0; t < ntiles; t++) off[t + 1] += off[t];
+  {
+    std::vector<uint32_t> cur(off, off + ntiles);
+    for (uint32_t bi = 0; bi < nb; bi++) {       // ascending bi per tile = the order the reference accumulates in
+      uint32_t x0, x1, y0, y1;
+      if (!tile_range(sl.h_blocks[bi], x0, x1, y0, y1)) continue;
+      for (uint32_t ty = y0; ty <= y1; ty++)
+        for (uint32_t tx = x0; tx <= x1; tx++) blk[cur[ty * tw + tx]++] = bi;
+    }
+  }
+  HJ_HIP(ctx, hipMemcpyAsync(sl.d_tiles.p, sl.h_tiles, sizeof(uint32_t) * words, hipMemcpyHostToDevice, s));
   if (other.recon_recorded) HJ_HIP(ctx, hipStreamWaitEvent(s, other.ev_recon, 0));
   const int ev = tm.begin(EV_RECON, s);
   hipLaunchKernelGGL(hj::k_recon_weights, dim3((nb * 25 + 255) / 256), dim3(256), 0, s, st.blocks, nb, o.recon_stddev,
                      static_cast<float*>(sl.d_wtab.p));
-  hipLaunchKernelGGL(hj::k_reconstruct, dim3((ctx->width + 15) / 16, (ctx->height + 15) / 16), dim3(256), 0, s, st,
-                     static_cast<const float*>(sl.d_wtab.p), ctx->accum, ctx->width, ctx->height);
+  const uint32_t* d_off = static_cast<const uint32_t*>(sl.d_tiles.p);
+  hipLaunchKernelGGL(hj::k_reconstruct, dim3(tw, th), dim3(256), 0, s, st, static_cast<const float*>(sl.d_wtab.p), d_off,
+                     d_off + ntiles + 1, ctx->accum, ctx->width, ctx->height);
   tm.end(ev, s);
   HJ_HIP(ctx, hipEventRecord(sl.ev_recon, s));
   sl.recon_recorded = true;
@@ -501,6 +553,8 @@ void hj_context_destroy(hj_context* ctx) {
   for (auto& sl : ctx->slots) {
     sl.d_blocks.release();
     sl.d_wtab.release();
+    sl.d_tiles.release();
+    if (sl.h_tiles) (void)hipHostFree(sl.h_tiles);
     if (sl.h_blocks) (void)hipHostFree(sl.h_blocks);
     if (sl.h_counts) (void)hipHostFree(sl.h_counts);
     for (hipEvent_t ev : {sl.ev_count[0], sl.ev_count[1], sl.ev_recon, sl.ev_done})

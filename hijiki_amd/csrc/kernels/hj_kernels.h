@@ -759,18 +759,23 @@ __global__ void k_recon_weights(const hj_image_block* blocks, uint32_t num_block
 // One thread per output pixel; gathers, IN BLOCK ORDER, what every block of
 // the batch splats onto it.  Per-pixel addition order == the reference's
 // serial per-block dispatch order (reconstruction.glsl:22-66, main.rs:1316-1355).
+// tile_off / tile_blk: for every 16x16 pixel tile the batch's blocks (ascending = list order) whose 2-pixel-extended
+// rectangle touches the tile, built on the host while the path kernel runs (CSR layout).
 __global__ __launch_bounds__(256) void k_reconstruct(BatchState st, const float* __restrict__ wtab,
+                                                     const uint32_t* __restrict__ tile_off,
+                                                     const uint32_t* __restrict__ tile_blk,
                                                      float4* __restrict__ accum, uint32_t W, uint32_t H) {
   const int tx0 = (int)(blockIdx.x * 16u), ty0 = (int)(blockIdx.y * 16u);
   const int x = tx0 + (int)(threadIdx.x & 15u), y = ty0 + (int)(threadIdx.x >> 4);
   const bool inimg = x < (int)W && y < (int)H;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   bool touched = false;     // pixels no block of this batch reaches are neither read nor written
-  for (uint32_t bi = 0; bi < st.num_blocks; bi++) {
+  const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
+  const uint32_t i0 = tile_off[tile], i1 = tile_off[tile + 1];
+  for (uint32_t idx = i0; idx < i1; idx++) {
+    const uint32_t bi = tile_blk[idx];
     const hj_image_block b = st.blocks[bi];
     const int ox = (int)b.origin[0], oy = (int)b.origin[1], Dx = (int)b.dimension[0], Dy = (int)b.dimension[1];
-    // tile-level (wave-uniform) cull
-    if (tx0 + 15 < ox - 2 || tx0 >= ox + Dx + 2 || ty0 + 15 < oy - 2 || ty0 >= oy + Dy + 2) continue;
     const int lx = x - ox, ly = y - oy;
     if (!inimg || lx < -2 || lx >= Dx + 2 || ly < -2 || ly >= Dy + 2) continue;
     if (!touched) { acc = accum[(size_t)y * W + x]; touched = true; }   // reconstruction.glsl:26
