@@ -617,33 +617,61 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
   static_assert(sizeof(hj_quad) == 3 * sizeof(float4) && sizeof(hj_sphere) == sizeof(float4), "shape records");
   static_assert(sizeof(hj_diffuse_cb) == 2 * sizeof(float4), "checkerboard record");
 #define HJ_UP(expr) do { rc = (expr); if (rc != HJ_OK) { release_scene(ctx); return rc; } } while (0)
-  // device node array: hottest (largest surface area) nodes first, explicit left/exit links (kernels/hj_device.h)
+  // device node array (kernels/hj_device.h): redundant inner nodes dropped, hottest (largest surface area) nodes
+  // first, explicit left/exit links.
   {
     const size_t N = s->num_bvh_nodes;
-    std::vector<uint32_t> order(N), map(N);
     std::vector<float> sa(N);
     for (size_t i = 0; i < N; i++) {
-      order[i] = (uint32_t)i;
       const float dx = s->bvh[i].aabb_max[0] - s->bvh[i].aabb_min[0], dy = s->bvh[i].aabb_max[1] - s->bvh[i].aabb_min[1],
                   dz = s->bvh[i].aabb_max[2] - s->bvh[i].aabb_min[2];
       sa[i] = (dx >= 0 && dy >= 0 && dz >= 0) ? dx * dy + dy * dz + dz * dx : 0.f;
     }
-    const size_t hot = std::min<size_t>(hj::kHotNodes, N);
+    // Collapse: an inner node P whose two children are inner nodes can be removed from the walk without changing
+    // which leaves are tested, in which order, with which tMax: a child box lies inside P's box and every term of
+    // the slab test is monotone in the bounds, so "child passes => P passes" and "P fails => both children fail";
+    // the children keep their own box tests and exits.  (Not for leaf children: a leaf's box is never tested, so
+    // P's test is the only guard in front of its shape test.)  It pays when P usually passes: with pass
+    // probability p ~ area(P) / area(nearest kept ancestor), testing P costs 1 + 2p box tests against 2 without.
+    std::vector<char> del(N, 0);
+    {
+      const float thr = (float)env_int("HJ_COLLAPSE_PCT", 50, 0, 1000) / 100.0f;
+      auto inner = [&](size_t i) { return s->bvh[i].shape_index == HJ_BVH_INNER; };
+      std::vector<float> anc(N, 0.f);   // area of the nearest kept ancestor
+      for (size_t i = 0; i < N; i++) {  // pre-order: ancestors come first
+        if (!inner(i) || i + 1 >= N) continue;
+        const size_t l = i + 1, r = s->bvh[l].exit_index;
+        if (r >= N || r <= l) continue;                       // not a well-formed pre-order pair: leave it alone
+        if (i != 0 && inner(l) && inner(r) && anc[i] > 0.f && sa[i] > thr * anc[i]) del[i] = 1;
+        anc[l] = anc[r] = del[i] ? anc[i] : sa[i];
+      }
+    }
+    auto resolve = [&](size_t i) { while (i < N && del[i]) i++; return i; };   // first kept node of a subtree
+    std::vector<uint32_t> order, map(N, 0);
+    for (size_t i = 0; i < N; i++) if (!del[i]) order.push_back((uint32_t)i);
+    const size_t M = order.size();
+    const size_t hot = std::min<size_t>(hj::kHotNodes, M);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return sa[a] > sa[b]; });
     std::vector<char> is_hot(N, 0);
     for (size_t k = 0; k < hot; k++) { map[order[k]] = (uint32_t)k; is_hot[order[k]] = 1; }
     uint32_t next = (uint32_t)hot;
-    for (size_t i = 0; i < N; i++) if (!is_hot[i]) map[i] = next++;
-    std::vector<float4> dev(2 * N);
+    for (size_t i = 0; i < N; i++) if (!del[i] && !is_hot[i]) map[i] = next++;
+    std::vector<float4> dev(2 * M);
     for (size_t i = 0; i < N; i++) {
+      if (del[i]) continue;
       const hj_bvh_node& nd = s->bvh[i];
       uint32_t a;
       if (nd.shape_index != HJ_BVH_INNER) a = nd.shape_index;
-      else a = hj::kInnerFlag | (i + 1 < N ? map[i + 1] : (uint32_t)N);          // left child = next pre-order record
-      const uint32_t b = nd.exit_index < N ? map[nd.exit_index] : (uint32_t)N;    // >= N ends the walk
+      else {
+        const size_t l = resolve(i + 1);                                             // left child = next pre-order record
+        a = hj::kInnerFlag | (l < N ? map[l] : (uint32_t)M);
+      }
+      const size_t e = nd.exit_index < N ? resolve(nd.exit_index) : N;
+      const uint32_t b = e < N ? map[e] : (uint32_t)M;                               // >= M ends the walk
       dev[2 * map[i] + 0] = make_float4(nd.aabb_min[0], nd.aabb_min[1], nd.aabb_min[2], __builtin_bit_cast(float, a));
       dev[2 * map[i] + 1] = make_float4(nd.aabb_max[0], nd.aabb_max[1], nd.aabb_max[2], __builtin_bit_cast(float, b));
     }
+    d.num_nodes = (uint32_t)M;
     d.root = N ? map[0] : 0u;
     d.num_hot = (uint32_t)hot;
     d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", 4, 1, 1 << 20);   // >= 1, or the walk would never advance
