@@ -112,14 +112,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{sr.local}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
         paths = W * H * spp * args.steps
         out = {
-            "metric": "Mrays/s (camera paths/s) at 512spp, cbox 1024x1024",
+            "metric": f"Mrays/s (camera paths/s) at {spp}spp, cbox {W}x{H}",
             "value": round(paths / elapsed / 1e6, 3),
             "unit": "Mrays/s",
             "n_gpus": world,

@@ -31,8 +31,8 @@ def init_process_group(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:   # HIJIKI_DIST_BACKEND=gloo lets several ranks share one GPU (test rigs); RCCL needs one GPU per rank
+            backend = os.environ.get("HIJIKI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -60,6 +60,7 @@ class ShardedRenderer:
         rank, world, local = env_rank_world()
         self.rank, self.world = rank, world
         self.local = local if local_rank is None else local_rank
+        self.local %= max(1, torch.cuda.device_count())      # ranks beyond the GPU count share devices (gloo test rigs only)
         torch.cuda.set_device(self.local)
         self.fb = torch.zeros((height, width, 4), dtype=torch.float32, device=f"cuda:{self.local}")
         self.renderer = device.Renderer(self.local)
