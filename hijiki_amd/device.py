@@ -83,6 +83,7 @@ class Renderer:
 
     def __init__(self, device=0):
         self._h = C.c_void_p()
+        self._destroy = lib().hj_context_destroy     # bound now: module globals may be gone at interpreter exit
         rc = lib().hj_context_create(device, C.byref(self._h))
         if rc != abi.HJ_OK:
             raise abi.HijikiError(rc, lib().hj_last_error(None).decode())
@@ -90,7 +91,7 @@ class Renderer:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().hj_context_destroy(self._h)
+            self._destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -90,6 +90,7 @@ class Scene:
 
     def __init__(self, _handle=None):
         self._h = C.c_void_p()
+        self._destroy = lib().hjh_scene_destroy      # bound now: module globals may be gone at interpreter exit
         if _handle is not None:
             self._h = _handle
         else:
@@ -97,7 +98,7 @@ class Scene:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().hjh_scene_destroy(self._h)
+            self._destroy(self._h)
             self._h = None
 
     @staticmethod
@@ -189,12 +190,13 @@ class CompiledScene:
 
     def __init__(self, handle):
         self._h = handle
+        self._destroy = lib().hjh_compiled_destroy
         self.desc = abi.SceneDesc()
         _check(lib().hjh_compiled_desc(self._h, C.byref(self.desc)))
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().hjh_compiled_destroy(self._h)
+            self._destroy(self._h)
             self._h = None
 
     # numpy views (borrowed; valid while self lives)
