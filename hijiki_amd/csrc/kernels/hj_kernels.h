@@ -772,27 +772,43 @@ __global__ __launch_bounds__(256) void k_reconstruct(BatchState st, const float*
   bool touched = false;     // pixels no block of this batch reaches are neither read nor written
   const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
   const uint32_t i0 = tile_off[tile], i1 = tile_off[tile + 1];
+  // The samples a tile needs from one block (the tile + 2 pixels all round, 20 x 20) are staged in LDS once and
+  // the 25 taps of its 256 pixels read them there instead of 50 global fetches per pixel.
+  constexpr int TS = 20;
+  __shared__ float4 s_rgb[TS * TS], s_nd[TS * TS];
+  const int px = (int)(threadIdx.x & 15u), py = (int)(threadIdx.x >> 4);
   for (uint32_t idx = i0; idx < i1; idx++) {
     const uint32_t bi = tile_blk[idx];
     const hj_image_block b = st.blocks[bi];
     const int ox = (int)b.origin[0], oy = (int)b.origin[1], Dx = (int)b.dimension[0], Dy = (int)b.dimension[1];
+    const uint32_t sbase = bi * kSlotsPerBlock;
+    const int bx0 = tx0 - 2 - ox, by0 = ty0 - 2 - oy;        // block-local coordinates of LDS entry (0, 0)
+    __syncthreads();                                          // previous block's taps are done with the LDS tile
+    for (int e = (int)threadIdx.x; e < TS * TS; e += 256) {
+      const int ex = bx0 + e % TS, ey = by0 + e / TS;
+      if (ex >= 0 && ex < Dx && ey >= 0 && ey < Dy) {
+        const uint32_t sp = sbase + (uint32_t)ey * HJ_BLOCK_SIZE + (uint32_t)ex;
+        s_rgb[e] = st.smp_rgb[sp];
+        s_nd[e] = st.smp_nd[sp];
+      }
+    }
+    __syncthreads();
     const int lx = x - ox, ly = y - oy;
     if (!inimg || lx < -2 || lx >= Dx + 2 || ly < -2 || ly >= Dy + 2) continue;
     if (!touched) { acc = accum[(size_t)y * W + x]; touched = true; }   // reconstruction.glsl:26
-    const uint32_t sbase = bi * kSlotsPerBlock;
     v3 nc = V(0, 0, 0);
-    if (lx >= 0 && lx < Dx && ly >= 0 && ly < Dy) nc = xyz(st.smp_nd[sbase + (uint32_t)ly * HJ_BLOCK_SIZE + (uint32_t)lx]);
+    if (lx >= 0 && lx < Dx && ly >= 0 && ly < Dy) nc = xyz(s_nd[(py + 2) * TS + (px + 2)]);
     for (int dx = -2; dx <= 2; dx++) {
       if (lx + dx < 0 || lx + dx >= Dx) continue;
       for (int dy = -2; dy <= 2; dy++) {
         if (ly + dy < 0 || ly + dy >= Dy) continue;
         float w = wtab[bi * 25u + (uint32_t)((dx + 2) * 5 + (dy + 2))];
         if (w < 0.0f) continue;
-        const uint32_t sp = sbase + (uint32_t)(ly + dy) * HJ_BLOCK_SIZE + (uint32_t)(lx + dx);
-        const float4 nd = st.smp_nd[sp];
+        const int e = (py + 2 + dy) * TS + (px + 2 + dx);
+        const float4 nd = s_nd[e];
         const v3 no = xyz(nd) - nc;
         w *= hj_exp(-(dot3(no, no) * 2.0f));
-        const float4 c = st.smp_rgb[sp];
+        const float4 c = s_rgb[e];
         const float v0 = w * c.x, v1 = w * c.y, v2 = w * c.z, v3_ = w * c.w;
         if (v0 != v0 || v1 != v1 || v2 != v2 || v3_ != v3_) continue;
         acc.x += v0; acc.y += v1; acc.z += v2; acc.w += v3_;
