@@ -350,6 +350,7 @@ HJ_DEV v3 checkerboard(const DeviceScene& sc, uint32_t idx, float u, float v) {
 struct WgShared {                 // LDS of a path workgroup (8.3 KB)
   uint32_t head;                  // next unread entry of the queue segment being traced
   uint32_t cnt_hit[kNumTags];     // hits binned by material tag (this bounce)
+  uint32_t wcnt[kBlockThreads / 64][kNumTags];   // per-wave tag counts of the ordered compaction
   uint32_t n_next, n_shadow;      // next-bounce rays / shadow rays produced by shade
   uint32_t n_gen;
   float4 n0[kHotNodes], n1[kHotNodes];   // LDS copy of the hottest BVH nodes
@@ -420,18 +421,10 @@ HJ_DEV void stage_trace_closest(const BatchState& st, const DeviceScene& sc, uin
   const uint32_t G = st.num_wg;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t* __restrict__ q = st.q_ray[parity] + (size_t)g * st.segcap;
-  // bin finished rays by material tag (divergent-BSDF sort): one ballot + one LDS atomic per tag per wave
+  // A finished ray only records its hit (objectID -1 = miss).  The hit queues are built afterwards in QUEUE order
+  // (below), not in finishing order, so that the paths a shading wave touches stay close together in memory.
   auto finish = [&](bool done, uint32_t slot, const RawHit& h) {
-    uint32_t tag = 0xFFu;
-    if (done && h.id != -1) {
-      st.hit[slot] = make_float4(h.t, __int_as_float(h.id), h.u, h.v);
-      tag = sc.materials[h.id] >> HJ_MATERIAL_TAG_SHIFT;
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < kNumTags; k++) {
-      const uint32_t qi = lds_push(&sh.cnt_hit[k], tag == k);
-      if (tag == k) st.q_hit[((size_t)k * G + g) * st.segcap + qi] = slot;
-    }
+    if (done) st.hit[slot] = make_float4(h.t, __int_as_float(h.id), h.u, h.v);
   };
   if (USE_BVH) {
     auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r) {
@@ -456,6 +449,53 @@ HJ_DEV void stage_trace_closest(const BatchState& st, const DeviceScene& sc, uin
       }
       finish(valid, slot, h);
     }
+  }
+  // Ordered compaction by material tag (divergent-BSDF sort): every wave takes a contiguous range of queue rows,
+  // counts its hits per tag, then (after a prefix over the waves) writes them at their final positions.
+  __syncthreads();
+  const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const uint32_t rows = (n + 63u) >> 6, rpw = (rows + waves - 1u) / waves;
+  const uint32_t r0 = wave * rpw < rows ? wave * rpw : rows, r1 = r0 + rpw < rows ? r0 + rpw : rows;
+  auto tag_of = [&](uint32_t i, uint32_t& slot) -> uint32_t {
+    if (i >= n) return 0xFFu;
+    slot = q[i];
+    const int id = __float_as_int(st.hit[slot].y);
+    return id >= 0 ? sc.materials[id] >> HJ_MATERIAL_TAG_SHIFT : 0xFFu;
+  };
+  uint32_t cnt[kNumTags];
+#pragma unroll
+  for (uint32_t k = 0; k < kNumTags; k++) cnt[k] = 0;
+  for (uint32_t row = r0; row < r1; row++) {
+    uint32_t slot = 0;
+    const uint32_t tag = tag_of(row * 64u + lane, slot);
+#pragma unroll
+    for (uint32_t k = 0; k < kNumTags; k++) cnt[k] += (uint32_t)__popcll(__ballot(tag == k));
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (uint32_t k = 0; k < kNumTags; k++) sh.wcnt[wave][k] = cnt[k];
+  }
+  __syncthreads();
+  uint32_t base[kNumTags];
+#pragma unroll
+  for (uint32_t k = 0; k < kNumTags; k++) {
+    base[k] = 0;
+    for (uint32_t w = 0; w < wave; w++) base[k] += sh.wcnt[w][k];
+  }
+  for (uint32_t row = r0; row < r1; row++) {
+    uint32_t slot = 0;
+    const uint32_t tag = tag_of(row * 64u + lane, slot);
+#pragma unroll
+    for (uint32_t k = 0; k < kNumTags; k++) {
+      const unsigned long long mask = __ballot(tag == k);
+      if (tag == k) st.q_hit[((size_t)k * G + g) * st.segcap + base[k] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
+      base[k] += (uint32_t)__popcll(mask);
+    }
+  }
+  if (threadIdx.x < kNumTags) {
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < waves; w++) total += sh.wcnt[w][threadIdx.x];
+    sh.cnt_hit[threadIdx.x] = total;
   }
 }
 
