@@ -18,6 +18,7 @@ BVH_ROOT_EXIT = 1000000
 BLOCK_SIZE = 128
 RENDER_TIME_KERNELS = 1
 RENDER_SPLIT_KERNELS = 2
+RENDER_STATIC_DEAL = 4
 
 f32, u32, u64 = C.c_float, C.c_uint32, C.c_uint64
 

@@ -880,11 +880,13 @@ int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed, uint32_
   if (world == 0 || rank >= world) return set_error(ctx, HJ_ERR_INVALID, "bad rank %u / world %u", rank, world);
   if (pass_end > spp || pass_begin > pass_end) return set_error(ctx, HJ_ERR_INVALID, "bad pass range [%u,%u) of %u", pass_begin, pass_end, spp);
   hijiki::BlockGrid grid(ctx->width, ctx->height, HJ_BLOCK_SIZE);
-  // Tile sharding: block j of every pass belongs to rank (j mod world), so that all passes of one
-  // block accumulate on one GPU in pass order.  The list is generated in chunks
+  // Tile sharding: block j of pass p belongs to rank grid.owner(p, j, world) (a diagonal deal that rotates with the
+  // pass; with HJ_RENDER_STATIC_DEAL all passes of one block stay on one GPU and accumulate there in pass order,
+  // SURVEY.md §8e).  The list is generated in chunks
   // (4096^2 x 4096 spp would be 4.2 M blocks = 168 MB if materialised at once).
   hj_render_stats total{};
   std::vector<hj_image_block> chunk;
+  const bool static_deal = opts && (opts->flags & HJ_RENDER_STATIC_DEAL);
   const uint32_t per_pass = grid.per_pass();
   const uint32_t passes_per_chunk = std::max<uint32_t>(1u, 32768u / std::max<uint32_t>(1u, (per_pass + world - 1) / world));
   int rc = HJ_OK;
@@ -892,7 +894,8 @@ int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed, uint32_
     const uint32_t p1 = std::min(pass_end, p0 + passes_per_chunk);
     chunk.clear();
     for (uint32_t p = p0; p < p1; p++)
-      for (uint32_t j = rank; j < per_pass; j += world) chunk.push_back(grid.make(master_seed, p, j));
+      for (uint32_t j = 0; j < per_pass; j++)
+        if (grid.owner(static_deal ? 0u : p, j, world) == rank) chunk.push_back(grid.make(master_seed, p, j));
     hj_render_stats st{};
     rc = hj_render_blocks(ctx, chunk.data(), chunk.size(), opts, &st);
     total.paths += st.paths; total.closest_rays += st.closest_rays; total.shadow_rays += st.shadow_rays;
@@ -1045,6 +1048,10 @@ int hj_debug_samples(hj_context* ctx, const hj_image_block* block, const hj_rend
 }
 
 uint32_t hj_block_seed(uint64_t master, uint32_t pass, uint32_t j) { return hijiki::block_seed(master, pass, j); }
+uint32_t hj_block_owner(uint32_t width, uint32_t height, uint32_t pass, uint32_t j, uint32_t world) {
+  if (!width || !height || !world) return 0;
+  return hijiki::BlockGrid(width, height, HJ_BLOCK_SIZE).owner(pass, j, world);
+}
 void hj_pass_offset(uint64_t master, uint32_t k, float out[2]) { hijiki::pass_offset(master, k, out); }
 
 }  // extern "C"

@@ -256,6 +256,10 @@ int hjh_write_pfm(const char* path, uint32_t w, uint32_t h, const float* rgb) {
 // hj_block_seed / hj_pass_offset are declared in hijiki_hip.h; the host
 // library exports them too so that a CPU-only host can build block lists.
 uint32_t hj_block_seed(uint64_t master, uint32_t pass, uint32_t j) { return block_seed(master, pass, j); }
+uint32_t hj_block_owner(uint32_t width, uint32_t height, uint32_t pass, uint32_t j, uint32_t world) {
+  if (!width || !height || !world) return 0;
+  return BlockGrid(width, height, HJ_BLOCK_SIZE).owner(pass, j, world);
+}
 void hj_pass_offset(uint64_t master, uint32_t k, float out[2]) { pass_offset(master, k, out); }
 
 }  // extern "C"

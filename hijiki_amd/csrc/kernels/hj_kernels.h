@@ -178,12 +178,13 @@ HJ_DEV bool traverse(const DeviceScene& sc, Ray r, RawHit& h) {
 //   finish(done, slot, h) wave-convergent: called when some lanes are done; `done` lanes have a final result
 constexpr uint32_t kRefillMin = 32;   // sweep on the fused kernel: 16 -> 1.39, 32..48 -> 1.43 Gpaths/s, 64 -> 1.24
 
-template <bool ANYHIT, class Fetch, class Finish>
+// MODE 0: closest-hit rays, 1: any-hit (shadow) rays, 2: both kinds in one queue (fetch says which per ray).
+template <int MODE, class Fetch, class Finish>
 HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head, const float4* s_n0,
                              const float4* s_n1, Fetch fetch, Finish finish) {
   const uint32_t lane = __lane_id();
   const uint32_t nn = sc.num_nodes, nhot = sc.num_hot;
-  bool active = false, pending = false, exhausted = false;
+  bool active = false, pending = false, exhausted = false, any = (MODE == 1);
   uint32_t slot = 0, cur = 0;
   Ray r; r.o = V(0, 0, 0); r.d = V(0, 0, 0); r.tmin = 0.f; r.tmax = 0.f;
   v3 inv = V(0, 0, 0), off = V(0, 0, 0);
@@ -196,7 +197,7 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     const unsigned long long idle = __ballot(!active);
     const uint32_t nidle = (uint32_t)__popcll(idle);
     if (nidle >= sc.refill_min || nidle == 64u) {
-      if (__ballot(pending) != 0) finish(pending, slot, h);
+      if (__ballot(pending) != 0) finish(pending, slot, h, any);
       pending = false;
       if (!exhausted) {
         uint32_t base = 0;
@@ -205,7 +206,7 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
         if (!active) {
           const uint32_t my = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
           if (my < n) {
-            fetch(my, slot, r);
+            fetch(my, slot, r, any);
             inv = V(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
             off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
             cur = sc.root; h.id = -1; active = true;
@@ -229,7 +230,7 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     if (at_leaf) {
       if (intersect_shape(sc, r, shape, h)) {
         h.id = (int)shape;
-        if (ANYHIT) active = false;           // occluded: nothing to add
+        if (MODE == 1 || (MODE == 2 && any)) active = false;   // occluded shadow ray: nothing to add
         else r.tmax = h.t - kEps;
       }
       cur = ex;
@@ -413,26 +414,28 @@ HJ_DEV void stage_gen_camera(const BatchState& st, const DeviceScene& sc, uint32
   }
 }
 
+HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uint32_t g, const uint32_t* __restrict__ q,
+                                uint32_t n, WgShared& sh);
+
 // Closest-hit walk over this workgroup's n rays of q_ray[parity]; hits binned by material tag.
 // Needs sh.head == 0, sh.cnt_hit[] == 0 and the hot nodes loaded (synced); leaves the tag counts in sh.cnt_hit.
 template <bool USE_BVH>
 HJ_DEV void stage_trace_closest(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t n,
                                 float tmin, WgShared& sh) {
-  const uint32_t G = st.num_wg;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t* __restrict__ q = st.q_ray[parity] + (size_t)g * st.segcap;
   // A finished ray only records its hit (objectID -1 = miss).  The hit queues are built afterwards in QUEUE order
   // (below), not in finishing order, so that the paths a shading wave touches stay close together in memory.
-  auto finish = [&](bool done, uint32_t slot, const RawHit& h) {
+  auto finish = [&](bool done, uint32_t slot, const RawHit& h, bool) {
     if (done) st.hit[slot] = make_float4(h.t, __int_as_float(h.id), h.u, h.v);
   };
   if (USE_BVH) {
-    auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r) {
+    auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r, bool&) {
       slot = q[i];
       const float4 o = st.ray_o[slot], d = st.ray_d[slot];
       r.o = xyz(o); r.d = xyz(d); r.tmin = tmin; r.tmax = kInf;
     };
-    trace_persistent<false>(sc, n, &sh.head, sh.n0, sh.n1, fetch, finish);
+    trace_persistent<0>(sc, n, &sh.head, sh.n0, sh.n1, fetch, finish);
   } else {
     for (;;) {
       const uint32_t c = lds_fetch_chunk(&sh.head);
@@ -447,9 +450,18 @@ HJ_DEV void stage_trace_closest(const BatchState& st, const DeviceScene& sc, uin
         Ray r; r.o = xyz(o); r.d = xyz(d); r.tmin = tmin; r.tmax = kInf;
         traverse<false, false>(sc, r, h);
       }
-      finish(valid, slot, h);
+      finish(valid, slot, h, false);
     }
   }
+  compact_hits_by_tag(st, sc, g, q, n, sh);
+}
+
+// Ordered compaction of the hits of this workgroup's n closest-hit rays (queue q) by material tag.
+// Starts with a barrier (all hit records written); needs sh.cnt_hit[] == 0; leaves the tag counts there.
+HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uint32_t g, const uint32_t* __restrict__ q,
+                                uint32_t n, WgShared& sh) {
+  const uint32_t G = st.num_wg;
+  const uint32_t lane = threadIdx.x & 63u;
   // Ordered compaction by material tag (divergent-BSDF sort): every wave takes a contiguous range of queue rows,
   // counts its hits per tag, then (after a prefix over the waves) writes them at their final positions.
   __syncthreads();
@@ -505,7 +517,7 @@ template <bool USE_BVH>
 HJ_DEV void stage_trace_shadow(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t n, WgShared& sh) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t* __restrict__ q = st.q_shadow + (size_t)g * st.segcap;
-  auto add_unoccluded = [&](bool done, uint32_t slot, const RawHit&) {
+  auto add_unoccluded = [&](bool done, uint32_t slot, const RawHit&, bool) {
     if (done) {
       const float4 cc = st.sh_c[slot];
       float4 s = st.smp_rgb[slot];
@@ -514,12 +526,12 @@ HJ_DEV void stage_trace_shadow(const BatchState& st, const DeviceScene& sc, uint
     }
   };
   if (USE_BVH) {
-    auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r) {
+    auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r, bool&) {
       slot = q[i];
       const float4 o = st.ray_o[slot], d = st.sh_d[slot];
       r.o = xyz(o); r.d = xyz(d); r.tmin = 2.0f * kEps; r.tmax = d.w;
     };
-    trace_persistent<true>(sc, n, &sh.head, sh.n0, sh.n1, fetch, add_unoccluded);
+    trace_persistent<1>(sc, n, &sh.head, sh.n0, sh.n1, fetch, add_unoccluded);
   } else {
     for (;;) {
       const uint32_t c = lds_fetch_chunk(&sh.head);
@@ -530,10 +542,44 @@ HJ_DEV void stage_trace_shadow(const BatchState& st, const DeviceScene& sc, uint
         const float4 o = st.ray_o[slot], d = st.sh_d[slot];
         Ray r; r.o = xyz(o); r.d = xyz(d); r.tmin = 2.0f * kEps; r.tmax = d.w;
         RawHit h;
-        if (!traverse<false, true>(sc, r, h)) add_unoccluded(true, slot, h);
+        if (!traverse<false, true>(sc, r, h)) add_unoccluded(true, slot, h, true);
       }
     }
   }
+}
+
+// One walk phase for BOTH ray kinds of a bounce round (BVH mode, fused kernel): the n closest-hit rays of bounce k
+// and the ns shadow rays that shade produced at bounce k-1 are one queue [0, n + ns).  The two are independent
+// (the next bounce ray never waits for the NEE visibility), so tracing them together halves the number of walk
+// phases per bounce - each of which ends with the workgroup waiting for its slowest ray - and halves the chain of
+// dependent walks of a deep path, i.e. the tail of the kernel.  Per path the radiance additions keep the
+// reference's order: NEE of bounce k-1 is added during this phase, emission of bounce k in the shade that follows
+// the barrier.  Needs sh.head == 0, sh.cnt_hit[] == 0 and the hot nodes loaded (synced).
+HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t n,
+                               uint32_t ns, float tmin, WgShared& sh) {
+  const uint32_t* __restrict__ q = st.q_ray[parity] + (size_t)g * st.segcap;
+  const uint32_t* __restrict__ qs = st.q_shadow + (size_t)g * st.segcap;
+  auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r, bool& any) {
+    any = i >= n;
+    slot = any ? qs[i - n] : q[i];
+    const float4 o = st.ray_o[slot];
+    float4 d;
+    if (any) d = st.sh_d[slot]; else d = st.ray_d[slot];
+    r.o = xyz(o); r.d = xyz(d);
+    r.tmin = any ? 2.0f * kEps : tmin;
+    r.tmax = any ? d.w : kInf;
+  };
+  auto finish = [&](bool done, uint32_t slot, const RawHit& h, bool any) {
+    if (done && !any) st.hit[slot] = make_float4(h.t, __int_as_float(h.id), h.u, h.v);
+    if (done && any) {                              // unoccluded shadow ray: render.glsl:123
+      const float4 cc = st.sh_c[slot];
+      float4 s = st.smp_rgb[slot];
+      s.x += cc.x; s.y += cc.y; s.z += cc.z;
+      st.smp_rgb[slot] = s;
+    }
+  };
+  trace_persistent<2>(sc, n + ns, &sh.head, sh.n0, sh.n1, fetch, finish);
+  compact_hits_by_tag(st, sc, g, q, n, sh);
 }
 
 // reference shader/scene.glsl:160-175 (populate), render.glsl:102-144, material.glsl:18-91.
@@ -744,6 +790,30 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
   __syncthreads();
   uint32_t n = sh.n_gen;
   uint32_t total_closest = 0, total_shadow = 0;
+  if (USE_BVH) {
+    // round k: walk {closest rays of bounce k + shadow rays of bounce k-1} together, then shade bounce k
+    uint32_t ns = 0;
+    for (uint32_t bounce = 0; (bounce < max_bounces && n != 0) || ns != 0; bounce++) {
+      const uint32_t parity = bounce & 1u;
+      if (threadIdx.x == 0) { sh.head = 0; sh.n_next = 0; sh.n_shadow = 0; }
+      if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
+      __syncthreads();
+      stage_trace_merged(st, sc, g, parity, n, ns, bounce == 0 ? kEps : 2.0f * kEps, sh);   // render.glsl:33,132
+      __syncthreads();
+      if (n != 0) stage_shade(st, sc, g, parity, bounce, max_bounces, rr_start, sh);
+      __syncthreads();
+      total_closest += n;
+      total_shadow += ns;
+      n = sh.n_next;
+      ns = sh.n_shadow;
+      __syncthreads();                       // everyone has read n_next / n_shadow before they are reset
+    }
+    if (threadIdx.x == 0) {
+      st.acc_closest[g] = total_closest;
+      st.acc_shadow[g] = total_shadow;
+    }
+    return;
+  }
   for (uint32_t bounce = 0; bounce < max_bounces && n != 0; bounce++) {
     const uint32_t parity = bounce & 1u;
     if (threadIdx.x == 0) { sh.head = 0; sh.n_next = 0; sh.n_shadow = 0; }

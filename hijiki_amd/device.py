@@ -19,7 +19,7 @@ _LIB = None
 EXPORTS = ("hj_context_create", "hj_context_destroy", "hj_last_error", "hj_version", "hj_default_render_opts",
            "hj_scene_upload", "hj_framebuffer_create", "hj_framebuffer_clear", "hj_framebuffer_device_ptr",
            "hj_framebuffer_read", "hj_framebuffer_resolve", "hj_render_blocks", "hj_render_frame", "hj_block_seed",
-           "hj_pass_offset", "hj_debug_trace", "hj_debug_samples", "hj_reduce_framebuffers")
+           "hj_pass_offset", "hj_block_owner", "hj_debug_trace", "hj_debug_samples", "hj_reduce_framebuffers")
 
 
 def lib():
@@ -56,6 +56,8 @@ def lib():
         L.hj_block_seed.restype = C.c_uint32
         L.hj_pass_offset.argtypes = [C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]
         L.hj_pass_offset.restype = None
+        L.hj_block_owner.argtypes = [C.c_uint32] * 5
+        L.hj_block_owner.restype = C.c_uint32
         _LIB = L
     return _LIB
 

@@ -1,7 +1,8 @@
 """Multi-GPU tile sharding: one process per GPU, one RCCL reduce of the framebuffer.
 
-The path shards by ImageBlock: block j of every pass belongs to
-rank j mod world, every rank accumulates its blocks (and their 2-pixel aprons)
+The path shards by ImageBlock: block j (column bx, row by) of every pass belongs to
+pass p belongs to
+rank (bx + by + p) mod world (hj_block_owner), every rank accumulates its blocks (and their 2-pixel aprons)
 into a private full-frame RGBA32F buffer that starts at zero, and one
 sum-reduce over xGMI (`torch.distributed`, backend "nccl" == RCCL) produces the
 frame on rank 0.  The reference has no multi-GPU path; this is the exchange
@@ -18,9 +19,13 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def owned_blocks(num_blocks_per_pass, rank, world):
-    """Block indices (within a pass) that `rank` renders — the C ABI's hj_render_frame uses the same rule."""
-    return list(range(rank, num_blocks_per_pass, world))
+def owned_blocks(width, height, rank, world, pass_index=0):
+    """Block indices (within pass `pass_index`) that `rank` renders — the rule hj_render_frame applies
+    (hj_block_owner; with HJ_RENDER_STATIC_DEAL every pass uses pass_index 0)."""
+    from . import host
+    L = host.lib()
+    per = host.blocks_per_pass(width, height)
+    return [j for j in range(per) if L.hj_block_owner(width, height, pass_index, j, world) == rank]
 
 
 def init_process_group(backend=None):

@@ -65,6 +65,8 @@ def lib():
         L.hj_block_seed.restype = C.c_uint32
         L.hj_pass_offset.argtypes = [C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]
         L.hj_pass_offset.restype = None
+        L.hj_block_owner.argtypes = [C.c_uint32] * 5
+        L.hj_block_owner.restype = C.c_uint32
         _LIB = L
     return _LIB
 

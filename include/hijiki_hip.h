@@ -155,6 +155,7 @@ typedef struct hj_render_opts {
 
 #define HJ_RENDER_TIME_KERNELS 1u   /* bracket every kernel with HIP events on its launch stream (fills *_ms) */
 #define HJ_RENDER_SPLIT_KERNELS 2u  /* diagnostic: one launch per stage per bounce instead of the fused kernel */
+#define HJ_RENDER_STATIC_DEAL 4u    /* hj_render_frame, world > 1: keep all passes of a block on one rank          */
 
 /* Per-render statistics (device counters; all in units of events). */
 typedef struct hj_render_stats {
@@ -228,8 +229,8 @@ int hj_render_blocks(hj_context* ctx, const hj_image_block* blocks, size_t num_b
                      hj_render_stats* stats /* may be NULL */);
 
 /* Deterministic ImageBlockGenerator (src/main.rs:619-682) + render of the
- * blocks owned by `rank` out of `world` (block index modulo world), for
- * passes [pass_begin, pass_end).  With world == 1 this is the whole frame.
+ * blocks owned by `rank` out of `world` (hj_block_owner: a diagonal deal over the block grid that
+ * moves one step per pass), for passes [pass_begin, pass_end).  With world == 1 this is the whole frame.
  * The reference seeds blocks from the OS RNG (src/main.rs:643,670,675);
  * here seeds/offsets come from hj_block_seed / hj_pass_offset below. */
 int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed,
@@ -267,6 +268,9 @@ int hj_debug_samples(hj_context* ctx, const hj_image_block* block, const hj_rend
  * library's ImageBlockGenerator and restated by the oracle. */
 uint32_t hj_block_seed(uint64_t master_seed, uint32_t pass, uint32_t block_in_pass);
 void hj_pass_offset(uint64_t master_seed, uint32_t offset_index, float out_xy[2]);
+/* Rank that renders block j (raster index inside a pass) of pass `pass` of a width x height frame:
+ * (column + row + pass) mod world.  With HJ_RENDER_STATIC_DEAL hj_render_frame uses pass = 0 for every pass. */
+uint32_t hj_block_owner(uint32_t width, uint32_t height, uint32_t pass, uint32_t block_in_pass, uint32_t world);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

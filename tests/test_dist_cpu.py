@@ -1,6 +1,6 @@
 """world_size-2 gloo test of the multi-GPU exchange step (hijiki_amd.dist) on CPU.
 
-Each rank renders ITS blocks (block j mod world, as hj_render_frame does) with the CPU oracle standing in for the
+Each rank renders ITS blocks (hj_block_owner's diagonal deal, rotating with the pass or static, as hj_render_frame does) with the CPU oracle standing in for the
 device renderer, then the framebuffers are sum-reduced to rank 0 through torch.distributed — the same call the
 RCCL path makes.  The reduced frame must equal the single-process frame (exactly away from block aprons).
 """
@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, W, H, spp, seed, out_path):
+def _worker(rank, world, port, W, H, spp, seed, static, out_path):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
@@ -36,7 +36,7 @@ def _worker(rank, world, port, W, H, spp, seed, out_path):
     cs = host.Scene.synthetic(host.SYNTH_CBOX, mesh_triangles=320).compile()
     per = host.blocks_per_pass(W, H)
     all_blocks = host.make_blocks(W, H, spp, seed)
-    mine = [all_blocks[p * per + j] for p in range(spp) for j in hjdist.owned_blocks(per, rank, world)]
+    mine = [all_blocks[p * per + j] for p in range(spp) for j in hjdist.owned_blocks(W, H, rank, world, 0 if static else p)]
     arr = (abi.ImageBlock * len(mine))(*mine)
     acc, _, _ = hj_oracle.render_blocks(cs, arr, W, H, nthreads=2)
     fb = torch.from_numpy(acc)
@@ -48,27 +48,38 @@ def _worker(rank, world, port, W, H, spp, seed, out_path):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_tile_sharding_gloo(tmp_path, oracle):
+@pytest.mark.parametrize("static", [False, True], ids=["rotating-deal", "static-deal"])
+def test_two_rank_tile_sharding_gloo(tmp_path, oracle, static):
     import torch.multiprocessing as mp
     from hijiki_amd import host
     W, H, spp, seed, world = 256, 256, 2, 5, 2
     out = str(tmp_path / "reduced.npy")
-    mp.spawn(_worker, args=(world, _free_port(), W, H, spp, seed, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), W, H, spp, seed, static, out), nprocs=world, join=True)
     reduced = np.load(out)
     cs = host.Scene.synthetic(host.SYNTH_CBOX, mesh_triangles=320).compile()
     full, _, _ = oracle.render_blocks(cs, host.make_blocks(W, H, spp, seed), W, H, nthreads=4)
-    interior = np.ones((H, W), bool)
-    interior[126:130, :] = False
-    interior[:, 126:130] = False
-    assert (reduced[interior] == full[interior]).all()
+    if static:      # all passes of a block on one rank: only the 2-pixel aprons change their association
+        interior = np.ones((H, W), bool)
+        interior[126:130, :] = False
+        interior[:, 126:130] = False
+        assert (reduced[interior] == full[interior]).all()
     np.testing.assert_allclose(reduced, full, rtol=3e-6, atol=1e-6)
 
 
 def test_block_ownership_rule():
     from hijiki_amd import dist as hjdist
+    W = H = 1024
     per = 64
     for world in (1, 2, 4, 8, 3):
-        owned = [hjdist.owned_blocks(per, r, world) for r in range(world)]
+        owned = [hjdist.owned_blocks(W, H, r, world) for r in range(world)]
         flat = sorted(j for o in owned for j in o)
         assert flat == list(range(per))
-        assert max(len(o) for o in owned) - min(len(o) for o in owned) <= 1
+        assert max(len(o) for o in owned) - min(len(o) for o in owned) <= 2
+        if world in (2, 4, 8):      # diagonal deal: every rank holds blocks of every column and every row
+            for o in owned:
+                assert {j % 8 for j in o} == set(range(8)) and {j // 8 for j in o} == set(range(8))
+        # the deal moves one diagonal per pass: over `world` passes every rank renders every block position once
+        for r in range(world):
+            seen = sorted(j for p in range(world) for j in hjdist.owned_blocks(W, H, r, world, p))
+            assert seen == list(range(per))
+            assert hjdist.owned_blocks(W, H, r, world, world) == owned[r]

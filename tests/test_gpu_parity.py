@@ -205,27 +205,34 @@ def test_rendering_is_deterministic_and_additive(gpu_renderer, cbox):
 
 
 def test_tile_sharding_sums_to_the_full_frame(gpu_renderer, cbox):
-    """N 'virtual ranks' on one device: the sum of the per-rank buffers equals the 1-GPU frame exactly away from
-    block borders and within a few ulp on the 2-pixel aprons (different association of the same addends)."""
+    """N 'virtual ranks' on one device.  Static deal (all passes of a block on one rank): the sum of the per-rank
+    buffers equals the 1-GPU frame exactly away from block borders and within a few ulp on the 2-pixel aprons
+    (different association of the same addends).  Default deal (moves one diagonal per pass): the same addends
+    in another association everywhere, so a few ulp everywhere; every block is rendered exactly once either way."""
     W = H = 384
     r = gpu_renderer
     r.upload_scene(cbox)
     r.create_framebuffer(W, H)
-    r.render_frame(6, 9)
+    st_full = r.render_frame(6, 9)
     full = r.read()
+    static = device.default_opts()
+    static.flags = abi.RENDER_STATIC_DEAL
     for world in (2, 3):
-        parts = []
-        for rank in range(world):
-            r.clear()
-            r.render_frame(6, 9, rank=rank, world=world)
-            parts.append(r.read().astype(np.float64))
-        total = np.sum(parts, axis=0)
-        interior = np.ones((H, W), bool)
-        for e in (128, 256):
-            interior[e - 2:e + 2, :] = False
-            interior[:, e - 2:e + 2] = False
-        assert (total[interior].astype(np.float32) == full[interior]).all()
-        np.testing.assert_allclose(total, full, rtol=3e-6, atol=1e-6)
+        for opts in (static, None):
+            parts, paths = [], 0
+            for rank in range(world):
+                r.clear()
+                paths += r.render_frame(6, 9, rank=rank, world=world, opts=opts)["paths"]
+                parts.append(r.read().astype(np.float64))
+            assert paths == st_full["paths"]
+            total = np.sum(parts, axis=0)
+            if opts is static:
+                interior = np.ones((H, W), bool)
+                for e in (128, 256):
+                    interior[e - 2:e + 2, :] = False
+                    interior[:, e - 2:e + 2] = False
+                assert (total[interior].astype(np.float32) == full[interior]).all()
+            np.testing.assert_allclose(total, full, rtol=3e-6, atol=1e-6)
 
 
 def test_config2_full_size_properties(gpu_renderer, cbox):
@@ -252,17 +259,23 @@ def test_config2_full_size_properties(gpu_renderer, cbox):
     r.render_frame(spp, 1, pass_begin=0, pass_end=200)
     r.render_frame(spp, 1, pass_begin=200, pass_end=512)
     assert (bits(r.read()) == bits(a)).all()
-    total = np.zeros((H, W, 4), np.float64)
-    for rank in range(8):
-        r.clear()
-        r.render_frame(spp, 1, rank=rank, world=8)
-        total += r.read()
-    interior = np.ones((H, W), bool)
-    for e in range(128, 1024, 128):
-        interior[e - 2:e + 2, :] = False
-        interior[:, e - 2:e + 2] = False
-    assert (total[interior].astype(np.float32) == a[interior]).all()
-    np.testing.assert_allclose(total, a, rtol=2e-5, atol=1e-5)
+    static = device.default_opts()
+    static.flags = abi.RENDER_STATIC_DEAL
+    for opts in (static, None):               # None = the default deal that rotates with the pass
+        total = np.zeros((H, W, 4), np.float64)
+        paths = []
+        for rank in range(8):
+            r.clear()
+            paths.append(r.render_frame(spp, 1, rank=rank, world=8, opts=opts)["paths"])
+            total += r.read()
+        assert sum(paths) == st["paths"] and max(paths) == min(paths)
+        if opts is static:
+            interior = np.ones((H, W), bool)
+            for e in range(128, 1024, 128):
+                interior[e - 2:e + 2, :] = False
+                interior[:, e - 2:e + 2] = False
+            assert (total[interior].astype(np.float32) == a[interior]).all()
+        np.testing.assert_allclose(total, a, rtol=5e-5, atol=1e-5)
 
 
 def test_large_mesh_and_large_frame(gpu_renderer, oracle):
