@@ -637,12 +637,19 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     {
       const float thr = (float)env_int("HJ_COLLAPSE_PCT", 50, 0, 1000) / 100.0f;
       auto inner = [&](size_t i) { return s->bvh[i].shape_index == HJ_BVH_INNER; };
+      auto inside = [&](size_t c, size_t p) {   // false for NaN bounds
+        bool ok = true;
+        for (int k = 0; k < 3; k++)
+          ok = ok && s->bvh[c].aabb_min[k] >= s->bvh[p].aabb_min[k] && s->bvh[c].aabb_max[k] <= s->bvh[p].aabb_max[k];
+        return ok;
+      };
       std::vector<float> anc(N, 0.f);   // area of the nearest kept ancestor
       for (size_t i = 0; i < N; i++) {  // pre-order: ancestors come first
         if (!inner(i) || i + 1 >= N) continue;
         const size_t l = i + 1, r = s->bvh[l].exit_index;
         if (r >= N || r <= l) continue;                       // not a well-formed pre-order pair: leave it alone
-        if (i != 0 && inner(l) && inner(r) && anc[i] > 0.f && sa[i] > thr * anc[i]) del[i] = 1;
+        // (an uploaded tree whose child boxes stick out of P's box keeps P: the argument above needs containment)
+        if (i != 0 && inner(l) && inner(r) && anc[i] > 0.f && sa[i] > thr * anc[i] && inside(l, i) && inside(r, i)) del[i] = 1;
         anc[l] = anc[r] = del[i] ? anc[i] : sa[i];
       }
     }

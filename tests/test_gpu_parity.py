@@ -187,6 +187,25 @@ def test_traversal_probe_matches_oracle(gpu_renderer, oracle, cbox):
     assert ((ai >= 0) == (oi >= 0)).all()
 
 
+def test_uploaded_tree_with_inconsistent_boxes(gpu_renderer, oracle):
+    """hj_scene_upload takes ANY skip-link tree.  Shrinking inner boxes so that their children stick out breaks the
+    containment that the device re-layout (dropping redundant inner nodes) relies on: those nodes must be kept, and
+    the walk must still be the reference's, box for box."""
+    cs = host.Scene.synthetic(host.SYNTH_CBOX, mesh_triangles=1280).compile()
+    nodes, f = cs.bvh, cs.bvh_f32
+    inner = np.nonzero(nodes[:, 3] == 0xFFFFFFFF)[0]
+    rng = np.random.default_rng(5)
+    for i in rng.choice(inner[1:], size=len(inner) // 3, replace=False):
+        c = 0.5 * (f[i, 0:3] + f[i, 4:7])
+        f[i, 0:3] = c + (f[i, 0:3] - c) * 0.8
+        f[i, 4:7] = c + (f[i, 4:7] - c) * 0.8
+    W = H = 128
+    blocks = host.make_blocks(W, H, 3, 11)
+    want, _, _ = oracle.render_blocks(cs, blocks, W, H)
+    got, _ = render(gpu_renderer, cs, W, H, blocks)
+    assert_same(got, want, "shrunk inner boxes")
+
+
 def test_rendering_is_deterministic_and_additive(gpu_renderer, cbox):
     """Size-independent properties at a larger size: run-to-run bitwise determinism, and passes [0,a)+[a,b)
     accumulated by two calls == one call (the framebuffer is a running sum)."""
