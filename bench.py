@@ -6,7 +6,7 @@ synthetic Cornell box at 1024 x 1024, 512 spp (BASELINE.json configs[1]) on N MI
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A step = one whole frame: every rank renders its ImageBlocks (diagonal deal, hj_block_owner) of all 512 passes into a private
+A step = one whole frame: every rank renders its ImageBlocks (rotating diagonal deal, hj_block_owner) of all 512 passes into a private
 full-frame RGBA32F buffer and one RCCL sum-reduce brings the frame to rank 0 (strong scaling: the frame is fixed).
 Scene, BVH and block lists are resident/derived before the timed region; nothing is read back inside it.
 
@@ -23,6 +23,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before torch initialises HIP: see hijiki_amd/__init__.py
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -132,7 +133,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"cbox-synth {W}x{H} {spp}spp diffuse+emissive, 6332 triangles, BVH, block 128, seed {args.seed}",
-                       "partition": f"ImageBlock (bx, by) -> rank (bx + by) mod {world}, RCCL sum-reduce of the {W}x{H} RGBA32F framebuffer"},
+                       "partition": f"ImageBlock (bx, by) of pass p -> rank (bx + by + p) mod {world}, RCCL sum-reduce of the {W}x{H} RGBA32F framebuffer"},
         }
         base = None
         ctr = None

@@ -507,6 +507,13 @@ void hj_default_render_opts(hj_render_opts* o) {
 
 const char* hj_last_error(const hj_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
+// Three batch streams + the context stream want their own hardware queues; the HIP runtime's default is 4 queues
+// for the whole process and streams that share one serialise (measured: frames 9 % slower when another HIP user
+// of the process had taken queues first).  The runtime reads GPU_MAX_HW_QUEUES when it initialises, i.e. at the
+// first HIP call of the process, so this only helps when the library is loaded before that; hosts that initialise
+// HIP earlier set the variable themselves.  An existing value is respected.
+__attribute__((constructor)) static void hj_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 int hj_context_create(int device, hj_context** out) {
   if (!out) return set_error(nullptr, HJ_ERR_INVALID, "null out pointer");
   *out = nullptr;

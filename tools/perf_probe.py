@@ -1,5 +1,8 @@
 """Render N frames of cbox 1024x1024 at --spp for profiling (no oracle work)."""
 import sys, os, time, argparse
+import os as _os
+if _os.environ.get("HJ_IMPORT_TORCH"):
+    import torch  # noqa: F401  (use the HIP runtime bundled with the torch wheel, as bench.py does)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hijiki_amd import host, device, abi
 
