@@ -394,8 +394,11 @@ int enqueue_batch_fused(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::
   if (rc != HJ_OK) return rc;
   const dim3 blk(hj::kBlockThreads), grid(st.num_wg);
   const int ev = tm.begin(EV_PATH, sl.stream);
-  if (o.use_bvh) hipLaunchKernelGGL(hj::k_path_wavefront<true>, grid, blk, 0, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
-  else hipLaunchKernelGGL(hj::k_path_wavefront<false>, grid, blk, 0, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  // HJ_LDS_PAD_KB (diagnostic): unused dynamic LDS that lowers the number of resident workgroups per CU without
+  // touching the code, to measure how the frame rate scales with occupancy.
+  static const size_t lds_pad = (size_t)env_int("HJ_LDS_PAD_KB", 0, 0, 64) * 1024;
+  if (o.use_bvh) hipLaunchKernelGGL(hj::k_path_wavefront<true>, grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  else hipLaunchKernelGGL(hj::k_path_wavefront<false>, grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
   tm.end(ev, sl.stream);
   if (reconstruct) {
     rc = enqueue_reconstruct(ctx, sl, other, st, nb, o, tm);
@@ -1060,6 +1063,17 @@ int hj_debug_samples(hj_context* ctx, const hj_image_block* block, const hj_rend
     }
   return HJ_OK;
 }
+
+#ifdef HJ_WALK_STATS
+extern "C" __attribute__((visibility("default"))) int hj_debug_walk_stats(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hj::g_walk_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return HJ_ERR_DEVICE;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hj::g_walk_stats), z, sizeof z) != hipSuccess) return HJ_ERR_DEVICE;
+  }
+  return HJ_OK;
+}
+#endif
 
 uint32_t hj_block_seed(uint64_t master, uint32_t pass, uint32_t j) { return hijiki::block_seed(master, pass, j); }
 uint32_t hj_block_owner(uint32_t width, uint32_t height, uint32_t pass, uint32_t j, uint32_t world) {

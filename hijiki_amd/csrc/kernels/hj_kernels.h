@@ -53,6 +53,25 @@ HJ_DEV uint32_t lds_fetch_chunk(uint32_t* lds_head) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
 }
 
+// Path-state accessors.  HJ_NT_STATE marks them non-temporal (streaming) so that they do not displace scene data
+// (nodes, triangles) from the 32 KB vector L1.
+typedef float f4s __attribute__((ext_vector_type(4)));
+HJ_DEV float4 ldp(const float4* p, uint32_t i) {
+#if defined(HJ_NT_STATE) || defined(HJ_NT_LOADS)
+  const f4s v = __builtin_nontemporal_load(reinterpret_cast<const f4s*>(p + i));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return p[i];
+#endif
+}
+HJ_DEV void stp(float4* p, uint32_t i, float4 v) {
+#if defined(HJ_NT_STATE) || defined(HJ_NT_STORES)
+  f4s w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+  __builtin_nontemporal_store(w, reinterpret_cast<f4s*>(p + i));
+#else
+  p[i] = v;
+#endif
+}
 struct Ray { v3 o, d; float tmin, tmax; };
 struct RawHit { float t, u, v; int id; };
 
@@ -178,10 +197,20 @@ HJ_DEV bool traverse(const DeviceScene& sc, Ray r, RawHit& h) {
 //   finish(done, slot, h) wave-convergent: called when some lanes are done; `done` lanes have a final result
 constexpr uint32_t kRefillMin = 32;   // sweep on the fused kernel: 16 -> 1.39, 32..48 -> 1.43 Gpaths/s, 64 -> 1.24
 
+#ifdef HJ_WALK_STATS
+// Diagnostic build only (tools/build_variant.sh stats -DHJ_WALK_STATS): wave-level occupancy of the walk's phases.
+// [0] outer iterations [1] inner wave-steps [2] lanes in them [3] leaf phases [4] lanes in them [5] refills
+// [6] lanes refilled [7] lanes active at the start of an outer iteration
+__device__ unsigned long long g_walk_stats[8];
+#define HJ_STAT(i, v) do { const long long v_ = (long long)(v); if (__lane_id() == 0) ws[i] += (unsigned long long)v_; } while (0)
+#else
+#define HJ_STAT(i, v) do { } while (0)
+#endif
+
 // MODE 0: closest-hit rays, 1: any-hit (shadow) rays, 2: both kinds in one queue (fetch says which per ray).
 template <int MODE, class Fetch, class Finish>
-HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head, const float4* s_n0,
-                             const float4* s_n1, Fetch fetch, Finish finish) {
+HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head, const float4* s_nodes,
+                             Fetch fetch, Finish finish) {
   const uint32_t lane = __lane_id();
   const uint32_t nn = sc.num_nodes, nhot = sc.num_hot;
   bool active = false, pending = false, exhausted = false, any = (MODE == 1);
@@ -189,6 +218,9 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
   Ray r; r.o = V(0, 0, 0); r.d = V(0, 0, 0); r.tmin = 0.f; r.tmax = 0.f;
   v3 inv = V(0, 0, 0), off = V(0, 0, 0);
   RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
+#ifdef HJ_WALK_STATS
+  unsigned long long ws[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (;;) {
     // Service phase: only when enough lanes are free.  Finished lanes keep their result in registers until
     // then, so that result STORES and new-ray LOADS are issued together, once per phase: vmcnt counts loads and
@@ -213,20 +245,29 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
           }
         }
         exhausted = base + nidle >= n;
+        HJ_STAT(5, 1); HJ_STAT(6, __popcll(__ballot(active)) - (64 - (int)nidle));
       }
     }
     if (__ballot(active) == 0) break;
+    HJ_STAT(0, 1); HJ_STAT(7, __popcll(__ballot(active)));
     uint32_t shape = 0, ex = 0;
     bool at_leaf = false;
     uint32_t burst = sc.inner_burst;       // lanes standing on a leaf wait at most this many box steps of the others
     while (active && cur < nn && !at_leaf && burst != 0) {
-      float4 n0, n1;
-      if (cur < nhot) { n0 = s_n0[cur]; n1 = s_n1[cur]; }                 // hot node: LDS copy
-      else { n0 = sc.nodes[2 * cur]; n1 = sc.nodes[2 * cur + 1]; }
+      // hot node: LDS copy, same 32-byte record layout as in HBM, so that ONE address select feeds both 16-byte
+      // loads (FLAT loads of base + 32*cur and +16; a per-array `if` compiled to two exec-masked address blocks)
+      const float4* __restrict__ nd = (cur < nhot ? s_nodes : sc.nodes) + 2 * cur;
+      const float4 n0 = nd[0], n1 = nd[1];
       at_leaf = node_step(n0, n1, inv, off, r, cur, shape, ex);
       burst--;
+#ifdef HJ_WALK_STATS
+      { const unsigned long long m = __ballot(true); if (lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[1] += 1; ws[2] += __popcll(m); } }
+#endif
     }
     if (active && !at_leaf && cur >= nn) { active = false; pending = true; }   // walked off the end of the tree
+#ifdef HJ_WALK_STATS
+    { const unsigned long long m = __ballot(at_leaf); if (m && lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[3] += 1; ws[4] += __popcll(m); } }
+#endif
     if (at_leaf) {
       if (intersect_shape(sc, r, shape, h)) {
         h.id = (int)shape;
@@ -236,6 +277,13 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
       cur = ex;
     }
   }
+#ifdef HJ_WALK_STATS
+  for (int i = 0; i < 8; i++) {      // ws[] lives in whichever lane did the counting: sum over the wave
+    unsigned long long v = ws[i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (lane == 0 && v) atomicAdd(&g_walk_stats[i], v);
+  }
+#endif
 }
 
 // ------------------------------------------------------------ populate (its)
@@ -354,11 +402,11 @@ struct WgShared {                 // LDS of a path workgroup (8.3 KB)
   uint32_t wcnt[kBlockThreads / 64][kNumTags];   // per-wave tag counts of the ordered compaction
   uint32_t n_next, n_shadow;      // next-bounce rays / shadow rays produced by shade
   uint32_t n_gen;
-  float4 n0[kHotNodes], n1[kHotNodes];   // LDS copy of the hottest BVH nodes
+  float4 nodes[2 * kHotNodes];    // LDS copy of the hottest BVH nodes (same record layout as DeviceScene::nodes)
 };
 
 HJ_DEV void load_hot_nodes(const DeviceScene& sc, WgShared& sh) {
-  for (uint32_t i = threadIdx.x; i < sc.num_hot; i += blockDim.x) { sh.n0[i] = sc.nodes[2 * i]; sh.n1[i] = sc.nodes[2 * i + 1]; }
+  for (uint32_t i = threadIdx.x; i < 2 * sc.num_hot; i += blockDim.x) sh.nodes[i] = sc.nodes[i];
 }
 
 // reference shader/render.glsl:26-36,149-162.  Needs sh.n_gen == 0 on entry (synced); leaves the count there.
@@ -401,13 +449,13 @@ HJ_DEV void stage_gen_camera(const BatchState& st, const DeviceScene& sc, uint32
       const v3 c2 = cross3(txyz, cq);
       const v3 rot = V((c2.x + txyz.x * qw) + cq.x * tw, (c2.y + txyz.y * qw) + cq.y * tw, (c2.z + txyz.z * qw) + cq.z * tw);
       const v3 d = normalize3(rot);
-      st.ray_o[slot] = make_float4(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2], 0.f);
-      st.ray_d[slot] = make_float4(d.x, d.y, d.z, 0.f);
-      st.thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(1u));   // wasDiscrete = true
-      if (sc.has_extinction) st.ext[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+      stp(st.ray_o, slot, make_float4(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2], 0.f));
+      stp(st.ray_d, slot, make_float4(d.x, d.y, d.z, 0.f));
+      stp(st.thr, slot, make_float4(1.f, 1.f, 1.f, __uint_as_float(1u)));   // wasDiscrete = true
+      if (sc.has_extinction) stp(st.ext, slot, make_float4(0.f, 0.f, 0.f, 0.f));
       st.rng[slot] = rng;
-      st.smp_rgb[slot] = make_float4(0.f, 0.f, 0.f, 1.f);
-      st.smp_nd[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+      stp(st.smp_rgb, slot, make_float4(0.f, 0.f, 0.f, 1.f));
+      stp(st.smp_nd, slot, make_float4(0.f, 0.f, 0.f, 0.f));
     }
     const uint32_t qi = lds_push(&sh.n_gen, valid);
     if (valid) q[qi] = slot;
@@ -427,15 +475,15 @@ HJ_DEV void stage_trace_closest(const BatchState& st, const DeviceScene& sc, uin
   // A finished ray only records its hit (objectID -1 = miss).  The hit queues are built afterwards in QUEUE order
   // (below), not in finishing order, so that the paths a shading wave touches stay close together in memory.
   auto finish = [&](bool done, uint32_t slot, const RawHit& h, bool) {
-    if (done) st.hit[slot] = make_float4(h.t, __int_as_float(h.id), h.u, h.v);
+    if (done) stp(st.hit, slot, make_float4(h.t, __int_as_float(h.id), h.u, h.v));
   };
   if (USE_BVH) {
     auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r, bool&) {
       slot = q[i];
-      const float4 o = st.ray_o[slot], d = st.ray_d[slot];
+      const float4 o = ldp(st.ray_o, slot), d = ldp(st.ray_d, slot);
       r.o = xyz(o); r.d = xyz(d); r.tmin = tmin; r.tmax = kInf;
     };
-    trace_persistent<0>(sc, n, &sh.head, sh.n0, sh.n1, fetch, finish);
+    trace_persistent<0>(sc, n, &sh.head, sh.nodes, fetch, finish);
   } else {
     for (;;) {
       const uint32_t c = lds_fetch_chunk(&sh.head);
@@ -446,7 +494,7 @@ HJ_DEV void stage_trace_closest(const BatchState& st, const DeviceScene& sc, uin
       RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
       if (valid) {
         slot = q[i];
-        const float4 o = st.ray_o[slot], d = st.ray_d[slot];
+        const float4 o = ldp(st.ray_o, slot), d = ldp(st.ray_d, slot);
         Ray r; r.o = xyz(o); r.d = xyz(d); r.tmin = tmin; r.tmax = kInf;
         traverse<false, false>(sc, r, h);
       }
@@ -471,7 +519,7 @@ HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uin
   auto tag_of = [&](uint32_t i, uint32_t& slot) -> uint32_t {
     if (i >= n) return 0xFFu;
     slot = q[i];
-    const int id = __float_as_int(st.hit[slot].y);
+    const int id = __float_as_int(ldp(st.hit, slot).y);
     return id >= 0 ? sc.materials[id] >> HJ_MATERIAL_TAG_SHIFT : 0xFFu;
   };
   uint32_t cnt[kNumTags];
@@ -519,19 +567,19 @@ HJ_DEV void stage_trace_shadow(const BatchState& st, const DeviceScene& sc, uint
   const uint32_t* __restrict__ q = st.q_shadow + (size_t)g * st.segcap;
   auto add_unoccluded = [&](bool done, uint32_t slot, const RawHit&, bool) {
     if (done) {
-      const float4 cc = st.sh_c[slot];
-      float4 s = st.smp_rgb[slot];
+      const float4 cc = ldp(st.sh_c, slot);
+      float4 s = ldp(st.smp_rgb, slot);
       s.x += cc.x; s.y += cc.y; s.z += cc.z;      // render.glsl:123
-      st.smp_rgb[slot] = s;
+      stp(st.smp_rgb, slot, s);
     }
   };
   if (USE_BVH) {
     auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r, bool&) {
       slot = q[i];
-      const float4 o = st.ray_o[slot], d = st.sh_d[slot];
+      const float4 o = ldp(st.ray_o, slot), d = ldp(st.sh_d, slot);
       r.o = xyz(o); r.d = xyz(d); r.tmin = 2.0f * kEps; r.tmax = d.w;
     };
-    trace_persistent<1>(sc, n, &sh.head, sh.n0, sh.n1, fetch, add_unoccluded);
+    trace_persistent<1>(sc, n, &sh.head, sh.nodes, fetch, add_unoccluded);
   } else {
     for (;;) {
       const uint32_t c = lds_fetch_chunk(&sh.head);
@@ -539,7 +587,7 @@ HJ_DEV void stage_trace_shadow(const BatchState& st, const DeviceScene& sc, uint
       const uint32_t i = c + lane;
       if (i < n) {
         const uint32_t slot = q[i];
-        const float4 o = st.ray_o[slot], d = st.sh_d[slot];
+        const float4 o = ldp(st.ray_o, slot), d = ldp(st.sh_d, slot);
         Ray r; r.o = xyz(o); r.d = xyz(d); r.tmin = 2.0f * kEps; r.tmax = d.w;
         RawHit h;
         if (!traverse<false, true>(sc, r, h)) add_unoccluded(true, slot, h, true);
@@ -562,23 +610,23 @@ HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint
   auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r, bool& any) {
     any = i >= n;
     slot = any ? qs[i - n] : q[i];
-    const float4 o = st.ray_o[slot];
+    const float4 o = ldp(st.ray_o, slot);
     float4 d;
-    if (any) d = st.sh_d[slot]; else d = st.ray_d[slot];
+    if (any) d = ldp(st.sh_d, slot); else d = ldp(st.ray_d, slot);
     r.o = xyz(o); r.d = xyz(d);
     r.tmin = any ? 2.0f * kEps : tmin;
     r.tmax = any ? d.w : kInf;
   };
   auto finish = [&](bool done, uint32_t slot, const RawHit& h, bool any) {
-    if (done && !any) st.hit[slot] = make_float4(h.t, __int_as_float(h.id), h.u, h.v);
+    if (done && !any) stp(st.hit, slot, make_float4(h.t, __int_as_float(h.id), h.u, h.v));
     if (done && any) {                              // unoccluded shadow ray: render.glsl:123
-      const float4 cc = st.sh_c[slot];
-      float4 s = st.smp_rgb[slot];
+      const float4 cc = ldp(st.sh_c, slot);
+      float4 s = ldp(st.smp_rgb, slot);
       s.x += cc.x; s.y += cc.y; s.z += cc.z;
-      st.smp_rgb[slot] = s;
+      stp(st.smp_rgb, slot, s);
     }
   };
-  trace_persistent<2>(sc, n + ns, &sh.head, sh.n0, sh.n1, fetch, finish);
+  trace_persistent<2>(sc, n + ns, &sh.head, sh.nodes, fetch, finish);
   compact_hits_by_tag(st, sc, g, q, n, sh);
 }
 
@@ -601,9 +649,9 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
     uint32_t slot = 0;
     if (valid) {
       slot = q[i];
-      const float4 hr = st.hit[slot];
-      const float4 ro4 = st.ray_o[slot], rd4 = st.ray_d[slot];
-      const float4 th4 = st.thr[slot];
+      const float4 hr = ldp(st.hit, slot);
+      const float4 ro4 = ldp(st.ray_o, slot), rd4 = ldp(st.ray_d, slot);
+      const float4 th4 = ldp(st.thr, slot);
       const v3 ro = xyz(ro4), rd = xyz(rd4);
       v3 T = xyz(th4);
       const bool was_discrete = (__float_as_uint(th4.w) & 1u) != 0u;
@@ -614,12 +662,12 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
       if (id < sc.ns) populate_sphere(sc.spheres[id], its);
       else if (id < sc.ns + sc.nq) populate_quad(sc, id - sc.ns, hr.z, hr.w, its);
       else populate_triangle(sc, id - sc.ns - sc.nq, hr.z, hr.w, its);
-      if (bounce == 0) st.smp_nd[slot] = make_float4(its.n.x, its.n.y, its.n.z, hr.x);   // render.glsl:102-105
+      if (bounce == 0) stp(st.smp_nd, slot, make_float4(its.n.x, its.n.y, its.n.z, hr.x));   // render.glsl:102-105
       const uint32_t mat = sc.materials[id];
       const uint32_t midx = mat & HJ_MATERIAL_INDEX_MASK;
       v3 ext = V(0, 0, 0);
       if (sc.has_extinction) {                                                             // render.glsl:111-112
-        ext = xyz(st.ext[slot]);
+        ext = xyz(ldp(st.ext, slot));
         const float dist = len3(ro - its.p);
         T = T * V(hj_exp(-ext.x * dist), hj_exp(-ext.y * dist), hj_exp(-ext.z * dist));
       }
@@ -629,9 +677,9 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
         case HJ_MAT_EMISSIVE: {
           if (was_discrete) {                                                              // render.glsl:114-116
             const v3 e = T * xyz(sc.emissive[midx]);
-            float4 s = st.smp_rgb[slot];
+            float4 s = ldp(st.smp_rgb, slot);
             s.x += e.x; s.y += e.y; s.z += e.z;
-            st.smp_rgb[slot] = s;
+            stp(st.smp_rgb, slot, s);
           }
           alive = false;   // sampleBSDF weight 0, wo unwritten (material.glsl:88-89)
           break;
@@ -645,8 +693,8 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
             const float cs = dot3(its.n, sdir);
             const v3 f = (color * cs) * kInvPi;                                            // material.glsl:18-30
             const v3 c = (T * f) * imp;
-            st.sh_d[slot] = make_float4(sdir.x, sdir.y, sdir.z, stmax);
-            st.sh_c[slot] = make_float4(c.x, c.y, c.z, 0.f);
+            stp(st.sh_d, slot, make_float4(sdir.x, sdir.y, sdir.z, stmax));
+            stp(st.sh_c, slot, make_float4(c.x, c.y, c.z, 0.f));
             want_shadow = true;
           }
           const v3 l = rand_cos_hemisphere(rng);                                           // material.glsl:37-46
@@ -696,12 +744,12 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
           else T = divs(T, qq);
         }
         if (bounce + 1u >= max_bounces) alive = false;                                     // render.glsl:92
-        st.ray_d[slot] = make_float4(wo.x, wo.y, wo.z, 0.f);
-        st.thr[slot] = make_float4(T.x, T.y, T.z, __uint_as_float(discrete ? 1u : 0u));
+        stp(st.ray_d, slot, make_float4(wo.x, wo.y, wo.z, 0.f));
+        stp(st.thr, slot, make_float4(T.x, T.y, T.z, __uint_as_float(discrete ? 1u : 0u)));
         st.rng[slot] = rng;
-        if (sc.has_extinction) st.ext[slot] = make_float4(ext.x, ext.y, ext.z, 0.f);
+        if (sc.has_extinction) stp(st.ext, slot, make_float4(ext.x, ext.y, ext.z, 0.f));
       }
-      st.ray_o[slot] = make_float4(its.p.x, its.p.y, its.p.z, 0.f);   // next origin == shadow-ray origin
+      stp(st.ray_o, slot, make_float4(its.p.x, its.p.y, its.p.z, 0.f));   // next origin == shadow-ray origin
     }
     const uint32_t qn = lds_push(&sh.n_next, alive);
     if (alive) q_next[qn] = slot;
