@@ -814,18 +814,49 @@ int hj_framebuffer_resolve(hj_context* ctx, float* host_rgb) {
   return HJ_OK;
 }
 
-int hj_render_blocks(hj_context* ctx, const hj_image_block* blocks, size_t n, const hj_render_opts* opts,
-                     hj_render_stats* stats) {
-  if (!ctx) return HJ_ERR_INVALID;
+// One render call = begin / submit ... / end, so that hj_render_frame can stream its block list through the batch
+// pipeline chunk by chunk without draining the slots between chunks (each drain exposes the tail of the last
+// kernels: ~3.5 ms on cbox).
+namespace {
+struct RenderRun {
+  hj_render_opts o{};
+  Timer tm{nullptr, false};
+  bool split = false;
+  hj_render_stats local{};
+  hj_render_stats* st = nullptr;
+  size_t k = 0;            // batches enqueued so far (slot rotation)
+  uint64_t paths = 0;
+  uint32_t batch = 0;
+  std::chrono::steady_clock::time_point wall0;
+};
+
+int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_render_stats* stats, size_t total_blocks) {
   if (!ctx->have_scene) return set_error(ctx, HJ_ERR_STATE, "render before hj_scene_upload");
   if (!ctx->accum) return set_error(ctx, HJ_ERR_STATE, "render before hj_framebuffer_create");
-  if (n && !blocks) return set_error(ctx, HJ_ERR_INVALID, "null block list");
-  hj_render_opts o;
-  if (opts) o = *opts;
-  else hj_default_render_opts(&o);
-  int rc = check_opts(ctx, o);
+  if (opts) run.o = *opts;
+  else hj_default_render_opts(&run.o);
+  int rc = check_opts(ctx, run.o);
   if (rc != HJ_OK) return rc;
-  uint64_t paths = 0;
+  HJ_HIP(ctx, hipSetDevice(ctx->device));
+  run.st = stats ? stats : &run.local;
+  std::memset(run.st, 0, sizeof *run.st);
+  ctx->events_used = 0;
+  run.tm = Timer{ctx, (run.o.flags & HJ_RENDER_TIME_KERNELS) != 0};
+  run.split = (run.o.flags & HJ_RENDER_SPLIT_KERNELS) != 0;
+  // Default batch: large batches amortise the latency-bound tail of a batch (measured: cbox+mirror+glass 700 ->
+  // 960 Mpaths/s from 512 to 2048 blocks), but at least ~8 batches should exist so that the slots can overlap.
+  const size_t n = total_blocks;
+  run.batch = run.o.batch_blocks ? run.o.batch_blocks
+                                 : (uint32_t)std::min<size_t>(2048, std::max<size_t>(256, ((n + 7) / 8 + 63) / 64 * 64));
+  run.batch = std::min<uint32_t>(run.batch, 4096u);
+  rc = sync_all(ctx);
+  if (rc != HJ_OK) return rc;
+  run.wall0 = std::chrono::steady_clock::now();
+  return HJ_OK;
+}
+
+// Enqueues the batches of `blocks` (copied into the slots' pinned staging before this returns).
+int run_submit(hj_context* ctx, RenderRun& run, const hj_image_block* blocks, size_t n) {
   for (size_t i = 0; i < n; i++) {
     const hj_image_block& b = blocks[i];
     if (b.dimension[0] == 0 || b.dimension[1] == 0 || b.dimension[0] > HJ_BLOCK_SIZE || b.dimension[1] > HJ_BLOCK_SIZE)
@@ -833,35 +864,28 @@ int hj_render_blocks(hj_context* ctx, const hj_image_block* blocks, size_t n, co
     if (b.original_dimension[0] != ctx->width || b.original_dimension[1] != ctx->height)
       return set_error(ctx, HJ_ERR_INVALID, "block %zu: original_dimension %ux%u != framebuffer %ux%u", i,
                        b.original_dimension[0], b.original_dimension[1], ctx->width, ctx->height);
-    paths += (uint64_t)std::min(b.dimension[0], b.original_dimension[0]) * std::min(b.dimension[1], b.original_dimension[1]);
+    run.paths += (uint64_t)std::min(b.dimension[0], b.original_dimension[0]) * std::min(b.dimension[1], b.original_dimension[1]);
   }
-  HJ_HIP(ctx, hipSetDevice(ctx->device));
-  hj_render_stats local{};
-  hj_render_stats* st_out = stats ? stats : &local;
-  std::memset(st_out, 0, sizeof *st_out);
-  ctx->events_used = 0;
-  Timer tm{ctx, (o.flags & HJ_RENDER_TIME_KERNELS) != 0};
-  const bool split = (o.flags & HJ_RENDER_SPLIT_KERNELS) != 0;
-  // Default batch: large batches amortise the latency-bound tail of a batch (measured: cbox+mirror+glass 700 ->
-  // 960 Mpaths/s from 512 to 2048 blocks), but at least ~8 batches should exist so that the slots can overlap.
-  uint32_t batch = o.batch_blocks ? o.batch_blocks
-                                  : (uint32_t)std::min<size_t>(2048, std::max<size_t>(256, ((n + 7) / 8 + 63) / 64 * 64));
-  batch = std::min<uint32_t>(batch, 4096u);
-  rc = sync_all(ctx);
-  if (rc != HJ_OK) return rc;
-  const auto wall0 = std::chrono::steady_clock::now();
-  size_t k = 0;
-  for (size_t begin = 0; begin < n && rc == HJ_OK; begin += batch, k++) {
-    const uint32_t nb = (uint32_t)std::min<size_t>(batch, n - begin);
-    hj_context::BatchSlot& sl = ctx->slots[k % ctx->num_slots];
-    hj_context::BatchSlot& other = ctx->slots[(k + ctx->num_slots - 1) % ctx->num_slots];   // the previous batch's slot
-    rc = harvest(ctx, sl, st_out);          // an older batch used this slot: its state arrays are free again
+  int rc = HJ_OK;
+  // (Shrinking the last batches of a run - each 1/2 .. 1/6 of what is left - was measured: no change; the ~3.5 ms a
+  // frame loses to pipeline fill and drain does not depend on the size of the last kernels.)
+  for (size_t begin = 0; begin < n && rc == HJ_OK; run.k++) {
+    const uint32_t nb = (uint32_t)std::min<size_t>(run.batch, n - begin);
+    hj_context::BatchSlot& sl = ctx->slots[run.k % ctx->num_slots];
+    hj_context::BatchSlot& other = ctx->slots[(run.k + ctx->num_slots - 1) % ctx->num_slots];   // the previous batch's slot
+    rc = harvest(ctx, sl, run.st);          // an older batch used this slot: its state arrays are free again
     if (rc != HJ_OK) break;
-    rc = split ? render_batch_split(ctx, sl, other, blocks + begin, nb, o, tm, st_out, true)
-               : enqueue_batch_fused(ctx, sl, other, blocks + begin, nb, o, tm, st_out, true);
+    rc = run.split ? render_batch_split(ctx, sl, other, blocks + begin, nb, run.o, run.tm, run.st, true)
+                   : enqueue_batch_fused(ctx, sl, other, blocks + begin, nb, run.o, run.tm, run.st, true);
+    begin += nb;
   }
+  return rc;
+}
+
+// Drains the slots (also after an error, so that nothing of this run is still in flight) and closes the statistics.
+int run_end(hj_context* ctx, RenderRun& run, int rc) {
   for (auto& sl : ctx->slots) {
-    const int rc2 = harvest(ctx, sl, st_out);
+    const int rc2 = harvest(ctx, sl, run.st);
     if (rc == HJ_OK) rc = rc2;
   }
   if (rc == HJ_OK) {
@@ -873,8 +897,9 @@ int hj_render_blocks(hj_context* ctx, const hj_image_block* blocks, size_t n, co
     if (e != hipSuccess) rc = set_error(ctx, HJ_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
   }
   if (rc == HJ_OK) {
-    st_out->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-    st_out->paths = paths;
+    hj_render_stats* st_out = run.st;
+    st_out->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - run.wall0).count();
+    st_out->paths = run.paths;
     for (size_t i = 0; i < ctx->events_used; i++) {
       float e = 0.f;
       if (hipEventElapsedTime(&e, ctx->events[i].a, ctx->events[i].b) != hipSuccess) continue;
@@ -889,6 +914,18 @@ int hj_render_blocks(hj_context* ctx, const hj_image_block* blocks, size_t n, co
   }
   return rc;
 }
+}  // namespace
+
+int hj_render_blocks(hj_context* ctx, const hj_image_block* blocks, size_t n, const hj_render_opts* opts,
+                     hj_render_stats* stats) {
+  if (!ctx) return HJ_ERR_INVALID;
+  if (n && !blocks) return set_error(ctx, HJ_ERR_INVALID, "null block list");
+  RenderRun run;
+  int rc = run_begin(ctx, run, opts, stats, n);
+  if (rc != HJ_OK) return rc;
+  rc = run_submit(ctx, run, blocks, n);
+  return run_end(ctx, run, rc);
+}
 
 int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed, uint32_t pass_begin, uint32_t pass_end,
                     uint32_t rank, uint32_t world, const hj_render_opts* opts, hj_render_stats* stats) {
@@ -901,29 +938,26 @@ int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed, uint32_
   // pass; with HJ_RENDER_STATIC_DEAL all passes of one block stay on one GPU and accumulate there in pass order,
   // SURVEY.md §8e).  The list is generated in chunks
   // (4096^2 x 4096 spp would be 4.2 M blocks = 168 MB if materialised at once).
-  hj_render_stats total{};
   std::vector<hj_image_block> chunk;
   const bool static_deal = opts && (opts->flags & HJ_RENDER_STATIC_DEAL);
   const uint32_t per_pass = grid.per_pass();
   const uint32_t passes_per_chunk = std::max<uint32_t>(1u, 32768u / std::max<uint32_t>(1u, (per_pass + world - 1) / world));
-  int rc = HJ_OK;
+  // blocks this rank will render (for the batch-size rule): every rank owns per_pass / world of each pass, +-1
+  const size_t mine_estimate = (size_t)(pass_end - pass_begin) * ((per_pass + world - 1) / world);
+  RenderRun run;
+  int rc = run_begin(ctx, run, opts, stats, mine_estimate);
+  if (rc != HJ_OK) return rc;
   for (uint32_t p0 = pass_begin; p0 < pass_end && rc == HJ_OK; p0 += passes_per_chunk) {
     const uint32_t p1 = std::min(pass_end, p0 + passes_per_chunk);
-    chunk.clear();
     for (uint32_t p = p0; p < p1; p++)
       for (uint32_t j = 0; j < per_pass; j++)
         if (grid.owner(static_deal ? 0u : p, j, world) == rank) chunk.push_back(grid.make(master_seed, p, j));
-    hj_render_stats st{};
-    rc = hj_render_blocks(ctx, chunk.data(), chunk.size(), opts, &st);
-    total.paths += st.paths; total.closest_rays += st.closest_rays; total.shadow_rays += st.shadow_rays;
-    total.batches += st.batches; total.bounce_rounds += st.bounce_rounds;
-    total.trace_closest_ms += st.trace_closest_ms; total.trace_shadow_ms += st.trace_shadow_ms;
-    total.shade_ms += st.shade_ms; total.reconstruct_ms += st.reconstruct_ms; total.total_ms += st.total_ms;
-    total.closest_launches += st.closest_launches;
-    total.path_ms += st.path_ms; total.path_launches += st.path_launches;
+    // whole batches now (the slots keep running while the next chunk is generated); the remainder joins the next chunk
+    const size_t full = p1 == pass_end ? chunk.size() : chunk.size() / run.batch * run.batch;
+    rc = run_submit(ctx, run, chunk.data(), full);
+    chunk.erase(chunk.begin(), chunk.begin() + (std::ptrdiff_t)full);
   }
-  if (stats) *stats = total;
-  return rc;
+  return run_end(ctx, run, rc);
 }
 
 // RCCL through dlopen: the library itself has no link-time dependency on librccl (and a process that already
