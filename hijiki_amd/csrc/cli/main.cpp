@@ -107,8 +107,9 @@ int main(int argc, char** argv) {
 
     std::vector<float> rgb((size_t)opt.width * opt.height * 3);
     check(ctx, hj_framebuffer_resolve(ctx, rgb.data()), "read-back");  // Renderer::save_image, src/main.rs:1493
-    const bool pfm = opt.output_image.size() > 4 && opt.output_image.substr(opt.output_image.size() - 4) == ".pfm";
-    if (pfm) hijiki::write_pfm(opt.output_image, opt.width, opt.height, rgb.data());
+    const std::string ext = opt.output_image.size() > 4 ? opt.output_image.substr(opt.output_image.size() - 4) : "";
+    if (ext == ".pfm") hijiki::write_pfm(opt.output_image, opt.width, opt.height, rgb.data());
+    else if (ext == ".png") hijiki::write_png(opt.output_image, opt.width, opt.height, rgb.data());   // the preview image
     else hijiki::write_exr(opt.output_image, opt.width, opt.height, rgb.data());
     hj_context_destroy(ctx);
     return 0;

@@ -245,6 +245,14 @@ int hjh_write_exr(const char* path, uint32_t w, uint32_t h, const float* rgb) {
   });
 }
 
+int hjh_write_png(const char* path, uint32_t w, uint32_t h, const float* rgb) {
+  if (!path || !rgb || !w || !h) return fail(HJ_ERR_INVALID, "bad argument");
+  return guarded([&] {
+    write_png(path, w, h, rgb);
+    return (int)HJ_OK;
+  });
+}
+
 int hjh_write_pfm(const char* path, uint32_t w, uint32_t h, const float* rgb) {
   if (!path || !rgb || !w || !h) return fail(HJ_ERR_INVALID, "bad argument");
   return guarded([&] {

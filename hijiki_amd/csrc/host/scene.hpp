@@ -88,5 +88,7 @@ void put_cbox_spheres(Scene& scene);
 // Image output (src/main.rs:1395-1419): rgb = W*H*3 floats, row 0 on top.
 void write_pfm(const std::string& path, uint32_t w, uint32_t h, const float* rgb);
 void write_exr(const std::string& path, uint32_t w, uint32_t h, const float* rgb);
+// 8-bit sRGB PNG of the same image: what the reference's preview window shows (shader/preview.glsl:9-12).
+void write_png(const std::string& path, uint32_t w, uint32_t h, const float* rgb);
 
 }  // namespace hijiki

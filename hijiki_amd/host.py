@@ -60,6 +60,7 @@ def lib():
         L.hjh_scene_put_cbox_spheres.argtypes = [vp]
         L.hjh_write_exr.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, f3]
         L.hjh_write_pfm.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, f3]
+        L.hjh_write_png.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, f3]
         L.hjh_scene_make_synthetic.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(vp)]
         L.hj_block_seed.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         L.hj_block_seed.restype = C.c_uint32
@@ -248,10 +249,12 @@ class CompiledScene:
 
 
 def write_image(path, rgb):
-    """`Renderer::save_image` tail (src/main.rs:1402-1419): (H, W, 3) float32 -> .exr (3 x FLOAT) or .pfm."""
+    """`Renderer::save_image` tail (src/main.rs:1402-1419): (H, W, 3) float32 -> .exr (3 x FLOAT), .pfm, or .png
+    (8-bit sRGB, the preview window's image)."""
     rgb = np.ascontiguousarray(rgb, np.float32)
     h, w = rgb.shape[:2]
-    fn = lib().hjh_write_pfm if str(path).lower().endswith(".pfm") else lib().hjh_write_exr
+    ext = str(path).lower().rsplit(".", 1)[-1]
+    fn = {"pfm": lib().hjh_write_pfm, "png": lib().hjh_write_png}.get(ext, lib().hjh_write_exr)
     _check(fn(os.fsencode(path), w, h, rgb.ctypes.data_as(C.POINTER(C.c_float))))
 
 

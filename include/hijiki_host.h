@@ -91,6 +91,8 @@ int hjh_scene_put_cbox_spheres(hjh_scene* s);
  * R,G,B, scan-line, uncompressed.  PFM: little-endian "PF". */
 int hjh_write_exr(const char* path, uint32_t width, uint32_t height, const float* rgb);
 int hjh_write_pfm(const char* path, uint32_t width, uint32_t height, const float* rgb);
+/* 8-bit sRGB PNG (stored deflate): the image the reference's preview window shows (shader/preview.glsl:9-12). */
+int hjh_write_png(const char* path, uint32_t width, uint32_t height, const float* rgb);
 
 /* --- Synthetic scenes (bench inputs) ---------- */
 enum hjh_synth_kind {

@@ -187,6 +187,35 @@ def test_exr_and_pfm_round_trip(tmp_path):
     assert (back.view(np.uint32) == rgb.view(np.uint32)).all()
 
 
+def test_png_preview_image(tmp_path):
+    """8-bit sRGB PNG (what the reference's preview window shows): decoded with zlib here, checked against the sRGB
+    transfer function, every chunk CRC verified; a frame larger than one stored deflate block."""
+    import struct
+    import zlib
+    h, w = 90, 300                                     # 81 KB of scan lines: two stored blocks
+    rgb = np.random.default_rng(4).random((h, w, 3)).astype(np.float32) * 1.2
+    rgb[0, 0] = (np.nan, -1.0, 7.0)
+    host.write_image(tmp_path / "a.png", rgb)
+    raw = open(tmp_path / "a.png", "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        data = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + data)
+        chunks.append((typ, data))
+        pos += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"sRGB", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (w, h, 8, 2, 0, 0, 0)
+    lines = np.frombuffer(zlib.decompress(chunks[2][1]), np.uint8).reshape(h, 1 + 3 * w)
+    assert (lines[:, 0] == 0).all()
+    got = lines[:, 1:].reshape(h, w, 3).astype(np.int32)
+    v = np.clip(np.nan_to_num(rgb.astype(np.float64), nan=0.0), 0.0, 1.0)
+    want = np.where(v <= 0.0031308, 12.92 * v, 1.055 * v ** (1 / 2.4) - 0.055) * 255
+    assert np.abs(got - want).max() <= 0.51
+    assert tuple(got[0, 0]) == (0, 0, 255)
+
+
 def test_cli_usage_and_flags():
     exe = os.path.join(ROOT, "hijiki_amd", "bin", "hijiki-hip")
     if not os.path.exists(exe):
