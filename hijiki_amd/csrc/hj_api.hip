@@ -220,7 +220,6 @@ int ensure_batch(hj_context* ctx, hj_context::BatchSlot& sl, uint32_t num_blocks
   HJ_ALLOC(hit, float4, n)
   HJ_ALLOC(thr, float4, n)
   HJ_ALLOC(ext, float4, n)
-  HJ_ALLOC(rng, uint32_t, n)
   HJ_ALLOC(smp_rgb, float4, n)
   HJ_ALLOC(smp_nd, float4, n)
   HJ_ALLOC(sh_d, float4, n)

@@ -62,11 +62,10 @@ struct DeviceScene {
 struct BatchState {
   // per path slot (slot = block_in_batch * 16384 + ly * 128 + lx)
   float4* ray_o;      // origin.xyz
-  float4* ray_d;      // direction.xyz
+  float4* ray_d;      // direction.xyz, RNG state bits
   float4* hit;        // (t, objectID bits, u, v) of the raw hit
   float4* thr;        // throughput.rgb, flags bits (bit0 wasDiscrete)
   float4* ext;        // current extinction (only touched if scene.has_extinction)
-  uint32_t* rng;
   float4* smp_rgb;    // layer 0 of the intermediate image: (radiance, 1)
   float4* smp_nd;     // layer 1: (first-hit normal, first-hit t)
   float4* sh_d;       // shadow ray direction.xyz, tMax

@@ -450,10 +450,9 @@ HJ_DEV void stage_gen_camera(const BatchState& st, const DeviceScene& sc, uint32
       const v3 rot = V((c2.x + txyz.x * qw) + cq.x * tw, (c2.y + txyz.y * qw) + cq.y * tw, (c2.z + txyz.z * qw) + cq.z * tw);
       const v3 d = normalize3(rot);
       stp(st.ray_o, slot, make_float4(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2], 0.f));
-      stp(st.ray_d, slot, make_float4(d.x, d.y, d.z, 0.f));
+      stp(st.ray_d, slot, make_float4(d.x, d.y, d.z, __uint_as_float(rng)));   // the RNG state rides in direction.w
       stp(st.thr, slot, make_float4(1.f, 1.f, 1.f, __uint_as_float(1u)));   // wasDiscrete = true
       if (sc.has_extinction) stp(st.ext, slot, make_float4(0.f, 0.f, 0.f, 0.f));
-      st.rng[slot] = rng;
       stp(st.smp_rgb, slot, make_float4(0.f, 0.f, 0.f, 1.f));
       stp(st.smp_nd, slot, make_float4(0.f, 0.f, 0.f, 0.f));
     }
@@ -655,7 +654,7 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
       const v3 ro = xyz(ro4), rd = xyz(rd4);
       v3 T = xyz(th4);
       const bool was_discrete = (__float_as_uint(th4.w) & 1u) != 0u;
-      uint32_t rng = st.rng[slot];
+      uint32_t rng = __float_as_uint(rd4.w);
       const uint32_t id = (uint32_t)__float_as_int(hr.y);
       Its its;
       its.p = V(fmaf(hr.x, rd.x, ro.x), fmaf(hr.x, rd.y, ro.y), fmaf(hr.x, rd.z, ro.z));   // scene.glsl:164
@@ -744,9 +743,8 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
           else T = divs(T, qq);
         }
         if (bounce + 1u >= max_bounces) alive = false;                                     // render.glsl:92
-        stp(st.ray_d, slot, make_float4(wo.x, wo.y, wo.z, 0.f));
+        stp(st.ray_d, slot, make_float4(wo.x, wo.y, wo.z, __uint_as_float(rng)));
         stp(st.thr, slot, make_float4(T.x, T.y, T.z, __uint_as_float(discrete ? 1u : 0u)));
-        st.rng[slot] = rng;
         if (sc.has_extinction) stp(st.ext, slot, make_float4(ext.x, ext.y, ext.z, 0.f));
       }
       stp(st.ray_o, slot, make_float4(its.p.x, its.p.y, its.p.z, 0.f));   // next origin == shadow-ray origin
