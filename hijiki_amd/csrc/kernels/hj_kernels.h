@@ -462,7 +462,7 @@ HJ_DEV void stage_gen_camera(const BatchState& st, const DeviceScene& sc, uint32
 }
 
 HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uint32_t g, const uint32_t* __restrict__ q,
-                                uint32_t n, WgShared& sh);
+                                uint32_t n, WgShared& sh, uint32_t waves);
 
 // Closest-hit walk over this workgroup's n rays of q_ray[parity]; hits binned by material tag.
 // Needs sh.head == 0, sh.cnt_hit[] == 0 and the hot nodes loaded (synced); leaves the tag counts in sh.cnt_hit.
@@ -500,19 +500,20 @@ HJ_DEV void stage_trace_closest(const BatchState& st, const DeviceScene& sc, uin
       finish(valid, slot, h, false);
     }
   }
-  compact_hits_by_tag(st, sc, g, q, n, sh);
+  compact_hits_by_tag(st, sc, g, q, n, sh, blockDim.x >> 6);
 }
 
 // Ordered compaction of the hits of this workgroup's n closest-hit rays (queue q) by material tag.
 // Starts with a barrier (all hit records written); needs sh.cnt_hit[] == 0; leaves the tag counts there.
+// `waves` = waves of the workgroup that take part (the fused kernel drops to one wave for small rounds).
 HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uint32_t g, const uint32_t* __restrict__ q,
-                                uint32_t n, WgShared& sh) {
+                                uint32_t n, WgShared& sh, uint32_t waves) {
   const uint32_t G = st.num_wg;
   const uint32_t lane = threadIdx.x & 63u;
   // Ordered compaction by material tag (divergent-BSDF sort): every wave takes a contiguous range of queue rows,
   // counts its hits per tag, then (after a prefix over the waves) writes them at their final positions.
   __syncthreads();
-  const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const uint32_t wave = threadIdx.x >> 6;
   const uint32_t rows = (n + 63u) >> 6, rpw = (rows + waves - 1u) / waves;
   const uint32_t r0 = wave * rpw < rows ? wave * rpw : rows, r1 = r0 + rpw < rows ? r0 + rpw : rows;
   auto tag_of = [&](uint32_t i, uint32_t& slot) -> uint32_t {
@@ -603,7 +604,7 @@ HJ_DEV void stage_trace_shadow(const BatchState& st, const DeviceScene& sc, uint
 // reference's order: NEE of bounce k-1 is added during this phase, emission of bounce k in the shade that follows
 // the barrier.  Needs sh.head == 0, sh.cnt_hit[] == 0 and the hot nodes loaded (synced).
 HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t n,
-                               uint32_t ns, float tmin, WgShared& sh) {
+                               uint32_t ns, float tmin, WgShared& sh, uint32_t waves) {
   const uint32_t* __restrict__ q = st.q_ray[parity] + (size_t)g * st.segcap;
   const uint32_t* __restrict__ qs = st.q_shadow + (size_t)g * st.segcap;
   auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r, bool& any) {
@@ -626,15 +627,15 @@ HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint
     }
   };
   trace_persistent<2>(sc, n + ns, &sh.head, sh.nodes, fetch, finish);
-  compact_hits_by_tag(st, sc, g, q, n, sh);
+  compact_hits_by_tag(st, sc, g, q, n, sh, waves);
 }
 
 // reference shader/scene.glsl:160-175 (populate), render.glsl:102-144, material.glsl:18-91.
 // Shades the hits counted in sh.cnt_hit[]; needs sh.n_next == sh.n_shadow == 0 (synced); leaves the counts there.
 HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t bounce,
-                        uint32_t max_bounces, uint32_t rr_start, WgShared& sh) {
+                        uint32_t max_bounces, uint32_t rr_start, WgShared& sh, uint32_t waves) {
   const uint32_t G = st.num_wg;
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t* __restrict__ q_next = st.q_ray[parity ^ 1u] + (size_t)g * st.segcap;
   uint32_t* __restrict__ q_sh = st.q_shadow + (size_t)g * st.segcap;
   // one material tag at a time: every wave shades ONE tag (no divergent BSDF switch)
@@ -807,7 +808,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(BatchState st, DeviceSc
   if (threadIdx.x == 0) { sh.n_next = 0; sh.n_shadow = 0; }
   if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = st.cnt_hit[g * kNumTags + threadIdx.x];
   __syncthreads();
-  stage_shade(st, sc, g, parity, bounce, max_bounces, rr_start, sh);
+  stage_shade(st, sc, g, parity, bounce, max_bounces, rr_start, sh, blockDim.x >> 6);
   __syncthreads();
   if (threadIdx.x == 0) {
     st.cnt_ray[parity ^ 1u][g] = sh.n_next;
@@ -821,6 +822,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(BatchState st, DeviceSc
 // its paths are dead.  Workgroups never exchange data, so there is no grid barrier, no host round trip and no
 // per-stage launch; while one workgroup shades (memory bound) its CU neighbours walk the BVH (latency bound).
 // Exit condition every wave reaches: its workgroup's ray count is zero, or max_bounces rounds are done.
+#ifndef HJ_TAIL1
+#define HJ_TAIL1 128u    // rays of a round at which the workgroup shrinks to one wave (sweep 64..256: within 1 %)
+#endif
+#ifndef HJ_TAIL2
+#define HJ_TAIL2 512u    // ... to two waves (0 = never; 512 measured +1-2 % on the mirror+glass scene)
+#endif
 #ifndef HJ_PATH_WAVES
 #define HJ_PATH_WAVES 6   // 80 VGPRs (9 spilled): measured 3-4 % faster than 5 (96 VGPRs) and than 8 (64 VGPRs, 33 spilled)
 #endif
@@ -839,14 +846,27 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
   if (USE_BVH) {
     // round k: walk {closest rays of bounce k + shadow rays of bounce k-1} together, then shade bounce k
     uint32_t ns = 0;
+    uint32_t waves = blockDim.x >> 6;
     for (uint32_t bounce = 0; (bounce < max_bounces && n != 0) || ns != 0; bounce++) {
+      // Tail of the workgroup: once one wave can hold every ray of a round (the counts never grow again), waves
+      // 1.. leave the kernel and free their registers and wave slots for the workgroups still waiting to start;
+      // wave 0 finishes the paths alone (barriers only wait for waves that have not ended).  A handful of paths
+      // bounce on for tens (diffuse) to hundreds (mirror, glass) of rounds after their neighbours are dead.
+      if (waves > 2u && n + ns <= HJ_TAIL2) {
+        if (threadIdx.x >= 128u) return;
+        waves = 2u;
+      }
+      if (waves > 1u && n + ns <= HJ_TAIL1) {
+        if (threadIdx.x >= 64u) return;
+        waves = 1u;
+      }
       const uint32_t parity = bounce & 1u;
       if (threadIdx.x == 0) { sh.head = 0; sh.n_next = 0; sh.n_shadow = 0; }
       if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
       __syncthreads();
-      stage_trace_merged(st, sc, g, parity, n, ns, bounce == 0 ? kEps : 2.0f * kEps, sh);   // render.glsl:33,132
+      stage_trace_merged(st, sc, g, parity, n, ns, bounce == 0 ? kEps : 2.0f * kEps, sh, waves);   // render.glsl:33,132
       __syncthreads();
-      if (n != 0) stage_shade(st, sc, g, parity, bounce, max_bounces, rr_start, sh);
+      if (n != 0) stage_shade(st, sc, g, parity, bounce, max_bounces, rr_start, sh, waves);
       __syncthreads();
       total_closest += n;
       total_shadow += ns;
@@ -867,7 +887,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
     __syncthreads();
     stage_trace_closest<USE_BVH>(st, sc, g, parity, n, bounce == 0 ? kEps : 2.0f * kEps, sh);   // render.glsl:33,132
     __syncthreads();
-    stage_shade(st, sc, g, parity, bounce, max_bounces, rr_start, sh);
+    stage_shade(st, sc, g, parity, bounce, max_bounces, rr_start, sh, blockDim.x >> 6);
     if (threadIdx.x == 0) sh.head = 0;       // the closest-hit walk is over (barrier above); shade does not use it
     __syncthreads();
     const uint32_t ns = sh.n_shadow;
