@@ -24,7 +24,7 @@ cli: hijiki_amd/bin/hijiki-hip
 hijiki_amd/lib/libhijiki_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p hijiki_amd/lib
 	$(CXX) -std=c++17 -O2 -g0 -fPIC -shared -Wall -Wextra $(FP_STRICT) -fvisibility=hidden \
-	  -DHJ_BUILDING -o $@ $(HOST_SRC)
+	  -DHJ_BUILDING -pthread -o $@ $(HOST_SRC)
 
 hijiki_amd/lib/libhijiki_hip.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p hijiki_amd/lib
@@ -41,7 +41,7 @@ CLI_SRC = hijiki_amd/csrc/cli/main.cpp hijiki_amd/csrc/host/scene.cpp hijiki_amd
           hijiki_amd/csrc/host/obj_loader.cpp hijiki_amd/csrc/host/image_io.cpp
 hijiki_amd/bin/hijiki-hip: $(CLI_SRC) $(HOST_HDR) hijiki_amd/lib/libhijiki_hip.so
 	@mkdir -p hijiki_amd/bin
-	$(CXX) -std=c++17 -O2 -Wall -Wextra $(FP_STRICT) -o $@ $(CLI_SRC) -Lhijiki_amd/lib -lhijiki_hip \
+	$(CXX) -std=c++17 -O2 -pthread -Wall -Wextra $(FP_STRICT) -o $@ $(CLI_SRC) -Lhijiki_amd/lib -lhijiki_hip \
 	  -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,$(ROCM)/lib -L$(ROCM)/lib -lamdhip64
 
 clean:
