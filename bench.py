@@ -157,7 +157,7 @@ def main():
         # quoted for the workload that was profiled (cbox 1024x1024, 512 spp, 1 GPU).
         traffic = traffic_bytes = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v6_pmc_hbm_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v7_pmc_hbm_traffic.json")))
             if (W, H, spp) == (1024, 1024, 512) and world == 1:
                 traffic_bytes = round(pmc["traffic_bytes_per_path_corrected"] * agg["paths"] / launches)
                 traffic = round(traffic_bytes / (avg_ms * 1e-3) / 1e9, 1)
