@@ -28,7 +28,10 @@
 
 namespace hj {
 
-constexpr int kBlockThreads = 256;
+#ifndef HJ_BLOCK_THREADS
+#define HJ_BLOCK_THREADS 256   // path workgroup size (128 and 512 measured: see DESIGN.md)
+#endif
+constexpr int kBlockThreads = HJ_BLOCK_THREADS;
 
 // ---------------------------------------------------------------- helpers
 
