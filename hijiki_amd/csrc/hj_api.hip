@@ -281,7 +281,7 @@ struct Timer {
   }
 };
 
-// Reconstruction of one slot's batch, ordered after the other slot's (framebuffer sums are defined by block order).
+// Reconstruction of one slot's batch, ordered after the previous batch's (framebuffer sums are defined by block order).
 int enqueue_reconstruct(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::BatchSlot& other, const hj::BatchState& st,
                         uint32_t nb, const hj_render_opts& o, Timer& tm) {
   hipStream_t s = sl.stream;
@@ -385,7 +385,7 @@ int finish_batch(hj_context* ctx, hj_context::BatchSlot& sl, const hj::BatchStat
   return HJ_OK;
 }
 
-// Default path: ONE persistent launch per batch (k_path_wavefront), asynchronous; the caller pipelines two slots.
+// Default path: ONE persistent launch per batch (k_path_wavefront), asynchronous; the caller keeps num_slots batches in flight.
 int enqueue_batch_fused(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::BatchSlot& other, const hj_image_block* blocks,
                         uint32_t nb, const hj_render_opts& o, Timer& tm, hj_render_stats* stats, bool reconstruct) {
   hj::BatchState st;
