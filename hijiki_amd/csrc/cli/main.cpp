@@ -20,7 +20,7 @@
 namespace {
 
 struct Opt {
-  bool put_cbox_spheres = false, use_bvh = false;
+  bool put_cbox_spheres = false, use_bvh = false, device_bvh = false;
   uint32_t width = 800, height = 600, present_interval = 128, sample_count = 64;
   uint64_t seed = 1;
   std::string output_image = "/tmp/output.exr", scene;
@@ -31,9 +31,10 @@ struct Opt {
   std::fprintf(stderr,
                "USAGE: hijiki-hip [FLAGS] [OPTIONS] <scene>\n\n"
                "FLAGS:\n    --put-cbox-spheres    Add a mirror and glass sphere to the scene\n"
-               "    --use-bvh             Use a BVH to optimize intersections\n\n"
+               "    --use-bvh             Use a BVH to optimize intersections\n"
+               "    --device-bvh          (not upstream) build the tree on the GPU (LBVH) instead of on the host (SAH)\n\n"
                "OPTIONS:\n    -h, --height <height>                        [default: 600]\n"
-               "    -o, --output-image <output-image>            [default: /tmp/output.exr] (.exr or .pfm)\n"
+               "    -o, --output-image <output-image>            [default: /tmp/output.exr] (.exr, .pfm or .png)\n"
                "        --present-interval <present-interval>    [default: 128] (ignored: no preview window)\n"
                "    -s, --sample-count <sample-count>            [default: 64]\n"
                "        --seed <seed>                            [default: 1]\n"
@@ -52,6 +53,7 @@ Opt parse(int argc, char** argv) {
     const std::string a = argv[i];
     if (a == "--put-cbox-spheres") o.put_cbox_spheres = true;
     else if (a == "--use-bvh") o.use_bvh = true;
+    else if (a == "--device-bvh") o.device_bvh = true;
     else if (a == "-w" || a == "--width") o.width = (uint32_t)std::stoul(value(i));
     else if (a == "-h" || a == "--height") o.height = (uint32_t)std::stoul(value(i));
     else if (a == "--present-interval") o.present_interval = (uint32_t)std::stoul(value(i));
@@ -86,12 +88,18 @@ int main(int argc, char** argv) {
     }
     if (opt.put_cbox_spheres) hijiki::put_cbox_spheres(scene);         // src/main.rs:1463-1483
     std::printf("Building BVH\n");                                     // src/main.rs:198
-    const hijiki::CompiledScene cs = hijiki::compile(scene);           // src/main.rs:1486
+    hijiki::CompiledScene cs = hijiki::compile(scene);                 // src/main.rs:1486
+    hj_context* ctx = nullptr;
+    if (hj_context_create(0, &ctx) != HJ_OK) throw std::runtime_error(hj_last_error(nullptr));
+    if (opt.device_bvh) {                                              // same shapes, tree from hj_build_bvh_device
+      const hj_scene_desc shapes = cs.desc();
+      std::vector<hj_bvh_node> nodes(cs.bvh.size());
+      check(ctx, hj_build_bvh_device(ctx, &shapes, nodes.data(), nodes.size(), nullptr), "device BVH build");
+      cs.bvh.swap(nodes);
+    }
     std::printf("Built BVH with %zu nodes\n", cs.bvh.size());          // src/main.rs:200
     const hj_scene_desc desc = cs.desc();
 
-    hj_context* ctx = nullptr;
-    if (hj_context_create(0, &ctx) != HJ_OK) throw std::runtime_error(hj_last_error(nullptr));
     check(ctx, hj_scene_upload(ctx, &desc), "scene upload");
     check(ctx, hj_framebuffer_create(ctx, opt.width, opt.height, nullptr), "framebuffer");
     hj_render_opts ro;

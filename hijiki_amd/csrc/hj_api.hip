@@ -22,6 +22,9 @@
 #include "../../include/hijiki_hip.h"
 #include "host/blockgen.hpp"
 #include "kernels/hj_kernels.h"
+#include "kernels/hj_lbvh.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #pragma clang fp contract(off)
 
@@ -1029,6 +1032,92 @@ int hj_reduce_framebuffers(hj_context* const* ctxs, int n, int root) {
     if (c) (void)g_rccl.CommDestroy(c);
   if (nrc != 0) return set_error(r, HJ_ERR_DEVICE, "ncclReduce: %s", g_rccl.GetErrorString(nrc));
   if (rc != HJ_OK) return set_error(r, rc, "stream synchronisation after the reduce failed");
+  return HJ_OK;
+}
+
+// the tree of Scene::compile (src/main.rs:199-231), built on the device (kernels/hj_lbvh.h).
+int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* out_nodes, size_t capacity, size_t* out_num_nodes) {
+  if (!ctx) return HJ_ERR_INVALID;
+  if (!s || !out_nodes) return set_error(ctx, HJ_ERR_INVALID, "null argument");
+  const size_t n = s->num_spheres + s->num_quads + s->num_triangles;
+  if (n < 2) return set_error(ctx, HJ_ERR_INVALID, "scene needs at least 2 shapes (reference panics: root would be a leaf, src/main.rs:230)");
+  if (n >= hj::kInnerFlag / 4) return set_error(ctx, HJ_ERR_INVALID, "scene too large");
+  const size_t total = 2 * n - 1;
+  if (capacity < total) return set_error(ctx, HJ_ERR_INVALID, "node buffer holds %zu records, the tree has %zu", capacity, total);
+  if ((s->num_spheres && !s->spheres) || (s->num_quads && !s->quads) || (s->num_triangles && (!s->triangles || !s->vertices)))
+    return set_error(ctx, HJ_ERR_INVALID, "null shape array");
+  for (size_t i = 0; i < s->num_triangles; i++)
+    for (int k = 0; k < 3; k++)
+      if (s->triangles[i].v[k] >= s->num_vertices) return set_error(ctx, HJ_ERR_INVALID, "triangle %zu refers to unknown vertex", i);
+  HJ_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<DevBuf> bufs;
+  struct Release { std::vector<DevBuf>& b; ~Release() { for (auto& x : b) x.release(); } } release{bufs};
+  bufs.reserve(32);
+  auto dev = [&](size_t bytes, void** p) -> int {
+    bufs.emplace_back();
+    const int rc = dev_alloc(ctx, bufs.back(), std::max<size_t>(bytes, 16));
+    *p = bufs.back().p;
+    return rc;
+  };
+  int rc = HJ_OK;
+#define HJ_DEVBUF(ptr, type, count) do { void* p_ = nullptr; rc = dev(sizeof(type) * (count), &p_); if (rc != HJ_OK) return rc; ptr = static_cast<type*>(p_); } while (0)
+  hipStream_t st = ctx->stream;
+  hj::lbvh::Shapes sh{};
+  {
+    float4* sp = nullptr; float4* qd = nullptr; hj_triangle* tr = nullptr; hj_vertex* vx = nullptr;
+    HJ_DEVBUF(sp, float4, s->num_spheres);
+    HJ_DEVBUF(qd, float4, 3 * s->num_quads);
+    HJ_DEVBUF(tr, hj_triangle, s->num_triangles);
+    HJ_DEVBUF(vx, hj_vertex, s->num_vertices);
+    if (s->num_spheres) HJ_HIP(ctx, hipMemcpyAsync(sp, s->spheres, sizeof(float4) * s->num_spheres, hipMemcpyHostToDevice, st));
+    if (s->num_quads) HJ_HIP(ctx, hipMemcpyAsync(qd, s->quads, sizeof(float4) * 3 * s->num_quads, hipMemcpyHostToDevice, st));
+    if (s->num_triangles) HJ_HIP(ctx, hipMemcpyAsync(tr, s->triangles, sizeof(hj_triangle) * s->num_triangles, hipMemcpyHostToDevice, st));
+    if (s->num_vertices) HJ_HIP(ctx, hipMemcpyAsync(vx, s->vertices, sizeof(hj_vertex) * s->num_vertices, hipMemcpyHostToDevice, st));
+    sh.spheres = sp; sh.quads = qd; sh.triangles = tr; sh.vertices = vx;
+    sh.ns = (uint32_t)s->num_spheres; sh.nq = (uint32_t)s->num_quads; sh.nt = (uint32_t)s->num_triangles;
+  }
+  hj::lbvh::Tree t{};
+  unsigned long long* keys_in = nullptr;
+  hj_bvh_node* d_out = nullptr;
+  HJ_DEVBUF(t.leaf_lo, float4, n);
+  HJ_DEVBUF(t.leaf_hi, float4, n);
+  HJ_DEVBUF(t.bounds, int, 6);
+  HJ_DEVBUF(keys_in, unsigned long long, n);
+  HJ_DEVBUF(t.keys, unsigned long long, n);
+  HJ_DEVBUF(t.child, uint32_t, 2 * (n - 1));
+  HJ_DEVBUF(t.first, uint32_t, n - 1);
+  HJ_DEVBUF(t.count, uint32_t, n - 1);
+  HJ_DEVBUF(t.parent, uint32_t, total);
+  HJ_DEVBUF(t.node_lo, float4, n - 1);
+  HJ_DEVBUF(t.node_hi, float4, n - 1);
+  HJ_DEVBUF(t.arrived, uint32_t, n - 1);
+  HJ_DEVBUF(d_out, hj_bvh_node, total);
+  const uint32_t N = (uint32_t)n;
+  const dim3 blk(256), grid_n((N + 255u) / 256u), grid_total(((uint32_t)total + 255u) / 256u);
+  hipLaunchKernelGGL(hj::lbvh::k_init_bounds, dim3(1), dim3(64), 0, st, t.bounds);
+  hipLaunchKernelGGL(hj::lbvh::k_shape_boxes, grid_n, blk, 0, st, sh, t, N);
+  {
+    hj::lbvh::Tree unsorted = t;
+    unsorted.keys = keys_in;
+    hipLaunchKernelGGL(hj::lbvh::k_morton_keys, grid_n, blk, 0, st, unsorted, N);
+  }
+  {
+    size_t tmp_bytes = 0;
+    HJ_HIP(ctx, rocprim::radix_sort_keys(nullptr, tmp_bytes, keys_in, t.keys, n, 0, 62, st));
+    void* tmp = nullptr;
+    HJ_DEVBUF(tmp, char, tmp_bytes);
+    HJ_HIP(ctx, rocprim::radix_sort_keys(tmp, tmp_bytes, keys_in, t.keys, n, 0, 62, st));
+  }
+  hipLaunchKernelGGL(hj::lbvh::k_hierarchy, grid_n, blk, 0, st, t, N);
+  hipLaunchKernelGGL(hj::lbvh::k_refit, grid_n, blk, 0, st, t, N);
+  // src/main.rs:231 hard-codes 1 000 000 for the root's exit; larger trees get the node count (see host/scene.cpp)
+  const uint32_t root_exit = total > HJ_BVH_ROOT_EXIT ? (uint32_t)total : HJ_BVH_ROOT_EXIT;
+  hipLaunchKernelGGL(hj::lbvh::k_emit, grid_total, blk, 0, st, t, N, root_exit, d_out);
+  HJ_HIP(ctx, hipGetLastError());
+  HJ_HIP(ctx, hipMemcpyAsync(out_nodes, d_out, sizeof(hj_bvh_node) * total, hipMemcpyDeviceToHost, st));
+  HJ_HIP(ctx, hipStreamSynchronize(st));
+#undef HJ_DEVBUF
+  if (out_num_nodes) *out_num_nodes = total;
   return HJ_OK;
 }
 

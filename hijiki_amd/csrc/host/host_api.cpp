@@ -174,6 +174,14 @@ int hjh_compiled_desc(const hjh_compiled* c, hj_scene_desc* out) {
   *out = c->cs.desc();
   return HJ_OK;
 }
+int hjh_compiled_set_bvh(hjh_compiled* c, const hj_bvh_node* nodes, size_t n) {
+  if (!c || !nodes) return fail(HJ_ERR_INVALID, "null argument");
+  if (n != c->cs.bvh.size()) return fail(HJ_ERR_INVALID, "a tree over these shapes has " + std::to_string(c->cs.bvh.size()) + " nodes");
+  return guarded([&] {
+    c->cs.bvh.assign(nodes, nodes + n);
+    return (int)HJ_OK;
+  });
+}
 size_t hjh_compiled_packed_size(const hjh_compiled* c) { return c ? c->cs.packed_size() : 0; }
 int hjh_compiled_pack(const hjh_compiled* c, void* buffer, size_t size) {
   if (!c || !buffer) return fail(HJ_ERR_INVALID, "null argument");

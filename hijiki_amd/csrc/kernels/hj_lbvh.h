@@ -1,0 +1,235 @@
+// Device-side BVH build: a Morton-code LBVH in the reference's node format.
+//
+// The reference builds its tree on the host with the `bvh` crate and flattens it depth-first with skip links
+// (src/main.rs:199-231): one shape per leaf, pre-order numbering (left child = next record), every node stores
+// the box its PARENT kept for it (= the bounds of its own subtree), exit = the record that follows its subtree
+// (the root and every node on the right spine: 1 000 000).  This file produces the same FORMAT for a different
+// topology: shapes sorted along a 30-bit Morton curve of their centroids, hierarchy by longest common prefix
+// (Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees and k-d trees"), bounds by a
+// bottom-up pass.  The image does not depend on the topology except through epsilon-ties; the
+// quality of an LBVH is below the host's binned SAH, so this is the fast start-up path, not the default.
+//
+// Pre-order without a traversal: a subtree over k leaves has 2k - 1 records, so for a node whose subtree covers
+// the sorted leaves [first, first + k)
+//     position = 2 * first + (number of LEFT turns on the way from the root to the node)
+//     exit     = position + 2k - 1
+// (the leaves to the left of the node fill 2 * first records minus one per subtree they form, and there is one
+// such subtree per RIGHT turn; the node's proper ancestors add one record each).
+#pragma once
+#include "hj_device.h"
+
+namespace hj {
+namespace lbvh {
+
+constexpr uint32_t kLeafBit = 0x80000000u;   // child reference: leaf (sorted position) or internal node index
+constexpr uint32_t kNoParent = 0xFFFFFFFFu;
+
+struct Shapes {               // the shape arrays of an hj_scene_desc, on the device
+  const float4* spheres;      // hj_sphere
+  const float4* quads;        // hj_quad as 3 x float4
+  const hj_triangle* triangles;
+  const hj_vertex* vertices;
+  uint32_t ns, nq, nt;
+};
+
+struct Tree {                 // working arrays, n = number of shapes
+  float4* leaf_lo;            // [n] bounds of shape i (global shape index), w unused
+  float4* leaf_hi;
+  int* bounds;                // [6] scene bounds of the CENTROIDS as order-preserving ints (min xyz, max xyz)
+  unsigned long long* keys;   // [n] (morton << 32) | shape index
+  uint32_t* child;            // [2 * (n - 1)] left, right of internal node i
+  uint32_t* first;            // [n - 1] first sorted leaf of internal node i
+  uint32_t* count;            // [n - 1] leaves below internal node i
+  uint32_t* parent;           // [2n - 1] parent of internal node i (index i) / of sorted leaf k (index n - 1 + k);
+                              //          bit 31 set when the node is the LEFT child
+  float4* node_lo;            // [n - 1] bounds of internal node i
+  float4* node_hi;
+  uint32_t* arrived;          // [n - 1] refit counters
+};
+
+// float <-> int that keeps the order (for atomicMin / atomicMax on floats)
+HJ_DEV int ordered(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+HJ_DEV float unordered(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+__global__ void k_init_bounds(int* bounds) {
+  if (threadIdx.x < 3) bounds[threadIdx.x] = 0x7FFFFFFF;
+  else if (threadIdx.x < 6) bounds[threadIdx.x] = (int)0x80000000;
+}
+
+// Shape bounds as the host computes them (src/shape.rs:13-20,46-54, src/main.rs:74-79) + bounds of the centroids.
+__global__ __launch_bounds__(256) void k_shape_boxes(Shapes s, Tree t, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  const bool valid = i < n;
+  if (valid) {
+    if (i < s.ns) {
+      const float4 sp = s.spheres[i];
+      const float c[3] = {sp.x, sp.y, sp.z};
+      for (int k = 0; k < 3; k++) { lo[k] = c[k] - sp.w; hi[k] = c[k] + sp.w; }
+      for (int k = 0; k < 3; k++) { const float a = f_min(lo[k], hi[k]), b = f_max(lo[k], hi[k]); lo[k] = a; hi[k] = b; }
+    } else if (i < s.ns + s.nq) {
+      const uint32_t q = i - s.ns;
+      const float4 o = s.quads[3 * q], e1 = s.quads[3 * q + 1], e2 = s.quads[3 * q + 2];
+      const float O[3] = {o.x, o.y, o.z}, A[3] = {e1.x, e1.y, e1.z}, B[3] = {e2.x, e2.y, e2.z};
+      for (int k = 0; k < 3; k++) {
+        const float p1 = O[k] + A[k], p2 = O[k] + B[k], p3 = (O[k] + A[k]) + B[k];
+        lo[k] = f_min(f_min(O[k], p1), f_min(p2, p3));
+        hi[k] = f_max(f_max(O[k], p1), f_max(p2, p3));
+      }
+    } else {
+      const hj_triangle tr = s.triangles[i - s.ns - s.nq];
+      const hj_vertex a = s.vertices[tr.v[0]], b = s.vertices[tr.v[1]], c = s.vertices[tr.v[2]];
+      for (int k = 0; k < 3; k++) {
+        lo[k] = f_min(f_min(a.pos[k], b.pos[k]), c.pos[k]);
+        hi[k] = f_max(f_max(a.pos[k], b.pos[k]), c.pos[k]);
+      }
+    }
+    t.leaf_lo[i] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    t.leaf_hi[i] = make_float4(hi[0], hi[1], hi[2], 0.f);
+  }
+  // centroid bounds: wave reduction, then one atomic pair per wave and axis
+  for (int k = 0; k < 3; k++) {
+    const float c = 0.5f * (lo[k] + hi[k]);
+    const bool ok = valid && c == c;                       // NaN centroids do not take part
+    int mn = ok ? ordered(c) : 0x7FFFFFFF, mx = ok ? ordered(c) : (int)0x80000000;
+    for (int o = 32; o > 0; o >>= 1) {
+      const int a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+      mn = a < mn ? a : mn;
+      mx = b > mx ? b : mx;
+    }
+    if ((threadIdx.x & 63u) == 0) {
+      atomicMin(&t.bounds[k], mn);
+      atomicMax(&t.bounds[3 + k], mx);
+    }
+  }
+}
+
+HJ_DEV uint32_t spread10(uint32_t v) {   // 10 bits -> every third bit
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_morton_keys(Tree t, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 lo = t.leaf_lo[i], hi = t.leaf_hi[i];
+  const float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+  uint32_t q[3];
+  for (int k = 0; k < 3; k++) {
+    const float mn = unordered(t.bounds[k]), mx = unordered(t.bounds[3 + k]);
+    const float e = mx - mn;
+    float u = e > 0.f ? (c[k] - mn) / e : 0.f;
+    u = u == u ? f_min(f_max(u, 0.f), 1.f) : 0.f;
+    q[k] = (uint32_t)f_min(u * 1024.0f, 1023.0f);
+  }
+  const uint32_t code = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
+  t.keys[i] = ((unsigned long long)code << 32) | i;        // the index makes every key unique
+}
+
+// Karras 2012, section 4: internal node i of the radix tree over the sorted (unique) keys.
+__global__ __launch_bounds__(256) void k_hierarchy(Tree t, uint32_t n) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int last_internal = (int)n - 2;
+  if (i > last_internal) return;
+  const unsigned long long* __restrict__ key = t.keys;
+  auto delta = [&](int a, int b) -> int { return (b < 0 || b >= (int)n) ? -1 : __clzll((long long)(key[a] ^ key[b])); };
+  const int d = delta(i, i + 1) - delta(i, i - 1) >= 0 ? 1 : -1;
+  const int dmin = delta(i, i - d);
+  int lmax = 2;
+  while (delta(i, i + lmax * d) > dmin) lmax *= 2;
+  int l = 0;
+  for (int s = lmax / 2; s >= 1; s /= 2)
+    if (delta(i, i + (l + s) * d) > dmin) l += s;
+  const int j = i + l * d;
+  const int dnode = delta(i, j);
+  int sp = 0;
+  for (int div = 2;; div *= 2) {                          // steps ceil(l/2), ceil(l/4), ... 1
+    const int s = (l + div - 1) / div;
+    if (delta(i, i + (sp + s) * d) > dnode) sp += s;
+    if (s <= 1) break;
+  }
+  const int gamma = i + sp * d + (d < 0 ? -1 : 0);
+  const int lo = i < j ? i : j, hi = i < j ? j : i;
+  const uint32_t left = lo == gamma ? (kLeafBit | (uint32_t)gamma) : (uint32_t)gamma;
+  const uint32_t right = hi == gamma + 1 ? (kLeafBit | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
+  t.child[2 * i] = left;
+  t.child[2 * i + 1] = right;
+  t.first[i] = (uint32_t)lo;
+  t.count[i] = (uint32_t)(hi - lo + 1);
+  t.parent[(left & kLeafBit) ? (n - 1) + (left & ~kLeafBit) : left] = (uint32_t)i | kLeafBit;   // bit 31: "I am the left child"
+  t.parent[(right & kLeafBit) ? (n - 1) + (right & ~kLeafBit) : right] = (uint32_t)i;
+  if (i == 0) t.parent[0] = kNoParent;
+  t.arrived[i] = 0;
+}
+
+// A float4 written earlier in the same launch by a thread of another CU: the vector L1 is not coherent between CUs
+// (a neighbouring record of the same line may sit there from before the write), so read at agent scope.
+HJ_DEV float4 ld_agent(const float4* p) {
+  const float* f = reinterpret_cast<const float*>(p);
+  return make_float4(__hip_atomic_load(f + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                     __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                     __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0.f);
+}
+
+// Bounds bottom-up: the second thread to arrive at a node owns it (no waiting: the first one simply leaves).
+__global__ __launch_bounds__(256) void k_refit(Tree t, uint32_t n) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  uint32_t p = t.parent[(n - 1) + k];
+  while (p != kNoParent) {
+    const uint32_t node = p & ~kLeafBit;
+    __threadfence();                                         // my child's bounds are visible before I count myself in
+    if (atomicAdd(&t.arrived[node], 1u) == 0u) return;
+    __threadfence();
+    float4 lo[2], hi[2];
+    for (int c = 0; c < 2; c++) {
+      const uint32_t ch = t.child[2 * node + c];
+      if (ch & kLeafBit) {
+        const uint32_t shape = (uint32_t)(t.keys[ch & ~kLeafBit] & 0xFFFFFFFFull);
+        lo[c] = t.leaf_lo[shape];
+        hi[c] = t.leaf_hi[shape];
+      } else {
+        lo[c] = ld_agent(&t.node_lo[ch]);                      // written by another CU in THIS launch: not through the L1
+        hi[c] = ld_agent(&t.node_hi[ch]);
+      }
+    }
+    t.node_lo[node] = make_float4(f_min(lo[0].x, lo[1].x), f_min(lo[0].y, lo[1].y), f_min(lo[0].z, lo[1].z), 0.f);
+    t.node_hi[node] = make_float4(f_max(hi[0].x, hi[1].x), f_max(hi[0].y, hi[1].y), f_max(hi[0].z, hi[1].z), 0.f);
+    p = t.parent[node];
+  }
+}
+
+// One record of the reference's flattened array per tree node (internal nodes: threads [0, n-1), leaves: the rest).
+__global__ __launch_bounds__(256) void k_emit(Tree t, uint32_t n, uint32_t root_exit, hj_bvh_node* out) {
+  const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t total = 2 * n - 1;
+  if (id >= total) return;
+  const bool leaf = id >= n - 1;
+  const uint32_t k = leaf ? id - (n - 1) : 0;
+  const uint32_t first = leaf ? k : t.first[id], cnt = leaf ? 1u : t.count[id];
+  uint32_t left_turns = 0;
+  for (uint32_t p = t.parent[id]; p != kNoParent; p = t.parent[p & ~kLeafBit]) left_turns += p >> 31;
+  const uint32_t pos = 2 * first + left_turns, end = pos + 2 * cnt - 1;
+  float4 lo, hi;
+  uint32_t shape = HJ_BVH_INNER;
+  if (leaf) {
+    shape = (uint32_t)(t.keys[k] & 0xFFFFFFFFull);
+    lo = t.leaf_lo[shape];
+    hi = t.leaf_hi[shape];
+  } else {
+    lo = t.node_lo[id];
+    hi = t.node_hi[id];
+  }
+  hj_bvh_node nd;
+  nd.aabb_min[0] = lo.x; nd.aabb_min[1] = lo.y; nd.aabb_min[2] = lo.z;
+  nd.shape_index = shape;
+  nd.aabb_max[0] = hi.x; nd.aabb_max[1] = hi.y; nd.aabb_max[2] = hi.z;
+  nd.exit_index = end >= total ? root_exit : end;           // right spine: the root's exit (src/main.rs:214-231)
+  out[pos] = nd;
+}
+
+}  // namespace lbvh
+}  // namespace hj

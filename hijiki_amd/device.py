@@ -19,7 +19,8 @@ _LIB = None
 EXPORTS = ("hj_context_create", "hj_context_destroy", "hj_last_error", "hj_version", "hj_default_render_opts",
            "hj_scene_upload", "hj_framebuffer_create", "hj_framebuffer_clear", "hj_framebuffer_device_ptr",
            "hj_framebuffer_read", "hj_framebuffer_resolve", "hj_render_blocks", "hj_render_frame", "hj_block_seed",
-           "hj_pass_offset", "hj_block_owner", "hj_debug_trace", "hj_debug_samples", "hj_reduce_framebuffers")
+           "hj_pass_offset", "hj_block_owner", "hj_debug_trace", "hj_debug_samples", "hj_reduce_framebuffers",
+           "hj_build_bvh_device")
 
 
 def lib():
@@ -52,6 +53,7 @@ def lib():
         L.hj_reduce_framebuffers.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
         L.hj_debug_trace.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
         L.hj_debug_samples.argtypes = [vp, C.POINTER(abi.ImageBlock), C.POINTER(abi.RenderOpts), C.POINTER(C.c_float)]
+        L.hj_build_bvh_device.argtypes = [vp, C.POINTER(abi.SceneDesc), C.POINTER(abi.BvhNode), C.c_size_t, C.POINTER(C.c_size_t)]
         L.hj_block_seed.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         L.hj_block_seed.restype = C.c_uint32
         L.hj_pass_offset.argtypes = [C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]
@@ -137,6 +139,16 @@ class Renderer:
         self._check(lib().hj_render_frame(self._h, spp, master_seed, pass_begin, pass_end, rank, world,
                                           C.byref(opts) if opts is not None else None, C.byref(st)))
         return stats_dict(st)
+
+    def build_bvh(self, compiled):
+        """LBVH over the shapes of `compiled`, built on the device (hj_build_bvh_device): (2 * shapes - 1, 8) uint32
+        records in the reference's layout.  `compiled.set_bvh(nodes)` installs it."""
+        n = 2 * compiled.num_shapes - 1
+        nodes = np.zeros((max(n, 1), 8), np.uint32)
+        got = C.c_size_t(0)
+        self._check(lib().hj_build_bvh_device(self._h, C.byref(compiled.desc), nodes.ctypes.data_as(C.POINTER(abi.BvhNode)),
+                                              len(nodes), C.byref(got)))
+        return nodes[:got.value]
 
     def trace(self, rays, use_bvh=True, any_hit=False):
         """intersectScene for (n,8) rays -> ids (n,) int32, t, u, v (n,) float32 (raw hit, before populate)."""

@@ -51,6 +51,7 @@ def lib():
         L.hjh_compiled_packed_size.argtypes = [vp]
         L.hjh_compiled_packed_size.restype = C.c_size_t
         L.hjh_compiled_pack.argtypes = [vp, vp, C.c_size_t]
+        L.hjh_compiled_set_bvh.argtypes = [vp, C.POINTER(abi.BvhNode), C.c_size_t]
         L.hjh_num_blocks_per_pass.argtypes = [C.c_uint32] * 3
         L.hjh_num_blocks_per_pass.restype = C.c_size_t
         L.hjh_make_blocks.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
@@ -239,6 +240,13 @@ class CompiledScene:
     @property
     def num_shapes(self):
         return self.desc.num_materials
+
+    def set_bvh(self, nodes):
+        """Replace the tree by `nodes` ((2 * shapes - 1, 8) uint32, the reference's record layout), e.g. the result
+        of `device.Renderer.build_bvh`."""
+        nodes = np.ascontiguousarray(nodes, np.uint32).reshape(-1, 8)
+        _check(lib().hjh_compiled_set_bvh(self._h, nodes.ctypes.data_as(C.POINTER(abi.BvhNode)), len(nodes)))
+        _check(lib().hjh_compiled_desc(self._h, C.byref(self.desc)))
 
     def packed(self):
         """The reference's packed scene buffer image (src/main.rs:561-605)."""

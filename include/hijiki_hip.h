@@ -238,6 +238,17 @@ int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed,
                     uint32_t rank, uint32_t world,
                     const hj_render_opts* opts, hj_render_stats* stats);
 
+/* ------------------------------------------------------------- BVH on device */
+
+/* The tree of `Scene::compile` (src/main.rs:199-231) built on the device instead of by the host's SAH builder
+ * (SURVEY.md 8f #2): a Morton-code LBVH over the shapes of `scene` (scene->bvh is ignored), written to
+ * out_nodes in the reference's flattened format - one shape per leaf, pre-order with skip links, every record
+ * holding the bounds of its own subtree, 2 * shapes - 1 records.  Start-up path for large meshes (1 M triangles
+ * in milliseconds); its topology is not the host builder's, which changes images only through epsilon-ties and
+ * traversal cost.  Put the result into scene->bvh before hj_scene_upload. */
+int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* scene, hj_bvh_node* out_nodes, size_t capacity,
+                        size_t* out_num_nodes /* may be NULL */);
+
 /* ---------------------------------------------------------------- multi-GPU */
 
 /* New with the multi-GPU tile sharding (no counterpart in the reference): element-wise SUM of the framebuffers of

@@ -63,6 +63,8 @@ int  hjh_scene_compile(const hjh_scene* s, hjh_compiled** out);
 void hjh_compiled_destroy(hjh_compiled* c);
 /* Borrowed view; valid while `c` lives. */
 int  hjh_compiled_desc(const hjh_compiled* c, hj_scene_desc* out);
+/* Replace the tree (e.g. by the one hj_build_bvh_device made from this scene's shapes); n must be 2 * shapes - 1. */
+int  hjh_compiled_set_bvh(hjh_compiled* c, const hj_bvh_node* nodes, size_t n);
 /* Size of the reference's packed scene buffer (12 sub-buffers padded to
  * 256 B, src/main.rs:314-339) and the packing itself (src/main.rs:561-605),
  * for tools that want the reference's exact buffer image. */

@@ -253,6 +253,93 @@ def test_uploaded_tree_with_inconsistent_boxes(gpu_renderer, oracle):
     assert_same(got, want, "shrunk inner boxes")
 
 
+def _check_skip_link_tree(nodes, boxes_of_shapes):
+    """The invariants of the reference's flattened tree (src/main.rs:203-231) on an (N, 8) uint32 array."""
+    N = len(nodes)
+    f = nodes.view(np.float32)
+    inner = nodes[:, 3] == 0xFFFFFFFF
+    shapes = nodes[~inner, 3]
+    assert N == 2 * len(shapes) - 1 and sorted(shapes.tolist()) == list(range(len(shapes)))   # every shape in ONE leaf
+    exits = nodes[:, 7].astype(np.int64)
+    assert (exits > np.arange(N)).all()                                   # the walk moves forward
+    assert exits[0] == max(1000000, N)                                    # root exit (src/main.rs:231)
+    size = np.zeros(N, np.int64)
+    for i in range(N - 1, -1, -1):                                        # pre-order: left child = next record
+        if not inner[i]:
+            size[i] = 1
+            continue
+        l = i + 1
+        r = l + size[l]
+        assert r < N and nodes[l, 7] == r                                 # exit of the left child = its sibling
+        size[i] = 1 + size[l] + size[r]
+        end = i + size[i]
+        assert nodes[r, 7] == nodes[i, 7] and (exits[i] == end if end < N else exits[i] == exits[0])
+        for c in (l, r):                                                  # a node's box = the bounds of its subtree
+            assert (f[c, 0:3] >= f[i, 0:3]).all() and (f[c, 4:7] <= f[i, 4:7]).all()
+        assert (np.minimum(f[l, 0:3], f[r, 0:3]) == f[i, 0:3]).all() and (np.maximum(f[l, 4:7], f[r, 4:7]) == f[i, 4:7]).all()
+    assert size[0] == N
+    lo, hi = boxes_of_shapes
+    leaf = np.nonzero(~inner)[0]
+    assert (f[leaf, 0:3] == lo[nodes[leaf, 3]]).all() and (f[leaf, 4:7] == hi[nodes[leaf, 3]]).all()
+
+
+def _shape_boxes(cs):
+    tri = cs.vertices[:, 0:3][cs.triangles]                               # (T, 3, 3)
+    lo = [cs.spheres[:, 0:3] - cs.spheres[:, 3:4]] if len(cs.spheres) else []
+    hi = [cs.spheres[:, 0:3] + cs.spheres[:, 3:4]] if len(cs.spheres) else []
+    if len(cs.quads):
+        o, e1, e2 = cs.quads[:, 0:3], cs.quads[:, 4:7], cs.quads[:, 8:11]
+        corners = np.stack([o, o + e1, o + e2, (o + e1) + e2], axis=1)
+        lo.append(corners.min(axis=1)); hi.append(corners.max(axis=1))
+    lo.append(tri.min(axis=1)); hi.append(tri.max(axis=1))
+    return np.concatenate(lo).astype(np.float32), np.concatenate(hi).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind", [host.SYNTH_CBOX, host.SYNTH_CBOX_SPHERES])
+def test_device_built_bvh(gpu_renderer, oracle, kind):
+    """hj_build_bvh_device: the LBVH comes back in the reference's flattened format (every invariant of
+    src/main.rs:203-231 checked on the host), renders bit-identically on GPU and oracle, and gives the image of the
+    host-built SAH tree up to epsilon-ties (the topology only decides between hits closer than 1e-4)."""
+    cs = host.Scene.synthetic(kind, mesh_triangles=1280).compile()
+    sah_nodes = cs.bvh.copy()
+    nodes = gpu_renderer.build_bvh(cs)
+    _check_skip_link_tree(nodes, _shape_boxes(cs))
+    assert (gpu_renderer.build_bvh(cs) == nodes).all()                    # deterministic
+    W, H = 128, 96
+    blocks = host.make_blocks(W, H, 4, 17)
+    ref, _, _ = oracle.render_blocks(cs, blocks, W, H)                    # SAH tree
+    cs.set_bvh(nodes)
+    assert (cs.bvh == nodes).all()
+    want, ctr, _ = oracle.render_blocks(cs, blocks, W, H)
+    got, _ = render(gpu_renderer, cs, W, H, blocks)
+    assert_same(got, want, "device-built tree")
+    rgb = lambda a: a[..., :3] / a[..., 3:4]
+    differ = (np.abs(rgb(want) - rgb(ref)) > 1e-6).any(axis=-1).mean()
+    assert differ < 0.02, differ                                          # a tie flips a whole path: rare pixels only
+    cs.set_bvh(sah_nodes)
+
+
+def test_device_built_bvh_large_and_degenerate(gpu_renderer, oracle):
+    """200 k triangles (deep Morton prefixes, many equal codes) and a scene whose shapes all share one centroid."""
+    cs = host.Scene.synthetic(host.SYNTH_CBOX_MESH, mesh_triangles=200000).compile()
+    nodes = gpu_renderer.build_bvh(cs)
+    _check_skip_link_tree(nodes, _shape_boxes(cs))
+    cs.set_bvh(nodes)
+    W = H = 128
+    blocks = host.make_blocks(W, H, 1, 3)
+    want, _, _ = oracle.render_blocks(cs, blocks, W, H)
+    got, _ = render(gpu_renderer, cs, W, H, blocks)
+    assert_same(got, want, "device-built tree, 200k mesh")
+    s = host.Scene()
+    s.set_camera_cbox()
+    m, e = s.add_diffuse((0.5, 0.5, 0.5)), s.add_emissive((5, 5, 5))
+    for r in (0.1, 0.2, 0.3, 0.4, 0.5):
+        s.add_sphere((0.0, 0.8, 0.0), r, e if r == 0.1 else m)            # concentric: identical centroids
+    cs = s.compile()
+    nodes = gpu_renderer.build_bvh(cs)
+    _check_skip_link_tree(nodes, _shape_boxes(cs))
+
+
 def test_rendering_is_deterministic_and_additive(gpu_renderer, cbox):
     """Size-independent properties at a larger size: run-to-run bitwise determinism, and passes [0,a)+[a,b)
     accumulated by two calls == one call (the framebuffer is a running sum)."""
