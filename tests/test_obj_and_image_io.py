@@ -253,3 +253,9 @@ def test_cli_renders_like_the_library(tmp_path, obj_path):
     out2 = str(tmp_path / "o2.exr")
     r = subprocess.run([exe, "-w", "128", "-h", "128", "-s", "1", "-o", out2, obj_path], capture_output=True, text=True)
     assert r.returncode == 0 and os.path.getsize(out2) > 128 * 128 * 12
+    # tree built on the GPU, preview image as PNG
+    out3 = str(tmp_path / "o3.png")
+    r = subprocess.run([exe, "--use-bvh", "--device-bvh", "-w", "96", "-h", "64", "-s", "2", "-o", out3, obj_path],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Built BVH with" in r.stdout and open(out3, "rb").read(8) == b"\x89PNG\r\n\x1a\n"
