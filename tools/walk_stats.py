@@ -4,12 +4,16 @@ os.environ.setdefault("HIJIKI_HIP_LIB", "hijiki_amd/lib/var_stats.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hijiki_amd import host, device
 kind = int(sys.argv[1]) if len(sys.argv) > 1 else host.SYNTH_CBOX
+max_bounces = int(sys.argv[2]) if len(sys.argv) > 2 else 0     # 1 = camera rays and their shadow rays only
 cs = host.Scene.synthetic(kind).compile()
 r = device.Renderer(0); r.upload_scene(cs); r.create_framebuffer(1024, 1024)
 L = device.lib()
 out = (C.c_ulonglong * 8)()
 L.hj_debug_walk_stats(out, 1)
-st = r.render_frame(16, 1)
+o = device.default_opts()
+if max_bounces:
+    o.max_bounces = max_bounces
+st = r.render_frame(16, 1, opts=o)
 L.hj_debug_walk_stats(out, 1)
 o = list(out)
 rays = st["closest_rays"] + st["shadow_rays"]
