@@ -205,6 +205,9 @@ constexpr uint32_t kRefillMin = 32;   // sweep on the fused kernel: 16 -> 1.39, 
 // [0] outer iterations [1] inner wave-steps [2] lanes in them [3] leaf phases [4] lanes in them [5] refills
 // [6] lanes refilled [7] lanes active at the start of an outer iteration
 __device__ unsigned long long g_walk_stats[8];
+// rounds of the fused kernel by size bucket b (rays of the round in [64 * 4^b / 4, 64 * 4^b), b = 0..7):
+// [b] rounds, [8 + b] rays, [16 + b] wave-cycles (wall clock of the round x waves of the workgroup still alive)
+__device__ unsigned long long g_round_stats[24];
 #define HJ_STAT(i, v) do { const long long v_ = (long long)(v); if (__lane_id() == 0) ws[i] += (unsigned long long)v_; } while (0)
 #else
 #define HJ_STAT(i, v) do { } while (0)
@@ -864,6 +867,10 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
         waves = 1u;
       }
       const uint32_t parity = bounce & 1u;
+#ifdef HJ_WALK_STATS
+      const unsigned long long round_t0 = wall_clock64();
+      const uint32_t round_rays = n + ns;
+#endif
       if (threadIdx.x == 0) { sh.head = 0; sh.n_next = 0; sh.n_shadow = 0; }
       if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
       __syncthreads();
@@ -876,6 +883,15 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
       n = sh.n_next;
       ns = sh.n_shadow;
       __syncthreads();                       // everyone has read n_next / n_shadow before they are reset
+#ifdef HJ_WALK_STATS
+      if (threadIdx.x == 0) {
+        uint32_t b = 0;
+        while (b < 7u && round_rays >= (16u << (2u * b))) b++;      // 16, 64, 256, 1024, 4096, 16384, 65536
+        atomicAdd(&g_round_stats[b], 1ull);
+        atomicAdd(&g_round_stats[8 + b], (unsigned long long)round_rays);
+        atomicAdd(&g_round_stats[16 + b], (wall_clock64() - round_t0) * waves);
+      }
+#endif
     }
     if (threadIdx.x == 0) {
       st.acc_closest[g] = total_closest;
