@@ -13,7 +13,10 @@ constexpr uint32_t kNumTags = 5;
 //   r1..r3 = (sphere centre | quad origin, edge1, edge2 | triangle a, b, c).xyz, w = emissive power r, g, b
 //   r4..r6 = triangle vertex normals
 constexpr uint32_t kEmitRecF4 = 7;
-constexpr uint32_t kHotNodes = 256;     // 8 KB of LDS per workgroup
+#ifndef HJ_HOT_NODES
+#define HJ_HOT_NODES 256   // 8 KB of LDS per workgroup (128 and 512 measured: no better)
+#endif
+constexpr uint32_t kHotNodes = HJ_HOT_NODES;
 constexpr uint32_t kInnerFlag = 0x80000000u;
 
 // Scene data in HBM.  `nodes` are 32-byte records (two float4 per node) derived from the reference's
