@@ -1,20 +1,32 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Mrays/s (camera paths/s, the reference's own numerator, src/main.rs:1491-1492) on the
-synthetic Cornell box at 1024 x 1024, 512 spp (BASELINE.json configs[1]) on N MI355X.
+"""Headline benchmark: Mrays/s (camera paths/s, the reference's own numerator, src/main.rs:1491-1492) of one whole
+frame of a BASELINE.json configuration on N MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W [--config c2|c3|c4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A step = one whole frame: every rank renders its ImageBlocks (rotating diagonal deal, hj_block_owner) of all 512 passes into a private
-full-frame RGBA32F buffer and one RCCL sum-reduce brings the frame to rank 0 (strong scaling: the frame is fixed).
-Scene, BVH and block lists are resident/derived before the timed region; nothing is read back inside it.
+  c2 (default, the configuration the metric is quoted on)  cbox 1024 x 1024, 512 spp, diffuse + emissive
+  c3                                                       cbox + mirror sphere + dielectric sphere, 1024 x 1024, 1024 spp
+  c4                                                       1 M-triangle mesh in the box, 2048 x 2048, 256 spp
+
+A step = one whole frame: every rank renders its ImageBlocks (rotating diagonal deal, hj_block_owner) of all passes into
+a private full-frame RGBA32F buffer and one RCCL sum-reduce brings the frame to rank 0 (strong scaling: the frame is
+fixed).  Scene, BVH and block lists are resident/derived before the timed region; nothing is read back inside it.
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline     — dominant kernel (k_path_wavefront): algorithmic bytes per launch / HIP-event duration
-  cpu_baseline — the CPU oracle ("Nori-style" port) timed on this host on a bounded sample of the same workload
+  roofline     - HBM roofline of the dominant kernel (k_path_wavefront).  `achieved` = the bytes the IMPLEMENTED
+                 algorithm has to stream through HBM (path records, hit records, shadow records, sample buffer; for c4
+                 also the BVH nodes and triangles that are not LDS-resident) per launch, divided by the kernel's
+                 EXCLUSIVE time per launch (union of the launches' HIP-event intervals / launches: launches of the three
+                 batch slots overlap).  It can not exceed the peak, and bytes/step / ms_per_step is printed beside it
+                 (`achieved_wall`).  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes under profiles/
+                 (tools/roofline_inputs.py regenerates that file from the CSVs).  `limiter` says what the counters say
+                 binds the kernel when it is not HBM.
+  cpu_baseline - the CPU oracle ("Nori-style" port) timed on this host on a bounded sample of the same workload
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -25,19 +37,51 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before torch initialises HIP: see hijiki_amd/__init__.py
 
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (about 6.3 TB/s achievable)
+
+CONFIGS = {
+    "c2": dict(kind="cbox", tris=0, size=1024, spp=512,
+               name="cbox-synth {W}x{H} {spp}spp diffuse+emissive, 6332 triangles"),
+    "c3": dict(kind="spheres", tris=0, size=1024, spp=1024,
+               name="cbox-synth + mirror sphere + dielectric sphere {W}x{H} {spp}spp, 6332 triangles + 2 spheres"),
+    "c4": dict(kind="mesh", tris=1_000_000, size=2048, spp=256,
+               name="synthetic 1M-triangle mesh in the box {W}x{H} {spp}spp"),
+}
 
 
-def algorithmic_bytes_per_path(ctr):
-    """SURVEY.md §8(d), B_path: bytes the REFERENCE algorithm touches per camera path =
-    S*(32*N_n + 108*N_t + 16*N_s [+48*N_q]) over all intersectScene calls (closest AND shadow: the reference walks
-    the full closest-hit query for shadow rays, scene.glsl:92-96) + H*(108+4+16) populate re-fetch + material word
-    + record + E*(16+108+4+16) emitter record + light triangle + its material + 128 for the sample write,
-    the reconstruction read and the accumulation read-modify-write.  Counters come from the CPU oracle on the same
-    scene/seed (properties of algorithm + tree, not of the GPU)."""
-    walk = 32.0 * (ctr["nodes"] + ctr["shadow_nodes"]) + 108.0 * (ctr["tri_tests"] + ctr["shadow_tri_tests"]) \
-        + 16.0 * (ctr["sphere_tests"] + ctr["shadow_sphere_tests"]) + 48.0 * (ctr["quad_tests"] + ctr["shadow_quad_tests"])
-    return (walk + 128.0 * ctr["hits"] + 144.0 * ctr["nee_evals"]) / max(1, ctr["paths"]) + 128.0
+def implemented_bytes(st):
+    """HBM bytes the implemented wavefront algorithm has to move for the work counted in the statistics `st`
+    (DESIGN.md section 4 lists every term).  Path records are far larger than any cache (pool x 2048 workgroups x
+    ~200 B), so every one of these accesses is compulsory traffic; scene data (0.6 MB on cbox: LDS/L1/L2-resident)
+    is NOT counted here."""
+    P, C, S = st["paths"], st["closest_rays"], st["shadow_rays"]
+    Hh, U = st["hits"], st["unoccluded_shadow_rays"]
+    A = C - P                      # continuing paths written by shade (every closest ray that is not a camera ray)
+    first_hits = P * (Hh / C) if C else 0.0
+    b = 0.0
+    b += P * (3 * 16 + 2 * 16)     # top-up: ray_o, ray_d, thr + sample init (smp_rgb, smp_nd)
+    b += C * (2 * 16 + 16)         # walk: fetch ray_o, ray_d; write the hit record
+    b += C * (2 * 16)              # compaction: two passes over the hit records
+    b += Hh * (4 + 4)              # hit queue: write + read of the position
+    b += Hh * (4 * 16)             # shade: hit, ray_o, ray_d, thr
+    b += A * (3 * 16)              # shade: record of the continuing path (ray_o, ray_d, thr)
+    b += S * (3 * 16)              # shade: shadow record (origin, direction + tMax, contribution + sample)
+    b += S * (2 * 16)              # walk: fetch shadow origin, direction
+    b += U * (16 + 2 * 16)         # unoccluded: contribution + read-modify-write of the sample
+    b += first_hits * 16           # first-hit normal + depth
+    b += P * (2 * 16 * (20 * 20) / (16 * 16))   # reconstruction: both sample layers, 20x20 staged per 16x16 tile
+    return b
+
+
+def roofline_inputs(config):
+    """Newest profiles/rNN_<config>_roofline_inputs.json (written by tools/roofline_inputs.py from rocprofv3 CSVs)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{config}_roofline_inputs.json")))
+    if not files:
+        return None, None
+    try:
+        return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+    except (OSError, ValueError):
+        return None, None
 
 
 def host_cores():
@@ -52,17 +96,17 @@ def host_cores():
     return n
 
 
-def cpu_baseline(cs, width, height, seed, budget_s=12.0):
+def cpu_baseline(cs, width, height, total_spp, seed, label, budget_s=12.0):
     """Oracle timed on the host cores of this box on whole passes of the same workload (cost is linear in passes)."""
     from hijiki_amd import host
     from oracle import hj_oracle
     cores = host_cores()
-    _, ctr, secs = hj_oracle.render_blocks(cs, host.make_blocks(width, height, 1, seed), width, height, nthreads=cores)
+    _, _, secs = hj_oracle.render_blocks(cs, host.make_blocks(width, height, 1, seed), width, height, nthreads=cores)
     rate1 = width * height / max(secs, 1e-9)
-    spp = int(max(1, min(64, budget_s * rate1 / (width * height))))
-    _, ctr, secs = hj_oracle.render_blocks(cs, host.make_blocks(width, height, spp, seed), width, height, nthreads=cores)
+    spp = int(max(1, min(64, total_spp, budget_s * rate1 / (width * height))))
+    _, _, secs = hj_oracle.render_blocks(cs, host.make_blocks(width, height, spp, seed), width, height, nthreads=cores)
     return {"value": round(width * height * spp / secs / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{spp} of the 512 passes of cbox {width}x{height} (oracle/hj_oracle.c, {cores} threads, {secs:.2f} s)"}, ctr
+            "sample": f"{spp} of the {total_spp} passes of {label} {width}x{height} (oracle/hj_oracle.c, {cores} threads, {secs:.2f} s)"}
 
 
 def main():
@@ -70,12 +114,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--spp", type=int, default=512)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     import torch
     import torch.distributed as dist
@@ -88,11 +134,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
 
-    cs = host.Scene.synthetic(host.SYNTH_CBOX).compile()
-    W, H, spp = args.width, args.height, args.spp
+    kind = {"cbox": host.SYNTH_CBOX, "spheres": host.SYNTH_CBOX_SPHERES, "mesh": host.SYNTH_CBOX_MESH}[cfg["kind"]]
+    cs = host.Scene.synthetic(kind, mesh_triangles=cfg["tris"]).compile()
+    W, H, spp = args.width or cfg["size"], args.height or cfg["size"], args.spp or cfg["spp"]
+    standard = (W, H, spp) == (cfg["size"], cfg["size"], cfg["spp"])
     sr = hjdist.ShardedRenderer(cs, W, H, local_rank=local)
     opts = device.default_opts()
-    opts.flags = abi.RENDER_TIME_KERNELS      # HIP events around every kernel class, on the library's own stream
+    opts.flags = abi.RENDER_TIME_KERNELS      # HIP events around every kernel class, on the library's own streams
 
     def barrier():
         if world > 1:
@@ -119,8 +167,9 @@ def main():
 
     if rank == 0:
         paths = W * H * spp * args.steps
+        label = cfg["name"].format(W=W, H=H, spp=spp)
         out = {
-            "metric": f"Mrays/s (camera paths/s) at {spp}spp, cbox {W}x{H}",
+            "metric": f"Mrays/s (camera paths/s) at {spp}spp, {cfg['kind'] if args.config != 'c2' else 'cbox'} {W}x{H}",
             "value": round(paths / elapsed / 1e6, 3),
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -132,48 +181,50 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"cbox-synth {W}x{H} {spp}spp diffuse+emissive, 6332 triangles, BVH, block 128, seed {args.seed}",
+            "config": {"workload": f"{args.config}: {label}, BVH, block 128, seed {args.seed}",
                        "partition": f"ImageBlock (bx, by) of pass p -> rank (bx + by + p) mod {world}, RCCL sum-reduce of the {W}x{H} RGBA32F framebuffer"},
         }
-        base = None
-        ctr = None
         if not args.no_cpu_baseline:
-            base, ctr = cpu_baseline(cs, W, H, args.seed)
-            out["cpu_baseline"] = base
-        else:
-            from oracle import hj_oracle
-            _, ctr, _ = hj_oracle.render_blocks(cs, host.make_blocks(W, H, 1, args.seed), W, H)
-        # dominant kernel: k_path_wavefront (the whole wavefront loop of a batch is ONE persistent launch).
-        # achieved = algorithmic bytes per launch / average launch duration, both over the timed region of THIS
-        # run (rank 0's launches, HIP events on the launch streams).  Two batches are in flight on two streams, so
-        # launches overlap in time: `achieved_wall` divides the same bytes by the wall time of the region instead.
-        bpp = algorithmic_bytes_per_path(ctr)
+            out["cpu_baseline"] = cpu_baseline(cs, W, H, spp, args.seed, cfg["kind"])
+
+        # ---- roofline of the dominant kernel, from THIS run's device counters and HIP events (rank 0's launches)
+        inputs, src = roofline_inputs(args.config) if standard and world == 1 else (None, None)
         launches = max(1, agg["path_launches"])
-        bytes_per_launch = bpp * agg["paths"] / launches
-        avg_ms = agg["path_ms"] / launches
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
-        # WRITE_SIZE in separate runs of this command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); only
-        # quoted for the workload that was profiled (cbox 1024x1024, 512 spp, 1 GPU).
-        traffic = traffic_bytes = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v7_pmc_hbm_traffic.json")))
-            if (W, H, spp) == (1024, 1024, 512) and world == 1:
-                traffic_bytes = round(pmc["traffic_bytes_per_path_corrected"] * agg["paths"] / launches)
-                traffic = round(traffic_bytes / (avg_ms * 1e-3) / 1e9, 1)
-        except (OSError, ValueError, KeyError):
-            pass
-        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                           "traffic_bytes_per_launch": traffic_bytes, "algorithmic_bytes_per_launch": round(bytes_per_launch),
-                           "kernel": "k_path_wavefront", "bytes_per_path": round(bpp, 1),
-                           "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
-                           "achieved_wall": round(bpp * agg["paths"] / elapsed / 1e9 * world, 1),
-                           "note": "algorithmic bytes of the reference algorithm (SURVEY 8d B_path); the 0.6 MB scene is "
-                                   "L1/L2-resident, so physical HBM traffic is far lower: the kernel is bound by "
-                                   "dependent-fetch latency and lane utilisation (DESIGN.md 6, profiles/)"}
-        out["kernel_ms_per_step"] = {k: round(agg[k] / args.steps, 3) for k in ("path_ms", "reconstruct_ms", "total_ms")}
-        out["rays_per_path"] = round((agg["closest_rays"] + agg["shadow_rays"]) / max(1, agg["paths"]), 3)
+        rays = agg["closest_rays"] + agg["shadow_rays"]
+        state_bytes = implemented_bytes(agg)
+        scene_bytes = 0.0
+        if inputs and inputs.get("scene_bytes_per_ray"):   # c4: nodes + triangles fetched from beyond the LDS copy
+            scene_bytes = inputs["scene_bytes_per_ray"] * rays
+        alg = state_bytes + scene_bytes
+        busy_ms = agg["path_busy_ms"] or (1e3 * elapsed)             # exclusive GPU time of the path kernels, rank 0
+        excl_ms = busy_ms / launches
+        achieved = alg / launches / (excl_ms * 1e-3) / 1e9
+        traffic = traffic_per_launch = None
+        if inputs and inputs.get("hbm_bytes_per_path"):
+            traffic_per_launch = inputs["hbm_bytes_per_path"] * agg["paths"] / launches
+            traffic = round(traffic_per_launch / (excl_ms * 1e-3) / 1e9, 1)
+        out["roofline"] = {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "kernel": "k_path_wavefront", "launches": int(launches),
+            "algorithmic_bytes_per_launch": round(alg / launches),
+            "algorithmic_bytes_per_path": round(alg / max(1, agg["paths"]), 1),
+            "scene_bytes_per_path": round(scene_bytes / max(1, agg["paths"]), 1),
+            "traffic_bytes_per_launch": None if traffic_per_launch is None else round(traffic_per_launch),
+            "traffic_source": src,
+            "exclusive_ms_per_launch": round(excl_ms, 4),
+            "overlapped_ms_per_launch": round(agg["path_ms"] / launches, 4),
+            "achieved_wall": round(alg * world / elapsed / 1e9, 1),
+            "reference_algorithm_bytes_per_path": None if not inputs else inputs.get("reference_bytes_per_path"),
+            "limiter": None if not inputs else inputs.get("limiter"),
+            "note": "bytes of the implemented algorithm (path/hit/shadow records and samples; scene data only where it "
+                    "is not LDS/cache-resident) over the kernel's exclusive time; `limiter` names what the counters "
+                    "say binds the kernel (DESIGN.md 6, profiles/)"}
+        out["kernel_ms_per_step"] = {"path_exclusive_ms": round(busy_ms / args.steps, 3),
+                                     "path_overlapped_sum_ms": round(agg["path_ms"] / args.steps, 3),
+                                     "reconstruct_sum_ms": round(agg["reconstruct_ms"] / args.steps, 3),
+                                     "total_ms": round(agg["total_ms"] / args.steps, 3)}
+        out["rays_per_path"] = round(rays / max(1, agg["paths"]), 3)
         print(json.dumps(out), flush=True)
     sr.close()
     if world > 1:

@@ -68,14 +68,14 @@ struct hj_context {
   // one batch (a few long paths) overlaps the throughput phase of the next ones.
   struct BatchSlot {
     hj::BatchState st{};
-    std::vector<DevBuf> bufs;
+    std::vector<DevBuf> bufs, sample_bufs;   // path-state arrays + queues; per-sample buffers
     DevBuf d_blocks, d_wtab, d_tiles;
     uint32_t* h_tiles = nullptr;          // pinned staging of the per-tile block lists
     size_t h_tiles_cap = 0;
     hipStream_t stream = nullptr;
     hj_image_block* h_blocks = nullptr;   // pinned staging of the block list
     uint32_t h_blocks_cap = 0;
-    uint32_t* h_counts = nullptr;         // pinned read-back: 4 arrays of num_wg words
+    uint32_t* h_counts = nullptr;         // pinned read-back: 2 (split-path ray counts) + 4 (statistics) arrays of num_wg words
     hipEvent_t ev_count[2] = {nullptr, nullptr};
     hipEvent_t ev_recon = nullptr;        // this slot's reconstruction has run (orders framebuffer updates)
     hipEvent_t ev_done = nullptr;         // batch complete, statistics copied back
@@ -83,6 +83,7 @@ struct hj_context {
   } slots[kMaxSlots];
   uint32_t num_slots = 3;
   uint32_t num_wg = 2048;                // grid size of every path kernel (= queue segments)
+  uint32_t pool = 8192;                  // path slots per workgroup of the fused kernel (HJ_POOL)
 
   // timing
   std::vector<EventPair> events;
@@ -145,6 +146,8 @@ void release_scene(hj_context* ctx) {
 void release_slot(hj_context::BatchSlot& sl) {
   for (auto& b : sl.bufs) b.release();
   sl.bufs.clear();
+  for (auto& b : sl.sample_bufs) b.release();
+  sl.sample_bufs.clear();
   sl.st = hj::BatchState{};
 }
 void release_batch(hj_context* ctx) {
@@ -199,65 +202,76 @@ int validate_scene(hj_context* ctx, const hj_scene_desc* s) {
   return HJ_OK;
 }
 
-int ensure_batch(hj_context* ctx, hj_context::BatchSlot& sl, uint32_t num_blocks) {
+// Sample buffers for `num_blocks` ImageBlocks and path-state arrays + queues of `pool` slots per workgroup.
+// pool: the fused kernel regenerates paths, so a few thousand slots per workgroup keep it busy whatever the batch
+// size (ctx->pool, HJ_POOL); the split-kernel path starts every sample of the batch at once and needs them all.
+int ensure_batch(hj_context* ctx, hj_context::BatchSlot& sl, uint32_t num_blocks, bool all_in_flight) {
   const uint32_t cap = num_blocks * hj::kSlotsPerBlock;
-  if (sl.st.capacity >= cap) return HJ_OK;
-  release_slot(sl);
-  auto alloc = [&](size_t bytes, void** out) -> int {
-    sl.bufs.emplace_back();
-    int rc = dev_alloc(ctx, sl.bufs.back(), bytes);
-    *out = sl.bufs.back().p;
-    return rc;
-  };
+  const uint32_t G = ctx->num_wg;
+  const uint32_t per_wg = (((cap + 63u) / 64u + G - 1u) / G) * 64u;     // samples of the busiest workgroup
+  const uint32_t pool = all_in_flight ? per_wg : std::min(per_wg, ctx->pool);
   hj::BatchState& st = sl.st;
   int rc = HJ_OK;
-  const size_t n = cap;
-#define HJ_ALLOC(field, type, count)                                       \
+  auto alloc = [&](std::vector<DevBuf>& bufs, size_t bytes, void** out) -> int {
+    bufs.emplace_back();
+    int rc2 = dev_alloc(ctx, bufs.back(), bytes);
+    *out = bufs.back().p;
+    return rc2;
+  };
+#define HJ_ALLOC(bufs, field, type, count)                                 \
   if (rc == HJ_OK) {                                                       \
     void* p_ = nullptr;                                                    \
-    rc = alloc(sizeof(type) * (count), &p_);                               \
+    rc = alloc(bufs, sizeof(type) * (count), &p_);                         \
     st.field = static_cast<type*>(p_);                                     \
   }
-  HJ_ALLOC(ray_o, float4, n)
-  HJ_ALLOC(ray_d, float4, n)
-  HJ_ALLOC(hit, float4, n)
-  HJ_ALLOC(thr, float4, n)
-  HJ_ALLOC(ext, float4, n)
-  HJ_ALLOC(smp_rgb, float4, n)
-  HJ_ALLOC(smp_nd, float4, n)
-  HJ_ALLOC(sh_d, float4, n)
-  HJ_ALLOC(sh_c, float4, n)
-  const uint32_t G = ctx->num_wg;
-  const uint32_t segcap = (((cap + 63u) / 64u + G - 1u) / G) * 64u;
-  const size_t qn = (size_t)G * segcap;
-  HJ_ALLOC(q_ray[0], uint32_t, qn)
-  HJ_ALLOC(q_ray[1], uint32_t, qn)
-  HJ_ALLOC(q_hit, uint32_t, qn * hj::kNumTags)
-  HJ_ALLOC(q_shadow, uint32_t, qn)
-  HJ_ALLOC(cnt_ray[0], uint32_t, G)
-  HJ_ALLOC(cnt_ray[1], uint32_t, G)
-  HJ_ALLOC(cnt_hit, uint32_t, (size_t)G * hj::kNumTags)
-  HJ_ALLOC(cnt_shadow, uint32_t, G)
-  HJ_ALLOC(acc_closest, uint32_t, G)
-  HJ_ALLOC(acc_shadow, uint32_t, G)
+  if (st.capacity < cap) {
+    for (auto& b : sl.sample_bufs) b.release();
+    sl.sample_bufs.clear();
+    st.capacity = 0;
+    HJ_ALLOC(sl.sample_bufs, smp_rgb, float4, (size_t)cap)
+    HJ_ALLOC(sl.sample_bufs, smp_nd, float4, (size_t)cap)
+    if (rc == HJ_OK) rc = dev_alloc(ctx, sl.d_blocks, sizeof(hj_image_block) * num_blocks);
+    if (rc == HJ_OK) rc = dev_alloc(ctx, sl.d_wtab, sizeof(float) * 25 * num_blocks);
+    if (rc == HJ_OK && sl.h_blocks_cap < num_blocks) {
+      if (sl.h_blocks) (void)hipHostFree(sl.h_blocks);
+      sl.h_blocks = nullptr;
+      sl.h_blocks_cap = 0;
+      if (hipHostMalloc((void**)&sl.h_blocks, sizeof(hj_image_block) * num_blocks, hipHostMallocDefault) != hipSuccess)
+        rc = set_error(ctx, HJ_ERR_NOMEM, "pinned block staging allocation failed");
+      else sl.h_blocks_cap = num_blocks;
+    }
+    if (rc == HJ_OK) st.capacity = cap;
+  }
+  if (rc == HJ_OK && st.pool < pool) {
+    for (auto& b : sl.bufs) b.release();
+    sl.bufs.clear();
+    st.pool = 0;
+    const size_t n = (size_t)G * pool;
+    for (int par = 0; par < 2; par++) {
+      HJ_ALLOC(sl.bufs, ray_o[par], float4, n)
+      HJ_ALLOC(sl.bufs, ray_d[par], float4, n)
+      HJ_ALLOC(sl.bufs, thr[par], float4, n)
+      HJ_ALLOC(sl.bufs, ext[par], float4, n)
+    }
+    HJ_ALLOC(sl.bufs, hit, float4, n)
+    HJ_ALLOC(sl.bufs, q_hit, uint32_t, n * hj::kNumTags)
+    HJ_ALLOC(sl.bufs, sh_o, float4, n)
+    HJ_ALLOC(sl.bufs, sh_d, float4, n)
+    HJ_ALLOC(sl.bufs, sh_c, float4, n)
+    HJ_ALLOC(sl.bufs, cnt_ray[0], uint32_t, G)
+    HJ_ALLOC(sl.bufs, cnt_ray[1], uint32_t, G)
+    HJ_ALLOC(sl.bufs, cnt_hit, uint32_t, (size_t)G * hj::kNumTags)
+    HJ_ALLOC(sl.bufs, cnt_shadow, uint32_t, G)
+    HJ_ALLOC(sl.bufs, acc_closest, uint32_t, (size_t)4 * G)     // closest | shadow | hits | unoccluded, one read-back
+    if (rc == HJ_OK) {
+      st.acc_shadow = st.acc_closest + G;
+      st.acc_hits = st.acc_closest + 2 * (size_t)G;
+      st.acc_unoccluded = st.acc_closest + 3 * (size_t)G;
+      st.pool = pool;
+    }
+  }
 #undef HJ_ALLOC
   st.num_wg = G;
-  st.segcap = segcap;
-  if (rc != HJ_OK) {
-    release_slot(sl);
-    return rc;
-  }
-  st.capacity = cap;
-  rc = dev_alloc(ctx, sl.d_blocks, sizeof(hj_image_block) * num_blocks);
-  if (rc == HJ_OK) rc = dev_alloc(ctx, sl.d_wtab, sizeof(float) * 25 * num_blocks);
-  if (rc == HJ_OK && sl.h_blocks_cap < num_blocks) {
-    if (sl.h_blocks) (void)hipHostFree(sl.h_blocks);
-    sl.h_blocks = nullptr;
-    sl.h_blocks_cap = 0;
-    if (hipHostMalloc((void**)&sl.h_blocks, sizeof(hj_image_block) * num_blocks, hipHostMallocDefault) != hipSuccess)
-      rc = set_error(ctx, HJ_ERR_NOMEM, "pinned block staging allocation failed");
-    else sl.h_blocks_cap = num_blocks;
-  }
   if (rc != HJ_OK) release_slot(sl);
   return rc;
 }
@@ -361,14 +375,17 @@ int harvest(hj_context* ctx, hj_context::BatchSlot& sl, hj_render_stats* stats) 
     for (uint32_t i = 0; i < G; i++) {
       stats->closest_rays += h_acc[i];
       stats->shadow_rays += h_acc[G + i];
+      stats->hits += h_acc[2 * (size_t)G + i];
+      stats->unoccluded_shadow_rays += h_acc[3 * (size_t)G + i];
     }
     stats->batches += 1;
   }
   return HJ_OK;
 }
 
-int stage_blocks(hj_context* ctx, hj_context::BatchSlot& sl, const hj_image_block* blocks, uint32_t nb, hj::BatchState& st) {
-  int rc = ensure_batch(ctx, sl, std::max<uint32_t>(nb, 1));
+int stage_blocks(hj_context* ctx, hj_context::BatchSlot& sl, const hj_image_block* blocks, uint32_t nb, hj::BatchState& st,
+                 bool all_in_flight) {
+  int rc = ensure_batch(ctx, sl, std::max<uint32_t>(nb, 1), all_in_flight);
   if (rc != HJ_OK) return rc;
   st = sl.st;
   st.blocks = static_cast<const hj_image_block*>(sl.d_blocks.p);
@@ -381,8 +398,7 @@ int stage_blocks(hj_context* ctx, hj_context::BatchSlot& sl, const hj_image_bloc
 int finish_batch(hj_context* ctx, hj_context::BatchSlot& sl, const hj::BatchState& st) {
   const uint32_t G = st.num_wg;
   uint32_t* h_acc = sl.h_counts + (size_t)2 * G;
-  HJ_HIP(ctx, hipMemcpyAsync(h_acc, st.acc_closest, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, sl.stream));
-  HJ_HIP(ctx, hipMemcpyAsync(h_acc + G, st.acc_shadow, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, sl.stream));
+  HJ_HIP(ctx, hipMemcpyAsync(h_acc, st.acc_closest, sizeof(uint32_t) * 4 * G, hipMemcpyDeviceToHost, sl.stream));
   HJ_HIP(ctx, hipEventRecord(sl.ev_done, sl.stream));
   sl.pending = true;
   return HJ_OK;
@@ -392,7 +408,7 @@ int finish_batch(hj_context* ctx, hj_context::BatchSlot& sl, const hj::BatchStat
 int enqueue_batch_fused(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::BatchSlot& other, const hj_image_block* blocks,
                         uint32_t nb, const hj_render_opts& o, Timer& tm, hj_render_stats* stats, bool reconstruct) {
   hj::BatchState st;
-  int rc = stage_blocks(ctx, sl, blocks, nb, st);
+  int rc = stage_blocks(ctx, sl, blocks, nb, st, false);
   if (rc != HJ_OK) return rc;
   const dim3 blk(hj::kBlockThreads), grid(st.num_wg);
   const int ev = tm.begin(EV_PATH, sl.stream);
@@ -415,7 +431,7 @@ int enqueue_batch_fused(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::
 int render_batch_split(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::BatchSlot& other, const hj_image_block* blocks,
                        uint32_t nb, const hj_render_opts& o, Timer& tm, hj_render_stats* stats, bool reconstruct) {
   hj::BatchState st;
-  int rc = stage_blocks(ctx, sl, blocks, nb, st);
+  int rc = stage_blocks(ctx, sl, blocks, nb, st, true);
   if (rc != HJ_OK) return rc;
   hipStream_t s = sl.stream;
   const uint32_t G = st.num_wg;
@@ -432,14 +448,13 @@ int render_batch_split(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::B
   static const bool trace_bounces = std::getenv("HJ_TRACE_BOUNCES") != nullptr;   // debugging aid: per-bounce table
   for (uint32_t bounce = 0; bounce < o.max_bounces; bounce++) {
     const uint32_t parity = bounce & 1u;
-    const float tmin = bounce == 0 ? hj::kEps : 2.0f * hj::kEps;   // render.glsl:33,132
     const size_t ev0 = ctx->events_used;
     int ev = tm.begin(EV_CLOSEST, s);
-    if (bvh) hipLaunchKernelGGL(hj::k_trace_closest<true>, grid, blk, 0, s, st, ctx->scene, parity, tmin);
-    else hipLaunchKernelGGL(hj::k_trace_closest<false>, grid, blk, 0, s, st, ctx->scene, parity, tmin);
+    if (bvh) hipLaunchKernelGGL(hj::k_trace_closest<true>, grid, blk, 0, s, st, ctx->scene, parity);
+    else hipLaunchKernelGGL(hj::k_trace_closest<false>, grid, blk, 0, s, st, ctx->scene, parity);
     tm.end(ev, s);
     ev = tm.begin(EV_SHADE, s);
-    hipLaunchKernelGGL(hj::k_shade, grid, blk, 0, s, st, ctx->scene, parity, bounce, o.max_bounces, o.rr_start);
+    hipLaunchKernelGGL(hj::k_shade, grid, blk, 0, s, st, ctx->scene, parity, o.max_bounces, o.rr_start);
     tm.end(ev, s);
     ev = tm.begin(EV_SHADOW, s);
     if (bvh) hipLaunchKernelGGL(hj::k_trace_shadow<true>, grid, blk, 0, s, st, ctx->scene);
@@ -497,7 +512,7 @@ int check_opts(hj_context* ctx, const hj_render_opts& o) {
 
 extern "C" {
 
-uint32_t hj_version(void) { return (0u << 16) | (1u << 8) | 0u; }
+uint32_t hj_version(void) { return (0u << 16) | (2u << 8) | 0u; }
 
 void hj_default_render_opts(hj_render_opts* o) {
   if (!o) return;
@@ -544,9 +559,10 @@ int hj_context_create(int device, hj_context** out) {
   // Tuning knobs (environment overrides exist only for sweeps; the defaults are the measured optima).
   ctx->num_wg = (uint32_t)ctx->num_cus * (uint32_t)env_int("HJ_WG_PER_CU", 8, 1, 32);   // 8 x 4 waves = the 32-wave CU limit
   ctx->num_slots = (uint32_t)env_int("HJ_SLOTS", 3, 1, (int)kMaxSlots);
+  ctx->pool = (uint32_t)env_int("HJ_POOL", 8192, 64, 1 << 20) / 64u * 64u;
   for (auto& sl : ctx->slots) {
     if ((e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
-    if ((e = hipHostMalloc((void**)&sl.h_counts, sizeof(uint32_t) * 4 * ctx->num_wg, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
+    if ((e = hipHostMalloc((void**)&sl.h_counts, sizeof(uint32_t) * 6 * ctx->num_wg, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
     for (hipEvent_t* ev : {&sl.ev_count[0], &sl.ev_count[1], &sl.ev_recon, &sl.ev_done})
       if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   }
@@ -695,6 +711,7 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     d.num_hot = (uint32_t)hot;
     d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", 4, 1, 1 << 20);   // >= 1, or the walk would never advance
     d.refill_min = (uint32_t)env_int("HJ_REFILL_MIN", (int)hj::kRefillMin, 1, 64);
+    d.cold_burst = (uint32_t)env_int("HJ_COLD_BURST", 2, 1, 1 << 20);
     HJ_UP(upload(ctx, dev.data(), dev.size(), &d.nodes));
   }
   HJ_UP(upload(ctx, isect.data(), isect.size(), &d.tri_isect));
@@ -902,6 +919,27 @@ int run_end(hj_context* ctx, RenderRun& run, int rc) {
     hj_render_stats* st_out = run.st;
     st_out->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - run.wall0).count();
     st_out->paths = run.paths;
+    // exclusive time of the dominant kernel: the union of the launches' intervals (launches of different batch slots
+    // overlap, so the sum of their durations exceeds the wall clock)
+    {
+      std::vector<std::pair<float, float>> iv;
+      for (size_t i = 0; i < ctx->events_used; i++) {
+        const int kind = ctx->events[i].kind;
+        if (kind != EV_PATH && kind != EV_CLOSEST && kind != EV_SHADE && kind != EV_SHADOW) continue;
+        float a = 0.f, b = 0.f;
+        if (hipEventElapsedTime(&a, ctx->events[0].a, ctx->events[i].a) != hipSuccess) continue;
+        if (hipEventElapsedTime(&b, ctx->events[0].a, ctx->events[i].b) != hipSuccess) continue;
+        iv.emplace_back(a, b);
+      }
+      std::sort(iv.begin(), iv.end());
+      float busy = 0.f, cur_a = 0.f, cur_b = -1.f;
+      for (auto& x : iv) {
+        if (cur_b < cur_a || x.first > cur_b) { if (cur_b > cur_a) busy += cur_b - cur_a; cur_a = x.first; cur_b = x.second; }
+        else cur_b = std::max(cur_b, x.second);
+      }
+      if (cur_b > cur_a) busy += cur_b - cur_a;
+      st_out->path_busy_ms = busy;
+    }
     for (size_t i = 0; i < ctx->events_used; i++) {
       float e = 0.f;
       if (hipEventElapsedTime(&e, ctx->events[i].a, ctx->events[i].b) != hipSuccess) continue;
@@ -1195,10 +1233,10 @@ extern "C" __attribute__((visibility("default"))) int hj_debug_round_stats(unsig
   }
   return HJ_OK;
 }
-extern "C" __attribute__((visibility("default"))) int hj_debug_walk_stats(unsigned long long out[8], int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hj::g_walk_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return HJ_ERR_DEVICE;
+extern "C" __attribute__((visibility("default"))) int hj_debug_walk_stats(unsigned long long out[16], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hj::g_walk_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return HJ_ERR_DEVICE;
   if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long z[16] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(hj::g_walk_stats), z, sizeof z) != hipSuccess) return HJ_ERR_DEVICE;
   }
   return HJ_OK;

@@ -39,6 +39,7 @@ struct DeviceScene {
   uint32_t num_hot;             // nodes [0, num_hot) are the LDS-cached ones (<= kHotNodes)
   uint32_t inner_burst;         // max box steps per round of the persistent walk before leaf tests run
   uint32_t refill_min;          // free lanes that trigger a ray refill
+  uint32_t cold_burst;          // max HBM-node steps per round of the persistent walk
   const float4* tri_isect;
   const float4* tri_shade;
   const float4* spheres;        // hj_sphere
@@ -58,34 +59,48 @@ struct DeviceScene {
   float tan_half_fov;           // (float)tan(radians(fov/2)) evaluated in double on the host
 };
 
-// Queues are partitioned into one private SEGMENT per workgroup: workgroup g of every stage kernel reads and
-// appends only segment g (counts in cnt_*[g], appends through LDS counters), so no stage touches a global
-// atomic.  (The first version used chip-wide queue counters: ~88 M same-address atomics/s bounded every kernel.)
-// Slot -> owner: 64-slot groups are dealt round-robin over the workgroups, so each one samples the whole image.
+// One wavefront batch = the samples of up to 4096 ImageBlocks.  Two index spaces:
+//   SAMPLE   = block_in_batch * 16384 + ly * 128 + lx: the intermediate image of the batch (what reconstruction
+//              reads); 64-sample groups are dealt round-robin over the workgroups, so each one samples the whole image;
+//   POSITION = index into the workgroup's segment [g * pool, (g + 1) * pool) of the path arrays.  The paths in flight
+//              are kept COMPACTED: the record of a path lives at its position in the current round's ray queue, shade
+//              writes the record of a continuing path at its position in the NEXT round's queue (the arrays are
+//              double-buffered by round parity), and the top-up appends NEW camera paths of the workgroup's sample
+//              sequence behind them (path regeneration).  So the queue is implicit (entry i = record i), every stage
+//              reads and writes the path arrays in queue order (coalesced), a path that ends simply is not written
+//              again, and ~pool paths stay in flight per workgroup until its samples run out instead of decaying
+//              bounce by bounce.  This is the "rays sorted/compacted by material and alive-mask" of the design brief.
+// Workgroup g reads and appends only its own segments (appends: wave ballot + one LDS atomic): no stage touches a
+// global atomic.  (The first version used chip-wide queue counters: ~88 M same-address atomics/s bounded every kernel.)
+constexpr uint32_t kCameraFlag = 0x80000000u;   // in ray_o.w beside the sample index: camera ray (tMin = eps, render.glsl:33)
 struct BatchState {
-  // per path slot (slot = block_in_batch * 16384 + ly * 128 + lx)
-  float4* ray_o;      // origin.xyz
-  float4* ray_d;      // direction.xyz, RNG state bits
-  float4* hit;        // (t, objectID bits, u, v) of the raw hit
-  float4* thr;        // throughput.rgb, flags bits (bit0 wasDiscrete)
-  float4* ext;        // current extinction (only touched if scene.has_extinction)
-  float4* smp_rgb;    // layer 0 of the intermediate image: (radiance, 1)
-  float4* smp_nd;     // layer 1: (first-hit normal, first-hit t)
-  float4* sh_d;       // shadow ray direction.xyz, tMax
-  float4* sh_c;       // pending NEE contribution rgb
-  uint32_t* q_ray[2]; // [num_wg][segcap] ray queues (index = bounce parity)
-  uint32_t* q_hit;    // [kNumTags][num_wg][segcap] hits binned by material tag
-  uint32_t* q_shadow; // [num_wg][segcap]
-  uint32_t* cnt_ray[2];   // [num_wg]
+  // per sample
+  float4* smp_rgb;      // layer 0 of the intermediate image: (radiance, 1)
+  float4* smp_nd;       // layer 1: (first-hit normal, first-hit t)
+  // per position, double-buffered by round parity: the paths in flight
+  float4* ray_o[2];     // origin.xyz, sample index bits | kCameraFlag
+  float4* ray_d[2];     // direction.xyz, RNG state bits
+  float4* thr[2];       // throughput.rgb, flags bits (bit0 wasDiscrete, bits 1.. bounce index)
+  float4* ext[2];       // current extinction (only touched if scene.has_extinction)
+  // per position of the current round
+  float4* hit;          // (t, objectID bits, u, v) of the raw hit
+  uint32_t* q_hit;      // [kNumTags][num_wg][pool] positions of the hits, binned by material tag, in queue order
+  // NEE shadow rays produced by shade, walked in the next round (self-contained: the path may be over by then)
+  float4* sh_o;         // origin.xyz
+  float4* sh_d;         // direction.xyz, tMax
+  float4* sh_c;         // pending NEE contribution rgb, sample index bits
+  uint32_t* cnt_ray[2];   // [num_wg]        (split-kernel path: counts between launches)
   uint32_t* cnt_hit;      // [num_wg][kNumTags]
   uint32_t* cnt_shadow;   // [num_wg]
   uint32_t* acc_closest;  // [num_wg] closest-hit rays traced by this workgroup over the batch (stats)
   uint32_t* acc_shadow;   // [num_wg] shadow rays
+  uint32_t* acc_hits;     // [num_wg] closest-hit rays that hit something
+  uint32_t* acc_unoccluded;   // [num_wg] shadow rays that reached their light
   const hj_image_block* blocks;  // the batch's ImageBlocks
   uint32_t num_blocks;
-  uint32_t capacity;             // slots allocated
+  uint32_t capacity;             // samples allocated
   uint32_t num_wg;               // grid size of every stage kernel
-  uint32_t segcap;               // entries per queue segment
+  uint32_t pool;                 // positions per workgroup, multiple of 64
 };
 
 }  // namespace hj

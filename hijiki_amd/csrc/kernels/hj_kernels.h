@@ -3,15 +3,15 @@
 // One batch = up to `capacity` camera paths (many ImageBlocks of many passes).  Every path workgroup owns one
 // private segment of every queue (hj_device.h) and advances ITS paths one bounce per round:
 //
-//   stage_gen_camera     render.glsl:149-162                 seed, camera ray, queue
-//   per bounce:
-//     stage_trace_closest  scene.glsl:97-133                 skip-link BVH walk -> hit record, hits binned by
-//                                                            MATERIAL TAG (wave ballot + LDS counters)
+//   per round:
+//     stage_gen_camera     render.glsl:149-162               top-up: seed, camera ray of NEW paths into free path slots
+//     stage_trace_merged   scene.glsl:92-133                 skip-link BVH walk of the closest-hit rays (-> hit record)
+//                                                            and of the previous round's shadow rays (any-hit, boolean-
+//                                                            equivalent to the reference's closest-hit; adds NEE radiance)
+//     compact_hits_by_tag                                    hits binned by MATERIAL TAG in queue order (wave ballots)
 //     stage_shade          scene.glsl:160-175, render.glsl:102-144, material.glsl
 //                                                            populate, emission, NEE sample, BSDF sample,
 //                                                            roulette -> next ray queue + shadow queue
-//     stage_trace_shadow   scene.glsl:92-96                  any-hit walk (boolean-equivalent to the reference's
-//                                                            closest-hit), adds NEE radiance
 //   k_recon_weights / k_reconstruct   reconstruction.glsl:22-66
 //
 // k_path_wavefront runs all stages of a batch in ONE persistent launch (workgroup barriers only);
@@ -198,13 +198,16 @@ HJ_DEV bool traverse(const DeviceScene& sc, Ray r, RawHit& h) {
 // Each ray still performs exactly the reference's pre-order skip-link walk (scene.glsl:97-133).
 //   fetch(i, slot, ray)   loads queue entry i
 //   finish(done, slot, h) wave-convergent: called when some lanes are done; `done` lanes have a final result
+#ifndef HJ_WALK_SPLIT
+#define HJ_WALK_SPLIT 0   // 1 = separate ds_read (hot) and global (cold) box-step phases: measured -12 % (cbox) / -30 % (1 M triangles), DESIGN.md
+#endif
 constexpr uint32_t kRefillMin = 32;   // sweep on the fused kernel: 16 -> 1.39, 32..48 -> 1.43 Gpaths/s, 64 -> 1.24
 
 #ifdef HJ_WALK_STATS
 // Diagnostic build only (tools/build_variant.sh stats -DHJ_WALK_STATS): wave-level occupancy of the walk's phases.
 // [0] outer iterations [1] inner wave-steps [2] lanes in them [3] leaf phases [4] lanes in them [5] refills
 // [6] lanes refilled [7] lanes active at the start of an outer iteration
-__device__ unsigned long long g_walk_stats[8];
+__device__ unsigned long long g_walk_stats[16];   // [8] cold wave-steps [9] lanes in them (HJ_WALK_SPLIT)
 // rounds of the fused kernel by size bucket b (rays of the round in [64 * 4^b / 4, 64 * 4^b), b = 0..7):
 // [b] rounds, [8 + b] rays, [16 + b] wave-cycles (wall clock of the round x waves of the workgroup still alive)
 __device__ unsigned long long g_round_stats[24];
@@ -225,9 +228,13 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
   v3 inv = V(0, 0, 0), off = V(0, 0, 0);
   RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
 #ifdef HJ_WALK_STATS
-  unsigned long long ws[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ws[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_begin = clock64();
 #endif
   for (;;) {
+#ifdef HJ_WALK_STATS
+    const unsigned long long t_a = clock64();   // [10] service, [11] box steps, [12] leaf tests: wave cycles by phase
+#endif
     // Service phase: only when enough lanes are free.  Finished lanes keep their result in registers until
     // then, so that result STORES and new-ray LOADS are issued together, once per phase: vmcnt counts loads and
     // stores in one in-order counter on gfx950, and a store between two node fetches would stall the walk for
@@ -256,35 +263,70 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     }
     if (__ballot(active) == 0) break;
     HJ_STAT(0, 1); HJ_STAT(7, __popcll(__ballot(active)));
+#ifdef HJ_WALK_STATS
+    const unsigned long long t_b = clock64();
+    HJ_STAT(10, t_b - t_a);
+#endif
     uint32_t shape = 0, ex = 0;
     bool at_leaf = false;
     uint32_t burst = sc.inner_burst;       // lanes standing on a leaf wait at most this many box steps of the others
-    while (active && cur < nn && !at_leaf && burst != 0) {
-      // hot node: LDS copy, same 32-byte record layout as in HBM, so that ONE address select feeds both 16-byte
-      // loads (FLAT loads of base + 32*cur and +16; a per-array `if` compiled to two exec-masked address blocks)
-      const float4* __restrict__ nd = (cur < nhot ? s_nodes : sc.nodes) + 2 * cur;
-      const float4 n0 = nd[0], n1 = nd[1];
+#if HJ_WALK_SPLIT
+    // Two box-step phases per round.  HOT: nodes [0, nhot) are read from the workgroup's LDS copy with ds_read
+    // (latency ~100 cycles): lanes standing on a cold node or a leaf sit these steps out.  COLD: lanes standing on
+    // a node of the HBM array take up to cold_burst steps with global loads (several hundred cycles each).  With one
+    // FLAT load for both (the previous form) every wave-step waited for its slowest lane, i.e. for a global fetch,
+    // although five of six node visits are hot.
+    while (active && !at_leaf && cur < nhot && burst != 0) {
+      const float4 n0 = s_nodes[2 * cur], n1 = s_nodes[2 * cur + 1];
       at_leaf = node_step(n0, n1, inv, off, r, cur, shape, ex);
       burst--;
 #ifdef HJ_WALK_STATS
       { const unsigned long long m = __ballot(true); if (lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[1] += 1; ws[2] += __popcll(m); } }
 #endif
     }
+    uint32_t cburst = sc.cold_burst;
+    while (active && !at_leaf && cur >= nhot && cur < nn && cburst != 0) {
+      const float4* __restrict__ nd = sc.nodes + 2 * cur;
+      const float4 n0 = nd[0], n1 = nd[1];
+      at_leaf = node_step(n0, n1, inv, off, r, cur, shape, ex);
+      cburst--;
+#ifdef HJ_WALK_STATS
+      { const unsigned long long m = __ballot(true); if (lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[8] += 1; ws[9] += __popcll(m); } }
+#endif
+    }
+#else
+    while (active && cur < nn && !at_leaf && burst != 0) {
+      // hot node: LDS copy, same 32-byte record layout as in HBM, so that ONE address select feeds both 16-byte
+      // loads (FLAT loads of base + 32*cur and +16; a per-array `if` compiled to two exec-masked address blocks)
+      const float4* __restrict__ nd = (cur < nhot ? s_nodes : sc.nodes) + 2 * cur;
+#ifdef HJ_WALK_STATS
+      { const unsigned long long m = __ballot(true), mc = __ballot(cur >= nhot);     // [14] lane-steps on nodes outside the LDS copy
+        if (lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[1] += 1; ws[2] += __popcll(m); ws[14] += __popcll(mc); } }
+#endif
+      const float4 n0 = nd[0], n1 = nd[1];
+      at_leaf = node_step(n0, n1, inv, off, r, cur, shape, ex);
+      burst--;
+    }
+#endif
     if (active && !at_leaf && cur >= nn) { active = false; pending = true; }   // walked off the end of the tree
 #ifdef HJ_WALK_STATS
+    const unsigned long long t_c = clock64();
+    HJ_STAT(11, t_c - t_b);
     { const unsigned long long m = __ballot(at_leaf); if (m && lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[3] += 1; ws[4] += __popcll(m); } }
 #endif
     if (at_leaf) {
       if (intersect_shape(sc, r, shape, h)) {
         h.id = (int)shape;
-        if (MODE == 1 || (MODE == 2 && any)) active = false;   // occluded shadow ray: nothing to add
+        if (MODE == 1 || (MODE == 2 && any)) { active = false; pending = true; }   // occluded shadow ray (h.id >= 0 tells finish)
         else r.tmax = h.t - kEps;
       }
       cur = ex;
     }
+    HJ_STAT(12, clock64() - t_c);
   }
 #ifdef HJ_WALK_STATS
-  for (int i = 0; i < 8; i++) {      // ws[] lives in whichever lane did the counting: sum over the wave
+  HJ_STAT(13, clock64() - t_begin);
+  for (int i = 0; i < 16; i++) {      // ws[] lives in whichever lane did the counting: sum over the wave
     unsigned long long v = ws[i];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     if (lane == 0 && v) atomicAdd(&g_walk_stats[i], v);
@@ -403,11 +445,13 @@ HJ_DEV v3 checkerboard(const DeviceScene& sc, uint32_t idx, float u, float v) {
 // persistent kernel k_path_wavefront (one launch per batch: camera rays, then the bounce loop).
 
 struct WgShared {                 // LDS of a path workgroup (8.3 KB)
-  uint32_t head;                  // next unread entry of the queue segment being traced
-  uint32_t cnt_hit[kNumTags];     // hits binned by material tag (this bounce)
+  uint32_t head;                  // next unread entry of the merged queue being walked
+  uint32_t cnt_hit[kNumTags];     // hits binned by material tag (this round)
   uint32_t wcnt[kBlockThreads / 64][kNumTags];   // per-wave tag counts of the ordered compaction
-  uint32_t n_next, n_shadow;      // next-bounce rays / shadow rays produced by shade
-  uint32_t n_gen;
+  uint32_t n_ray[2];              // paths in the arrays of each parity (continuing paths, written by shade)
+  uint32_t n_gen;                 // new camera paths the current top-up has appended behind them
+  uint32_t n_shadow;              // shadow records
+  uint32_t n_unocc;               // statistics: unoccluded shadow rays of this round
   float4 nodes[2 * kHotNodes];    // LDS copy of the hottest BVH nodes (same record layout as DeviceScene::nodes)
 };
 
@@ -415,27 +459,48 @@ HJ_DEV void load_hot_nodes(const DeviceScene& sc, WgShared& sh) {
   for (uint32_t i = threadIdx.x; i < 2 * sc.num_hot; i += blockDim.x) sh.nodes[i] = sc.nodes[i];
 }
 
-// reference shader/render.glsl:26-36,149-162.  Needs sh.n_gen == 0 on entry (synced); leaves the count there.
-HJ_DEV void stage_gen_camera(const BatchState& st, const DeviceScene& sc, uint32_t g, WgShared& sh) {
+// Barrier between two stages of a workgroup.  In the tail of a batch the workgroup is down to ONE wave (the others
+// have left the kernel): that wave only has to order its own memory operations and never executes s_barrier again.
+HJ_DEV void wg_sync(uint32_t waves) {
+  if (waves > 1u) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Sample groups of workgroup g: group k of its sequence is global group g + k * num_wg.
+HJ_DEV uint32_t wg_num_groups(const BatchState& st, uint32_t g) {
+  const uint32_t groups = (st.num_blocks * kSlotsPerBlock + 63u) / 64u;
+  return groups > g ? (groups - g + st.num_wg - 1u) / st.num_wg : 0u;
+}
+
+// reference shader/render.glsl:26-36,149-162: camera paths for groups [k0, k0 + ngen) of this workgroup's sample
+// sequence, appended to the path arrays of `parity` behind the n0 continuing paths (positions n0 + sh.n_gen...; the
+// caller guarantees n0 + 64 * ngen <= pool).
+HJ_DEV void stage_gen_camera(const BatchState& st, const DeviceScene& sc, uint32_t g, WgShared& sh, uint32_t parity,
+                             uint32_t n0, uint32_t k0, uint32_t ngen, uint32_t waves) {
   const uint32_t G = st.num_wg;
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t total = st.num_blocks * kSlotsPerBlock;
-  uint32_t* __restrict__ q = st.q_ray[0] + (size_t)g * st.segcap;
-  // this workgroup owns the 64-slot groups g, g+G, g+2G, ...
-  for (uint32_t grp = g + wave * G; grp * 64u < total; grp += waves * G) {
-    const uint32_t slot = grp * 64u + lane;
-    bool valid = slot < total;
+  const uint32_t seg = g * st.pool + n0;
+  for (uint32_t k = k0 + wave; k < k0 + ngen; k += waves) {
+    const uint32_t smp = (g + k * G) * 64u + lane;
+    bool valid = smp < total;
     hj_image_block b;
     uint32_t lx = 0, ly = 0;
     if (valid) {
-      b = st.blocks[slot / kSlotsPerBlock];
-      lx = slot & (HJ_BLOCK_SIZE - 1u);
-      ly = (slot / HJ_BLOCK_SIZE) & (HJ_BLOCK_SIZE - 1u);
+      b = st.blocks[smp / kSlotsPerBlock];
+      lx = smp & (HJ_BLOCK_SIZE - 1u);
+      ly = (smp / HJ_BLOCK_SIZE) & (HJ_BLOCK_SIZE - 1u);
       valid = lx < b.dimension[0] && ly < b.dimension[1];
       // render.glsl:152 compares the LOCAL id with the image size
       valid = valid && lx < b.original_dimension[0] && ly < b.original_dimension[1];
     }
+    const uint32_t qi = lds_push(&sh.n_gen, valid);
     if (valid) {
+      const uint32_t pos = seg + qi;
       const uint32_t seed = b.seed + lx + ly * b.dimension[0];          // render.glsl:156
       const uint32_t rng = rng_seed(seed);
       const float W = (float)b.original_dimension[0], H = (float)b.original_dimension[1];
@@ -455,85 +520,116 @@ HJ_DEV void stage_gen_camera(const BatchState& st, const DeviceScene& sc, uint32
       const v3 c2 = cross3(txyz, cq);
       const v3 rot = V((c2.x + txyz.x * qw) + cq.x * tw, (c2.y + txyz.y * qw) + cq.y * tw, (c2.z + txyz.z * qw) + cq.z * tw);
       const v3 d = normalize3(rot);
-      stp(st.ray_o, slot, make_float4(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2], 0.f));
-      stp(st.ray_d, slot, make_float4(d.x, d.y, d.z, __uint_as_float(rng)));   // the RNG state rides in direction.w
-      stp(st.thr, slot, make_float4(1.f, 1.f, 1.f, __uint_as_float(1u)));   // wasDiscrete = true
-      if (sc.has_extinction) stp(st.ext, slot, make_float4(0.f, 0.f, 0.f, 0.f));
-      stp(st.smp_rgb, slot, make_float4(0.f, 0.f, 0.f, 1.f));
-      stp(st.smp_nd, slot, make_float4(0.f, 0.f, 0.f, 0.f));
+      // the sample index rides in origin.w, the RNG state in direction.w
+      stp(st.ray_o[parity], pos, make_float4(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2], __uint_as_float(smp | kCameraFlag)));
+      stp(st.ray_d[parity], pos, make_float4(d.x, d.y, d.z, __uint_as_float(rng)));
+      stp(st.thr[parity], pos, make_float4(1.f, 1.f, 1.f, __uint_as_float(1u)));   // wasDiscrete = true, bounce 0
+      if (sc.has_extinction) stp(st.ext[parity], pos, make_float4(0.f, 0.f, 0.f, 0.f));
+      stp(st.smp_rgb, smp, make_float4(0.f, 0.f, 0.f, 1.f));
+      stp(st.smp_nd, smp, make_float4(0.f, 0.f, 0.f, 0.f));
     }
-    const uint32_t qi = lds_push(&sh.n_gen, valid);
-    if (valid) q[qi] = slot;
   }
 }
 
-HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uint32_t g, const uint32_t* __restrict__ q,
-                                uint32_t n, WgShared& sh, uint32_t waves);
+// reference shader/scene.glsl:134-158 with a run-time any-hit switch (linear-scan mode of the merged walk)
+HJ_DEV void linear_scan(const DeviceScene& sc, Ray r, RawHit& h, bool any) {
+  h.id = -1;
+  if (sc.ns > 100 || sc.nq > 100) return;  // scene.glsl:135-138
+  const uint32_t total = sc.ns + sc.nq + sc.nt;
+  for (uint32_t s = 0; s < total; s++) {
+    if (intersect_shape(sc, r, s, h)) {
+      h.id = (int)s;
+      if (any) return;
+      r.tmax = h.t - kEps;
+    }
+  }
+}
 
-// Closest-hit walk over this workgroup's n rays of q_ray[parity]; hits binned by material tag.
-// Needs sh.head == 0, sh.cnt_hit[] == 0 and the hot nodes loaded (synced); leaves the tag counts in sh.cnt_hit.
+// One walk phase for BOTH ray kinds of a round: the n closest-hit rays of the paths in flight (arrays of `parity`)
+// and the ns shadow rays that shade produced in the previous round are one queue [0, n + ns).  The two are
+// independent (the next bounce ray never waits for the NEE visibility), so tracing them together halves the number
+// of walk phases per bounce - each of which ends with the workgroup waiting for its slowest ray - and halves the
+// chain of dependent walks of a deep path.  Per path the radiance additions keep the reference's order: NEE of
+// bounce k-1 is added during this phase, emission of bounce k in the shade that follows the barrier.  A closest-hit
+// ray only records its hit (objectID -1 = miss); an unoccluded shadow ray adds its NEE radiance (render.glsl:122-124).
+// Needs sh.head == 0 and the hot nodes loaded (synced).
 template <bool USE_BVH>
-HJ_DEV void stage_trace_closest(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t n,
-                                float tmin, WgShared& sh) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t* __restrict__ q = st.q_ray[parity] + (size_t)g * st.segcap;
-  // A finished ray only records its hit (objectID -1 = miss).  The hit queues are built afterwards in QUEUE order
-  // (below), not in finishing order, so that the paths a shading wave touches stay close together in memory.
-  auto finish = [&](bool done, uint32_t slot, const RawHit& h, bool) {
-    if (done) stp(st.hit, slot, make_float4(h.t, __int_as_float(h.id), h.u, h.v));
+HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t n,
+                               uint32_t ns, WgShared& sh) {
+  const uint32_t seg = g * st.pool;
+  const float4* __restrict__ ro = st.ray_o[parity] + seg;
+  const float4* __restrict__ rd = st.ray_d[parity] + seg;
+  uint32_t unocc = 0;                                               // wave-uniform count (statistics)
+  auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r, bool& any) {
+    any = i >= n;
+    slot = any ? i - n : i;                                         // position in the path / shadow arrays
+    float4 o, d;
+    if (any) { o = ldp(st.sh_o + seg, slot); d = ldp(st.sh_d + seg, slot); }
+    else { o = ldp(ro, slot); d = ldp(rd, slot); }
+    r.o = xyz(o); r.d = xyz(d);
+    r.tmin = (!any && (__float_as_uint(o.w) & kCameraFlag) != 0u) ? kEps : 2.0f * kEps;   // render.glsl:33,132; scene.glsl:85
+    r.tmax = any ? d.w : kInf;
+  };
+  auto finish = [&](bool done, uint32_t slot, const RawHit& h, bool any) {   // wave-convergent
+    if (done && !any) stp(st.hit + seg, slot, make_float4(h.t, __int_as_float(h.id), h.u, h.v));
+    const bool add = done && any && h.id < 0;       // unoccluded shadow ray: render.glsl:123
+    if (add) {
+      const float4 cc = ldp(st.sh_c + seg, slot);
+      const uint32_t smp = __float_as_uint(cc.w);
+      float4 s = ldp(st.smp_rgb, smp);
+      s.x += cc.x; s.y += cc.y; s.z += cc.z;
+      stp(st.smp_rgb, smp, s);
+    }
+    unocc += (uint32_t)__popcll(__ballot(add));
   };
   if (USE_BVH) {
-    auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r, bool&) {
-      slot = q[i];
-      const float4 o = ldp(st.ray_o, slot), d = ldp(st.ray_d, slot);
-      r.o = xyz(o); r.d = xyz(d); r.tmin = tmin; r.tmax = kInf;
-    };
-    trace_persistent<0>(sc, n, &sh.head, sh.nodes, fetch, finish);
+    trace_persistent<2>(sc, n + ns, &sh.head, sh.nodes, fetch, finish);
   } else {
+    const uint32_t lane = threadIdx.x & 63u;
     for (;;) {
       const uint32_t c = lds_fetch_chunk(&sh.head);
-      if (c >= n) break;
+      if (c >= n + ns) break;
       const uint32_t i = c + lane;
-      const bool valid = i < n;
+      const bool valid = i < n + ns;
       uint32_t slot = 0;
+      bool any = false;
       RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
       if (valid) {
-        slot = q[i];
-        const float4 o = ldp(st.ray_o, slot), d = ldp(st.ray_d, slot);
-        Ray r; r.o = xyz(o); r.d = xyz(d); r.tmin = tmin; r.tmax = kInf;
-        traverse<false, false>(sc, r, h);
+        Ray r;
+        fetch(i, slot, r, any);
+        linear_scan(sc, r, h, any);
       }
-      finish(valid, slot, h, false);
+      finish(valid, slot, h, any);
     }
   }
-  compact_hits_by_tag(st, sc, g, q, n, sh, blockDim.x >> 6);
+  if ((threadIdx.x & 63u) == 0 && unocc != 0) atomicAdd(&sh.n_unocc, unocc);
 }
 
-// Ordered compaction of the hits of this workgroup's n closest-hit rays (queue q) by material tag.
+// Ordered compaction of the hits of this workgroup's n closest-hit rays by material tag (divergent-BSDF sort): every
+// wave takes a contiguous range of queue rows, counts its hits per tag, then (after a prefix over the waves) writes
+// the positions to their final places - queue order, not finishing order, so that the paths a shading wave touches
+// stay close together in memory.  Paths whose ray missed are over (render.glsl:94-96): nothing refers to them again.
 // Starts with a barrier (all hit records written); needs sh.cnt_hit[] == 0; leaves the tag counts there.
-// `waves` = waves of the workgroup that take part (the fused kernel drops to one wave for small rounds).
-HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uint32_t g, const uint32_t* __restrict__ q,
-                                uint32_t n, WgShared& sh, uint32_t waves) {
+// `waves` = waves of the workgroup that take part.
+HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t n, WgShared& sh,
+                                uint32_t waves) {
   const uint32_t G = st.num_wg;
   const uint32_t lane = threadIdx.x & 63u;
-  // Ordered compaction by material tag (divergent-BSDF sort): every wave takes a contiguous range of queue rows,
-  // counts its hits per tag, then (after a prefix over the waves) writes them at their final positions.
-  __syncthreads();
+  const float4* __restrict__ hit = st.hit + g * st.pool;
+  wg_sync(waves);
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t rows = (n + 63u) >> 6, rpw = (rows + waves - 1u) / waves;
   const uint32_t r0 = wave * rpw < rows ? wave * rpw : rows, r1 = r0 + rpw < rows ? r0 + rpw : rows;
-  auto tag_of = [&](uint32_t i, uint32_t& slot) -> uint32_t {
+  auto tag_of = [&](uint32_t i) -> uint32_t {
     if (i >= n) return 0xFFu;
-    slot = q[i];
-    const int id = __float_as_int(ldp(st.hit, slot).y);
+    const int id = __float_as_int(ldp(hit, i).y);
     return id >= 0 ? sc.materials[id] >> HJ_MATERIAL_TAG_SHIFT : 0xFFu;
   };
   uint32_t cnt[kNumTags];
 #pragma unroll
   for (uint32_t k = 0; k < kNumTags; k++) cnt[k] = 0;
   for (uint32_t row = r0; row < r1; row++) {
-    uint32_t slot = 0;
-    const uint32_t tag = tag_of(row * 64u + lane, slot);
+    const uint32_t tag = tag_of(row * 64u + lane);
 #pragma unroll
     for (uint32_t k = 0; k < kNumTags; k++) cnt[k] += (uint32_t)__popcll(__ballot(tag == k));
   }
@@ -541,7 +637,7 @@ HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uin
 #pragma unroll
     for (uint32_t k = 0; k < kNumTags; k++) sh.wcnt[wave][k] = cnt[k];
   }
-  __syncthreads();
+  wg_sync(waves);
   uint32_t base[kNumTags];
 #pragma unroll
   for (uint32_t k = 0; k < kNumTags; k++) {
@@ -549,12 +645,12 @@ HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uin
     for (uint32_t w = 0; w < wave; w++) base[k] += sh.wcnt[w][k];
   }
   for (uint32_t row = r0; row < r1; row++) {
-    uint32_t slot = 0;
-    const uint32_t tag = tag_of(row * 64u + lane, slot);
+    const uint32_t i = row * 64u + lane;
+    const uint32_t tag = tag_of(i);
 #pragma unroll
     for (uint32_t k = 0; k < kNumTags; k++) {
       const unsigned long long mask = __ballot(tag == k);
-      if (tag == k) st.q_hit[((size_t)k * G + g) * st.segcap + base[k] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
+      if (tag == k) st.q_hit[((size_t)k * G + g) * st.pool + base[k] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = i;
       base[k] += (uint32_t)__popcll(mask);
     }
   }
@@ -565,127 +661,61 @@ HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uin
   }
 }
 
-// Any-hit walk over this workgroup's n shadow rays; unoccluded ones add their NEE radiance (render.glsl:122-124).
-// Needs sh.head == 0 and the hot nodes loaded (synced).
-template <bool USE_BVH>
-HJ_DEV void stage_trace_shadow(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t n, WgShared& sh) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t* __restrict__ q = st.q_shadow + (size_t)g * st.segcap;
-  auto add_unoccluded = [&](bool done, uint32_t slot, const RawHit&, bool) {
-    if (done) {
-      const float4 cc = ldp(st.sh_c, slot);
-      float4 s = ldp(st.smp_rgb, slot);
-      s.x += cc.x; s.y += cc.y; s.z += cc.z;      // render.glsl:123
-      stp(st.smp_rgb, slot, s);
-    }
-  };
-  if (USE_BVH) {
-    auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r, bool&) {
-      slot = q[i];
-      const float4 o = ldp(st.ray_o, slot), d = ldp(st.sh_d, slot);
-      r.o = xyz(o); r.d = xyz(d); r.tmin = 2.0f * kEps; r.tmax = d.w;
-    };
-    trace_persistent<1>(sc, n, &sh.head, sh.nodes, fetch, add_unoccluded);
-  } else {
-    for (;;) {
-      const uint32_t c = lds_fetch_chunk(&sh.head);
-      if (c >= n) break;
-      const uint32_t i = c + lane;
-      if (i < n) {
-        const uint32_t slot = q[i];
-        const float4 o = ldp(st.ray_o, slot), d = ldp(st.sh_d, slot);
-        Ray r; r.o = xyz(o); r.d = xyz(d); r.tmin = 2.0f * kEps; r.tmax = d.w;
-        RawHit h;
-        if (!traverse<false, true>(sc, r, h)) add_unoccluded(true, slot, h, true);
-      }
-    }
-  }
-}
-
-// One walk phase for BOTH ray kinds of a bounce round (BVH mode, fused kernel): the n closest-hit rays of bounce k
-// and the ns shadow rays that shade produced at bounce k-1 are one queue [0, n + ns).  The two are independent
-// (the next bounce ray never waits for the NEE visibility), so tracing them together halves the number of walk
-// phases per bounce - each of which ends with the workgroup waiting for its slowest ray - and halves the chain of
-// dependent walks of a deep path, i.e. the tail of the kernel.  Per path the radiance additions keep the
-// reference's order: NEE of bounce k-1 is added during this phase, emission of bounce k in the shade that follows
-// the barrier.  Needs sh.head == 0, sh.cnt_hit[] == 0 and the hot nodes loaded (synced).
-HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t n,
-                               uint32_t ns, float tmin, WgShared& sh, uint32_t waves) {
-  const uint32_t* __restrict__ q = st.q_ray[parity] + (size_t)g * st.segcap;
-  const uint32_t* __restrict__ qs = st.q_shadow + (size_t)g * st.segcap;
-  auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r, bool& any) {
-    any = i >= n;
-    slot = any ? qs[i - n] : q[i];
-    const float4 o = ldp(st.ray_o, slot);
-    float4 d;
-    if (any) d = ldp(st.sh_d, slot); else d = ldp(st.ray_d, slot);
-    r.o = xyz(o); r.d = xyz(d);
-    r.tmin = any ? 2.0f * kEps : tmin;
-    r.tmax = any ? d.w : kInf;
-  };
-  auto finish = [&](bool done, uint32_t slot, const RawHit& h, bool any) {
-    if (done && !any) stp(st.hit, slot, make_float4(h.t, __int_as_float(h.id), h.u, h.v));
-    if (done && any) {                              // unoccluded shadow ray: render.glsl:123
-      const float4 cc = ldp(st.sh_c, slot);
-      float4 s = ldp(st.smp_rgb, slot);
-      s.x += cc.x; s.y += cc.y; s.z += cc.z;
-      stp(st.smp_rgb, slot, s);
-    }
-  };
-  trace_persistent<2>(sc, n + ns, &sh.head, sh.nodes, fetch, finish);
-  compact_hits_by_tag(st, sc, g, q, n, sh, waves);
-}
-
 // reference shader/scene.glsl:160-175 (populate), render.glsl:102-144, material.glsl:18-91.
-// Shades the hits counted in sh.cnt_hit[]; needs sh.n_next == sh.n_shadow == 0 (synced); leaves the counts there.
-HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t bounce,
-                        uint32_t max_bounces, uint32_t rr_start, WgShared& sh, uint32_t waves) {
+// Shades the hits counted in sh.cnt_hit[] (paths of `parity`); the record of a continuing path is written at the
+// next free position of the arrays of parity ^ 1 (sh.n_ray[parity ^ 1]), NEE shadow rays become shadow records
+// (sh.n_shadow).
+HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t max_bounces,
+                        uint32_t rr_start, WgShared& sh, uint32_t waves) {
   const uint32_t G = st.num_wg;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint32_t* __restrict__ q_next = st.q_ray[parity ^ 1u] + (size_t)g * st.segcap;
-  uint32_t* __restrict__ q_sh = st.q_shadow + (size_t)g * st.segcap;
+  const uint32_t seg = g * st.pool;
+  const uint32_t np = parity ^ 1u;
   // one material tag at a time: every wave shades ONE tag (no divergent BSDF switch)
   for (uint32_t tag = 0; tag < kNumTags; tag++) {
     const uint32_t n = sh.cnt_hit[tag];
-    const uint32_t* __restrict__ q = st.q_hit + ((size_t)tag * G + g) * st.segcap;
+    const uint32_t* __restrict__ q = st.q_hit + ((size_t)tag * G + g) * st.pool;
     for (uint32_t base = wave * 64u; base < n; base += waves * 64u) {
     const uint32_t i = base + lane;
     const bool valid = i < n;
     bool alive = false, want_shadow = false;
-    uint32_t slot = 0;
+    v3 T = V(0, 0, 0), wo = V(0, 0, 0), ext = V(0, 0, 0), sdir = V(0, 0, 0), scol = V(0, 0, 0);
+    float stmax = 0.f;
+    Its its; its.p = V(0, 0, 0);
+    uint32_t rng = 0, smp = 0, flags_out = 0;
     if (valid) {
-      slot = q[i];
+      const uint32_t slot = seg + q[i];
       const float4 hr = ldp(st.hit, slot);
-      const float4 ro4 = ldp(st.ray_o, slot), rd4 = ldp(st.ray_d, slot);
-      const float4 th4 = ldp(st.thr, slot);
+      const float4 ro4 = ldp(st.ray_o[parity], slot), rd4 = ldp(st.ray_d[parity], slot);
+      const float4 th4 = ldp(st.thr[parity], slot);
       const v3 ro = xyz(ro4), rd = xyz(rd4);
-      v3 T = xyz(th4);
-      const bool was_discrete = (__float_as_uint(th4.w) & 1u) != 0u;
-      uint32_t rng = __float_as_uint(rd4.w);
+      T = xyz(th4);
+      const uint32_t flags = __float_as_uint(th4.w);
+      const bool was_discrete = (flags & 1u) != 0u;
+      const uint32_t bounce = flags >> 1;
+      smp = __float_as_uint(ro4.w) & ~kCameraFlag;
+      rng = __float_as_uint(rd4.w);
       const uint32_t id = (uint32_t)__float_as_int(hr.y);
-      Its its;
       its.p = V(fmaf(hr.x, rd.x, ro.x), fmaf(hr.x, rd.y, ro.y), fmaf(hr.x, rd.z, ro.z));   // scene.glsl:164
       if (id < sc.ns) populate_sphere(sc.spheres[id], its);
       else if (id < sc.ns + sc.nq) populate_quad(sc, id - sc.ns, hr.z, hr.w, its);
       else populate_triangle(sc, id - sc.ns - sc.nq, hr.z, hr.w, its);
-      if (bounce == 0) stp(st.smp_nd, slot, make_float4(its.n.x, its.n.y, its.n.z, hr.x));   // render.glsl:102-105
+      if (bounce == 0) stp(st.smp_nd, smp, make_float4(its.n.x, its.n.y, its.n.z, hr.x));   // render.glsl:102-105
       const uint32_t mat = sc.materials[id];
       const uint32_t midx = mat & HJ_MATERIAL_INDEX_MASK;
-      v3 ext = V(0, 0, 0);
       if (sc.has_extinction) {                                                             // render.glsl:111-112
-        ext = xyz(ldp(st.ext, slot));
+        ext = xyz(ldp(st.ext[parity], slot));
         const float dist = len3(ro - its.p);
         T = T * V(hj_exp(-ext.x * dist), hj_exp(-ext.y * dist), hj_exp(-ext.z * dist));
       }
-      v3 wo = V(0, 0, 0);
       alive = true;
       switch (tag) {
         case HJ_MAT_EMISSIVE: {
           if (was_discrete) {                                                              // render.glsl:114-116
             const v3 e = T * xyz(sc.emissive[midx]);
-            float4 s = ldp(st.smp_rgb, slot);
+            float4 s = ldp(st.smp_rgb, smp);
             s.x += e.x; s.y += e.y; s.z += e.z;
-            stp(st.smp_rgb, slot, s);
+            stp(st.smp_rgb, smp, s);
           }
           alive = false;   // sampleBSDF weight 0, wo unwritten (material.glsl:88-89)
           break;
@@ -693,14 +723,11 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
         case HJ_MAT_DIFFUSE:
         case HJ_MAT_DIFFUSECBOARD: {
           const v3 color = (tag == HJ_MAT_DIFFUSE) ? xyz(sc.diffuse[midx]) : checkerboard(sc, midx, its.u, its.v);
-          v3 sdir; float stmax;
           const v3 imp = sample_emitter(sc, its.p, rng, sdir, stmax);                      // render.glsl:117-126
           if (len3(imp) > kEps && dot3(sdir, its.n) > 0.0f) {
             const float cs = dot3(its.n, sdir);
             const v3 f = (color * cs) * kInvPi;                                            // material.glsl:18-30
-            const v3 c = (T * f) * imp;
-            stp(st.sh_d, slot, make_float4(sdir.x, sdir.y, sdir.z, stmax));
-            stp(st.sh_c, slot, make_float4(c.x, c.y, c.z, 0.f));
+            scol = (T * f) * imp;
             want_shadow = true;
           }
           const v3 l = rand_cos_hemisphere(rng);                                           // material.glsl:37-46
@@ -750,139 +777,99 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
           else T = divs(T, qq);
         }
         if (bounce + 1u >= max_bounces) alive = false;                                     // render.glsl:92
-        stp(st.ray_d, slot, make_float4(wo.x, wo.y, wo.z, __uint_as_float(rng)));
-        stp(st.thr, slot, make_float4(T.x, T.y, T.z, __uint_as_float(discrete ? 1u : 0u)));
-        if (sc.has_extinction) stp(st.ext, slot, make_float4(ext.x, ext.y, ext.z, 0.f));
+        flags_out = (discrete ? 1u : 0u) | ((bounce + 1u) << 1);
       }
-      stp(st.ray_o, slot, make_float4(its.p.x, its.p.y, its.p.z, 0.f));   // next origin == shadow-ray origin
     }
-    const uint32_t qn = lds_push(&sh.n_next, alive);
-    if (alive) q_next[qn] = slot;
+    // the record of a continuing path goes to its position in the next round's arrays (coalesced append)
+    const uint32_t qn = lds_push(&sh.n_ray[np], alive);
+    if (alive) {
+      const uint32_t pos = seg + qn;
+      stp(st.ray_o[np], pos, make_float4(its.p.x, its.p.y, its.p.z, __uint_as_float(smp)));
+      stp(st.ray_d[np], pos, make_float4(wo.x, wo.y, wo.z, __uint_as_float(rng)));
+      stp(st.thr[np], pos, make_float4(T.x, T.y, T.z, __uint_as_float(flags_out)));
+      if (sc.has_extinction) stp(st.ext[np], pos, make_float4(ext.x, ext.y, ext.z, 0.f));
+    }
     const uint32_t qs = lds_push(&sh.n_shadow, want_shadow);
-    if (want_shadow) q_sh[qs] = slot;
+    if (want_shadow) {
+      const uint32_t pos = seg + qs;
+      stp(st.sh_o, pos, make_float4(its.p.x, its.p.y, its.p.z, 0.f));
+      stp(st.sh_d, pos, make_float4(sdir.x, sdir.y, sdir.z, stmax));
+      stp(st.sh_c, pos, make_float4(scol.x, scol.y, scol.z, __uint_as_float(smp)));
+    }
     }
   }
 }
 
 // ------------------------------------------------------------------ kernels
 
-__global__ __launch_bounds__(kBlockThreads) void k_gen_camera(BatchState st, DeviceScene sc) {
-  __shared__ WgShared sh;
-  const uint32_t g = blockIdx.x;
-  if (threadIdx.x == 0) sh.n_gen = 0;
-  __syncthreads();
-  stage_gen_camera(st, sc, g, sh);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    st.cnt_ray[0][g] = sh.n_gen;
-    st.acc_closest[g] = 0;
-    st.acc_shadow[g] = 0;
-  }
-}
-
-template <bool USE_BVH>
-__global__ __launch_bounds__(kBlockThreads) void k_trace_closest(BatchState st, DeviceScene sc, uint32_t parity,
-                                                                 float tmin) {
-  __shared__ WgShared sh;
-  const uint32_t g = blockIdx.x;
-  const uint32_t n = st.cnt_ray[parity][g];
-  if (threadIdx.x == 0) sh.head = 0;
-  if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
-  if (USE_BVH && n != 0) load_hot_nodes(sc, sh);
-  __syncthreads();
-  stage_trace_closest<USE_BVH>(st, sc, g, parity, n, tmin, sh);
-  __syncthreads();
-  if (threadIdx.x < kNumTags) st.cnt_hit[g * kNumTags + threadIdx.x] = sh.cnt_hit[threadIdx.x];
-  if (threadIdx.x == 0) st.acc_closest[g] += n;
-}
-
-template <bool USE_BVH>
-__global__ __launch_bounds__(kBlockThreads) void k_trace_shadow(BatchState st, DeviceScene sc) {
-  __shared__ WgShared sh;
-  const uint32_t g = blockIdx.x;
-  const uint32_t n = st.cnt_shadow[g];
-  if (threadIdx.x == 0) sh.head = 0;
-  if (USE_BVH && n != 0) load_hot_nodes(sc, sh);
-  __syncthreads();
-  stage_trace_shadow<USE_BVH>(st, sc, g, n, sh);
-}
-
-__global__ __launch_bounds__(kBlockThreads) void k_shade(BatchState st, DeviceScene sc, uint32_t parity,
-                                                         uint32_t bounce, uint32_t max_bounces, uint32_t rr_start) {
-  __shared__ WgShared sh;
-  const uint32_t g = blockIdx.x;
-  if (threadIdx.x == 0) { sh.n_next = 0; sh.n_shadow = 0; }
-  if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = st.cnt_hit[g * kNumTags + threadIdx.x];
-  __syncthreads();
-  stage_shade(st, sc, g, parity, bounce, max_bounces, rr_start, sh, blockDim.x >> 6);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    st.cnt_ray[parity ^ 1u][g] = sh.n_next;
-    st.cnt_shadow[g] = sh.n_shadow;
-    st.acc_shadow[g] += sh.n_shadow;
-  }
-}
-
-// The whole life of a batch in ONE launch: every workgroup generates the camera rays of its slot groups and
-// then loops over bounces {closest-hit walk -> shade -> shadow walk} on its private queue segments until all of
-// its paths are dead.  Workgroups never exchange data, so there is no grid barrier, no host round trip and no
-// per-stage launch; while one workgroup shades (memory bound) its CU neighbours walk the BVH (latency bound).
-// Exit condition every wave reaches: its workgroup's ray count is zero, or max_bounces rounds are done.
+// The whole life of a batch in ONE launch.  Every workgroup walks through ITS samples (64-sample groups g, g + G, ...):
+// rounds of { top-up: new camera paths behind the continuing ones -> ONE walk phase for the closest-hit rays of the
+// paths in flight and the shadow rays of the previous round -> hits compacted by material tag -> shade, which writes
+// the continuing paths compacted into the other parity's arrays } on its private segments.  Workgroups never
+// exchange data, so there is no grid barrier, no host round trip and no per-stage launch; while one workgroup shades
+// (memory bound) its CU neighbours walk the BVH (latency bound).  Path regeneration keeps ~pool paths in flight per
+// workgroup until its samples run out; only then do the rounds shrink, and once a round fits one wave the other
+// waves leave the kernel (their registers and wave slots start workgroups of the next batch) and wave 0 finishes the
+// long paths alone, without barriers.
+// Exit condition every wave reaches: no rays, no shadow rays and no samples left (every path ends: a bounce ends it
+// with probability >= 1 % from bounce rr_start on, and max_bounces caps it).
 #ifndef HJ_TAIL1
 #define HJ_TAIL1 128u    // rays of a round at which the workgroup shrinks to one wave (sweep 64..256: within 1 %)
 #endif
-#ifndef HJ_TAIL2
-#define HJ_TAIL2 512u    // ... to two waves (0 = never; 512 measured +1-2 % on the mirror+glass scene)
-#endif
 #ifndef HJ_PATH_WAVES
-#define HJ_PATH_WAVES 6   // 80 VGPRs (9 spilled): measured 3-4 % faster than 5 (96 VGPRs) and than 8 (64 VGPRs, 33 spilled)
+#define HJ_PATH_WAVES 6   // 80 VGPRs: measured 3-4 % faster than 5 (96 VGPRs) and than 8 (64 VGPRs, 33 spilled)
 #endif
 template <bool USE_BVH>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(HJ_PATH_WAVES, 8))) void k_path_wavefront(BatchState st, DeviceScene sc, uint32_t max_bounces,
                                                                   uint32_t rr_start) {
   __shared__ WgShared sh;
   const uint32_t g = blockIdx.x;
-  if (threadIdx.x == 0) sh.n_gen = 0;
-  if (USE_BVH) load_hot_nodes(sc, sh);
-  __syncthreads();
-  stage_gen_camera(st, sc, g, sh);
-  __syncthreads();
-  uint32_t n = sh.n_gen;
-  uint32_t total_closest = 0, total_shadow = 0;
-  if (USE_BVH) {
-    // round k: walk {closest rays of bounce k + shadow rays of bounce k-1} together, then shade bounce k
-    uint32_t ns = 0;
+  uint32_t groups_left = wg_num_groups(st, g);
+  uint32_t total_closest = 0, total_shadow = 0, total_hits = 0, total_unocc = 0;   // (thread 0's copies are published)
+  if (groups_left != 0) {
+    uint32_t k_next = 0;                     // next group of this workgroup's sample sequence
+    if (threadIdx.x == 0) { sh.n_ray[0] = 0; sh.n_ray[1] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; }
+    if (USE_BVH) load_hot_nodes(sc, sh);
     uint32_t waves = blockDim.x >> 6;
-    for (uint32_t bounce = 0; (bounce < max_bounces && n != 0) || ns != 0; bounce++) {
-      // Tail of the workgroup: once one wave can hold every ray of a round (the counts never grow again), waves
-      // 1.. leave the kernel and free their registers and wave slots for the workgroups still waiting to start;
-      // wave 0 finishes the paths alone (barriers only wait for waves that have not ended).  A handful of paths
-      // bounce on for tens (diffuse) to hundreds (mirror, glass) of rounds after their neighbours are dead.
-      if (waves > 2u && n + ns <= HJ_TAIL2) {
-        if (threadIdx.x >= 128u) return;
-        waves = 2u;
+    wg_sync(waves);
+    for (uint32_t parity = 0;; parity ^= 1u) {
+      // top-up: new camera paths behind the continuing ones, whole 64-sample groups while they fit
+      const uint32_t n0 = sh.n_ray[parity];
+      const uint32_t ngen = min(groups_left, (st.pool - n0) >> 6);
+      if (ngen != 0) {
+        stage_gen_camera(st, sc, g, sh, parity, n0, k_next, ngen, waves);
+        k_next += ngen;
+        groups_left -= ngen;
+        wg_sync(waves);
       }
-      if (waves > 1u && n + ns <= HJ_TAIL1) {
+      const uint32_t n = n0 + sh.n_gen, ns = sh.n_shadow;
+      if (n + ns == 0) {
+        if (groups_left == 0) break;
+        continue;                            // every sample of the new groups lay outside its block: next groups
+      }
+      // Tail of the workgroup: one wave can hold every ray of a round and the counts never grow again.
+      if (waves > 1u && groups_left == 0 && n + ns <= HJ_TAIL1) {
+        wg_sync(waves);                      // (everyone has read the counts)
         if (threadIdx.x >= 64u) return;
         waves = 1u;
       }
-      const uint32_t parity = bounce & 1u;
 #ifdef HJ_WALK_STATS
       const unsigned long long round_t0 = wall_clock64();
       const uint32_t round_rays = n + ns;
 #endif
-      if (threadIdx.x == 0) { sh.head = 0; sh.n_next = 0; sh.n_shadow = 0; }
+      wg_sync(waves);                        // everyone has read the counts before they are reset
+      if (threadIdx.x == 0) { sh.head = 0; sh.n_ray[parity ^ 1u] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; }
       if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
-      __syncthreads();
-      stage_trace_merged(st, sc, g, parity, n, ns, bounce == 0 ? kEps : 2.0f * kEps, sh, waves);   // render.glsl:33,132
-      __syncthreads();
-      if (n != 0) stage_shade(st, sc, g, parity, bounce, max_bounces, rr_start, sh, waves);
-      __syncthreads();
+      wg_sync(waves);
+      stage_trace_merged<USE_BVH>(st, sc, g, parity, n, ns, sh);
+      compact_hits_by_tag(st, sc, g, n, sh, waves);
+      wg_sync(waves);
+      if (n != 0) stage_shade(st, sc, g, parity, max_bounces, rr_start, sh, waves);
       total_closest += n;
       total_shadow += ns;
-      n = sh.n_next;
-      ns = sh.n_shadow;
-      __syncthreads();                       // everyone has read n_next / n_shadow before they are reset
+      for (uint32_t k = 0; k < kNumTags; k++) total_hits += sh.cnt_hit[k];
+      total_unocc += sh.n_unocc;
+      wg_sync(waves);
 #ifdef HJ_WALK_STATS
       if (threadIdx.x == 0) {
         uint32_t b = 0;
@@ -893,32 +880,83 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
       }
 #endif
     }
-    if (threadIdx.x == 0) {
-      st.acc_closest[g] = total_closest;
-      st.acc_shadow[g] = total_shadow;
-    }
-    return;
-  }
-  for (uint32_t bounce = 0; bounce < max_bounces && n != 0; bounce++) {
-    const uint32_t parity = bounce & 1u;
-    if (threadIdx.x == 0) { sh.head = 0; sh.n_next = 0; sh.n_shadow = 0; }
-    if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
-    __syncthreads();
-    stage_trace_closest<USE_BVH>(st, sc, g, parity, n, bounce == 0 ? kEps : 2.0f * kEps, sh);   // render.glsl:33,132
-    __syncthreads();
-    stage_shade(st, sc, g, parity, bounce, max_bounces, rr_start, sh, blockDim.x >> 6);
-    if (threadIdx.x == 0) sh.head = 0;       // the closest-hit walk is over (barrier above); shade does not use it
-    __syncthreads();
-    const uint32_t ns = sh.n_shadow;
-    total_closest += n;
-    total_shadow += ns;
-    n = sh.n_next;
-    stage_trace_shadow<USE_BVH>(st, sc, g, ns, sh);
-    __syncthreads();                         // everyone has read n_next / n_shadow before they are reset
   }
   if (threadIdx.x == 0) {
     st.acc_closest[g] = total_closest;
     st.acc_shadow[g] = total_shadow;
+    st.acc_hits[g] = total_hits;
+    st.acc_unoccluded[g] = total_unocc;
+  }
+}
+
+// ---- split-kernel path (HJ_RENDER_SPLIT_KERNELS): the same stage functions, one launch per stage per bounce, for
+// per-stage timing and counters.  No regeneration: the pool holds every sample of the workgroup (hj_api.hip sizes
+// it so) and k_gen_camera starts them all.
+
+__global__ __launch_bounds__(kBlockThreads) void k_gen_camera(BatchState st, DeviceScene sc) {
+  __shared__ WgShared sh;
+  const uint32_t g = blockIdx.x;
+  if (threadIdx.x == 0) sh.n_gen = 0;
+  __syncthreads();
+  stage_gen_camera(st, sc, g, sh, 0, 0, 0, wg_num_groups(st, g), blockDim.x >> 6);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st.cnt_ray[0][g] = sh.n_gen;
+    st.cnt_shadow[g] = 0;
+    st.acc_closest[g] = 0;
+    st.acc_shadow[g] = 0;
+    st.acc_hits[g] = 0;
+    st.acc_unoccluded[g] = 0;
+  }
+}
+
+template <bool USE_BVH>
+__global__ __launch_bounds__(kBlockThreads) void k_trace_closest(BatchState st, DeviceScene sc, uint32_t parity) {
+  __shared__ WgShared sh;
+  const uint32_t g = blockIdx.x;
+  const uint32_t n = st.cnt_ray[parity][g];
+  if (threadIdx.x == 0) { sh.head = 0; sh.n_unocc = 0; }
+  if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
+  if (USE_BVH && n != 0) load_hot_nodes(sc, sh);
+  __syncthreads();
+  stage_trace_merged<USE_BVH>(st, sc, g, parity, n, 0, sh);
+  compact_hits_by_tag(st, sc, g, n, sh, blockDim.x >> 6);
+  __syncthreads();
+  if (threadIdx.x < kNumTags) st.cnt_hit[g * kNumTags + threadIdx.x] = sh.cnt_hit[threadIdx.x];
+  if (threadIdx.x == 0) {
+    st.acc_closest[g] += n;
+    uint32_t hits = 0;
+    for (uint32_t k = 0; k < kNumTags; k++) hits += sh.cnt_hit[k];
+    st.acc_hits[g] += hits;
+  }
+}
+
+template <bool USE_BVH>
+__global__ __launch_bounds__(kBlockThreads) void k_trace_shadow(BatchState st, DeviceScene sc) {
+  __shared__ WgShared sh;
+  const uint32_t g = blockIdx.x;
+  const uint32_t ns = st.cnt_shadow[g];
+  if (threadIdx.x == 0) { sh.head = 0; sh.n_unocc = 0; }
+  if (USE_BVH && ns != 0) load_hot_nodes(sc, sh);
+  __syncthreads();
+  stage_trace_merged<USE_BVH>(st, sc, g, 0, 0, ns, sh);
+  __syncthreads();
+  if (threadIdx.x == 0) st.acc_unoccluded[g] += sh.n_unocc;
+}
+
+__global__ __launch_bounds__(kBlockThreads) void k_shade(BatchState st, DeviceScene sc, uint32_t parity,
+                                                         uint32_t max_bounces, uint32_t rr_start) {
+  __shared__ WgShared sh;
+  const uint32_t g = blockIdx.x;
+  if (threadIdx.x == 0) { sh.n_ray[parity ^ 1u] = 0; sh.n_shadow = 0; }
+  if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = st.cnt_hit[g * kNumTags + threadIdx.x];
+  __syncthreads();
+  stage_shade(st, sc, g, parity, max_bounces, rr_start, sh, blockDim.x >> 6);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st.cnt_ray[parity ^ 1u][g] = sh.n_ray[parity ^ 1u];
+    st.cnt_shadow[g] = sh.n_shadow;
+    st.acc_shadow[g] += sh.n_shadow;
   }
 }
 

@@ -170,8 +170,11 @@ typedef struct hj_render_stats {
   double   reconstruct_ms;
   double   total_ms;         /* host wall time of the call (all batches, both streams) */
   uint64_t closest_launches; /* number of closest-hit kernel launches timed         */
-  double   path_ms;          /* HIP-event time of the fused k_path_wavefront launches */
+  double   path_ms;          /* HIP-event time of the fused k_path_wavefront launches (sum; launches overlap) */
   uint64_t path_launches;
+  uint64_t hits;             /* closest-hit rays that hit a shape                   */
+  uint64_t unoccluded_shadow_rays; /* shadow rays that reached their light           */
+  double   path_busy_ms;     /* union of the path kernels' intervals = their exclusive GPU time (if timed) */
 } hj_render_stats;
 
 typedef struct hj_context hj_context;

@@ -1,27 +1,39 @@
-"""Wave-level occupancy of the walk's phases (needs the diagnostic build: tools/build_variant.sh stats -DHJ_WALK_STATS)."""
-import sys, os, ctypes as C
+"""Wave-level occupancy of the walk's phases (needs the diagnostic build: tools/build_variant.sh stats -DHJ_WALK_STATS).
+
+    python tools/walk_stats.py KIND [MAX_BOUNCES] [--json OUT]     env: HJ_STATS_SPP (16), HJ_STATS_SIZE (1024), HJ_STATS_TRIS
+"""
+import sys, os, json, ctypes as C
 os.environ.setdefault("HIJIKI_HIP_LIB", "hijiki_amd/lib/var_stats.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hijiki_amd import host, device
-kind = int(sys.argv[1]) if len(sys.argv) > 1 else host.SYNTH_CBOX
-max_bounces = int(sys.argv[2]) if len(sys.argv) > 2 else 0     # 1 = camera rays and their shadow rays only
-cs = host.Scene.synthetic(kind).compile()
-r = device.Renderer(0); r.upload_scene(cs); r.create_framebuffer(1024, 1024)
+argv = [a for a in sys.argv[1:]]
+js = None
+if "--json" in argv:
+    js = argv[argv.index("--json") + 1]
+    del argv[argv.index("--json"):argv.index("--json") + 2]
+kind = int(argv[0]) if len(argv) > 0 else host.SYNTH_CBOX
+max_bounces = int(argv[1]) if len(argv) > 1 else 0     # 1 = camera rays and their shadow rays only
+spp = int(os.environ.get("HJ_STATS_SPP", "16")); size = int(os.environ.get("HJ_STATS_SIZE", "1024"))
+cs = host.Scene.synthetic(kind, mesh_triangles=int(os.environ.get("HJ_STATS_TRIS", "0"))).compile()
+r = device.Renderer(0); r.upload_scene(cs); r.create_framebuffer(size, size)
 L = device.lib()
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 L.hj_debug_walk_stats(out, 1)
 rs = (C.c_ulonglong * 24)()
 L.hj_debug_round_stats(rs, 1)
 o = device.default_opts()
 if max_bounces:
     o.max_bounces = max_bounces
-st = r.render_frame(16, 1, opts=o)
+st = r.render_frame(spp, 1, opts=o)
 L.hj_debug_walk_stats(out, 1)
 o = list(out)
 rays = st["closest_rays"] + st["shadow_rays"]
+steps = o[1] + o[8]
 print(f"rays {rays/1e6:.1f} M; outer iterations {o[0]/1e6:.2f} M, active lanes at their start {o[7]/max(1,o[0]):.1f}")
-print(f"inner wave-steps {o[1]/1e6:.2f} M with {o[2]/max(1,o[1]):.1f} lanes  ({o[2]/rays:.1f} lane-steps per ray; {o[1]/max(1,o[0]):.2f} wave-steps per outer iteration)")
+print(f"box wave-steps {steps/1e6:.2f} M with {(o[2]+o[9])/max(1,steps):.1f} lanes  ({(o[2]+o[9])/rays:.1f} lane-steps per ray, {o[14]/rays:.2f} of them on nodes outside the LDS copy; {steps/max(1,o[0]):.2f} wave-steps per outer iteration)")
 print(f"leaf phases {o[3]/1e6:.2f} M with {o[4]/max(1,o[3]):.1f} lanes  ({o[4]/rays:.2f} leaf tests per ray; in {100*o[3]/max(1,o[0]):.0f} % of outer iterations)")
+tot = max(1, o[13])
+print(f"wave cycles in the walk: service {100*o[10]/tot:.1f} %, box steps {100*o[11]/tot:.1f} %, leaf tests {100*o[12]/tot:.1f} %; per outer iteration {o[13]/max(1,o[0]):.0f} cycles; per box wave-step {o[11]/max(1,steps):.0f}; per leaf phase {o[12]/max(1,o[3]):.0f}; per refill {o[10]/max(1,o[5]):.0f}")
 print(f"refills {o[5]/1e6:.2f} M with {o[6]/max(1,o[5]):.1f} rays each")
 L.hj_debug_round_stats(rs, 1)
 rs = list(rs)
@@ -29,8 +41,17 @@ tot_c = sum(rs[16:24]) or 1
 tot_r = sum(rs[8:16]) or 1
 print("rounds of the fused kernel by size (rays in the round): share of rays vs share of wave-time")
 lo = 0
+hist = []
 for b in range(8):
     hi = 16 << (2 * b)
     if rs[b]:
         print(f"  [{lo:6d}, {hi if b < 7 else 10**9:>10d}): {rs[b]/1e3:9.1f} k rounds, {100*rs[8+b]/tot_r:5.1f} % of rays, {100*rs[16+b]/tot_c:5.1f} % of wave-time")
+        hist.append({"rays_lo": lo, "rays_hi": hi, "rounds": rs[b], "share_of_rays": rs[8+b]/tot_r, "share_of_wave_time": rs[16+b]/tot_c})
     lo = hi
+if js:
+    json.dump({"kind": kind, "size": size, "spp": spp, "rays": rays, "paths": st["paths"],
+               "box_lane_steps_per_ray": (o[2] + o[9]) / rays, "cold_node_steps_per_ray": o[14] / rays,
+               "leaf_tests_per_ray": o[4] / rays, "lanes_per_box_step": (o[2] + o[9]) / max(1, steps),
+               "lanes_per_leaf_phase": o[4] / max(1, o[3]), "active_lanes": o[7] / max(1, o[0]),
+               "cycle_share": {"service": o[10] / tot, "box": o[11] / tot, "leaf": o[12] / tot},
+               "rounds": hist}, open(js, "w"), indent=1)
