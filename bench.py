@@ -40,11 +40,11 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before torch initialises HIP
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (about 6.3 TB/s achievable)
 
 CONFIGS = {
-    "c2": dict(kind="cbox", tris=0, size=1024, spp=512,
+    "c2": dict(kind="cbox", short="cbox", tris=0, size=1024, spp=512,
                name="cbox-synth {W}x{H} {spp}spp diffuse+emissive, 6332 triangles"),
-    "c3": dict(kind="spheres", tris=0, size=1024, spp=1024,
+    "c3": dict(kind="spheres", short="cbox+mirror+dielectric spheres", tris=0, size=1024, spp=1024,
                name="cbox-synth + mirror sphere + dielectric sphere {W}x{H} {spp}spp, 6332 triangles + 2 spheres"),
-    "c4": dict(kind="mesh", tris=1_000_000, size=2048, spp=256,
+    "c4": dict(kind="mesh", short="1M-triangle mesh", tris=1_000_000, size=2048, spp=256,
                name="synthetic 1M-triangle mesh in the box {W}x{H} {spp}spp"),
 }
 
@@ -109,6 +109,52 @@ def cpu_baseline(cs, width, height, total_spp, seed, label, budget_s=12.0):
             "sample": f"{spp} of the {total_spp} passes of {label} {width}x{height} (oracle/hj_oracle.c, {cores} threads, {secs:.2f} s)"}
 
 
+def main_inproc(args, cfg):
+    """The multi-GPU frame without torch: one context per GPU in this process, frames in flight on all of them at once
+    (each context's worker thread), one RCCL reduce through a communicator object that is created once."""
+    from hijiki_amd import abi, device, host
+    n = args.gpus
+    if device.device_count() < n:
+        raise SystemExit(f"--inproc --gpus {n}: only {device.device_count()} GPU(s) visible")
+    kind = {"cbox": host.SYNTH_CBOX, "spheres": host.SYNTH_CBOX_SPHERES, "mesh": host.SYNTH_CBOX_MESH}[cfg["kind"]]
+    cs = host.Scene.synthetic(kind, mesh_triangles=cfg["tris"]).compile()
+    W, H, spp = args.width or cfg["size"], args.height or cfg["size"], args.spp or cfg["spp"]
+    rs = [device.Renderer(i) for i in range(n)]
+    for r in rs:
+        r.upload_scene(cs)
+        r.create_framebuffer(W, H)
+    comm = device.Comm(rs)
+    opts = device.default_opts()
+    opts.flags = abi.RENDER_TIME_KERNELS
+
+    def step():
+        for r in rs:
+            r.clear()
+        for i, r in enumerate(rs):
+            r.render_frame_async(spp, args.seed, rank=i, world=n, opts=opts)
+        comm.reduce(0)                                   # joins every frame, then the RCCL sum into GPU 0
+        return [r.sync() for r in rs]
+
+    for _ in range(args.warmup):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    elapsed = time.perf_counter() - t0                   # comm.reduce returns after every stream has been synchronised
+    paths = W * H * spp * args.steps
+    out = {"metric": f"Mrays/s (camera paths/s) at {spp}spp, {cfg['short']} {W}x{H}", "value": round(paths / elapsed / 1e6, 3),
+           "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{args.config}: {cfg['name'].format(W=W, H=H, spp=spp)}, BVH, block 128, seed {args.seed}",
+                      "partition": f"ImageBlock (bx, by) of pass p -> GPU (bx + by + p) mod {n}; one process, hj_render_frame_async per "
+                                   f"context, hj_comm_reduce_framebuffers (RCCL sum of the {W}x{H} RGBA32F framebuffers)"}}
+    print(json.dumps(out), flush=True)
+    comm.close()
+    for r in rs:
+        r.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,8 +166,13 @@ def main():
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inproc", action="store_true",
+                    help="ONE process drives all --gpus GPUs through the C ABI alone (hj_render_frame_async per context, "
+                         "hj_comm_reduce_framebuffers): no torch, no torchrun")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    if args.inproc:
+        return main_inproc(args, cfg)
 
     import torch
     import torch.distributed as dist
@@ -169,7 +220,7 @@ def main():
         paths = W * H * spp * args.steps
         label = cfg["name"].format(W=W, H=H, spp=spp)
         out = {
-            "metric": f"Mrays/s (camera paths/s) at {spp}spp, {cfg['kind'] if args.config != 'c2' else 'cbox'} {W}x{H}",
+            "metric": f"Mrays/s (camera paths/s) at {spp}spp, {cfg['short']} {W}x{H}",
             "value": round(paths / elapsed / 1e6, 3),
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -185,7 +236,7 @@ def main():
                        "partition": f"ImageBlock (bx, by) of pass p -> rank (bx + by + p) mod {world}, RCCL sum-reduce of the {W}x{H} RGBA32F framebuffer"},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cs, W, H, spp, args.seed, cfg["kind"])
+            out["cpu_baseline"] = cpu_baseline(cs, W, H, spp, args.seed, cfg["short"])
 
         # ---- roofline of the dominant kernel, from THIS run's device counters and HIP events (rank 0's launches)
         inputs, src = roofline_inputs(args.config) if standard and world == 1 else (None, None)

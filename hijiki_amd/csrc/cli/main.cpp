@@ -106,6 +106,12 @@ int main(int argc, char** argv) {
     hj_default_render_opts(&ro);
     ro.use_bvh = opt.use_bvh ? 1u : 0u;                                // --use-bvh, src/main.rs:1432-1434
     hj_render_stats st;
+    // the window title of the preview shows the percentage, updated every --present-interval blocks (src/main.rs:1335-1340)
+    hj_set_progress_callback(ctx, [](void*, uint64_t done, uint64_t total) {
+      std::fprintf(stderr, "\r%3.3f%% %llu/%llu", 100.0 * (double)done / (double)(total ? total : 1),      // the title's format
+                   (unsigned long long)done, (unsigned long long)total);
+      if (done >= total) std::fprintf(stderr, "\n");
+    }, nullptr, opt.present_interval);
     std::printf("Starting to render...\n");                            // src/main.rs:1488
     const auto t0 = std::chrono::steady_clock::now();
     check(ctx, hj_render_frame(ctx, opt.sample_count, opt.seed, 0, opt.sample_count, 0, 1, &ro, &st), "render");

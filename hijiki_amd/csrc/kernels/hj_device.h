@@ -18,6 +18,9 @@ constexpr uint32_t kEmitRecF4 = 7;
 #endif
 constexpr uint32_t kHotNodes = HJ_HOT_NODES;
 constexpr uint32_t kInnerFlag = 0x80000000u;
+#ifndef HJ_LEAF_INLINE
+#define HJ_LEAF_INLINE 0    // 1 = leaves carry their shape in the node array (two 32-byte slots): measured -3 % (cbox), -1 % (1 M triangles)
+#endif
 
 // Scene data in HBM.  `nodes` are 32-byte records (two float4 per node) derived from the reference's
 // skip-link array (same tree, same boxes, same visiting order) but RE-INDEXED: the kHotNodes nodes with the
@@ -26,6 +29,12 @@ constexpr uint32_t kInnerFlag = 0x80000000u;
 // record" no longer holds, links are explicit:
 //   n0 = (aabb_min.xyz, A)   A = shape index for a leaf, 0x80000000 | left-child index for an inner node
 //   n1 = (aabb_max.xyz, B)   B = exit index (>= num_nodes ends the walk)
+// A LEAF record (HJ_LEAF_INLINE) takes TWO consecutive 32-byte slots and holds the shape itself where an inner node
+// holds its box (a leaf's box is never tested, scene.glsl:105-119):
+//   triangle: (a.xyz, A) (b-a .xyz, B) (c-a .xyz, -) (-)     quad: (origin, A) (edge1, B) (edge2, -) (-)
+//   sphere:   (centre.xyz, A) (radius, -, -, B)
+// so the leaf test reads the line the box step has just fetched instead of a record of another array (one dependent
+// fetch fewer per leaf).  Indices (left child, exit, root, num_nodes, num_hot) count 32-byte slots.
 // The walk starts at `root`.  Triangles are additionally pre-gathered per
 // triangle so that a leaf test is ONE dependent fetch instead of the
 // reference's index -> vertex chain (shader/shapes/triangle.glsl:16-18):

@@ -122,6 +122,26 @@ HJ_DEV bool intersect_quad(const DeviceScene& sc, const Ray& r, uint32_t ix, Raw
   return false;
 }
 
+// The leaf test on an inline leaf record (hj_device.h): the same arithmetic as intersect_triangle / _quad / _sphere on
+// values that are copies of the ones those read.
+HJ_DEV bool intersect_leaf(const DeviceScene& sc, const Ray& r, uint32_t shape, const float4* __restrict__ nd, RawHit& h) {
+  const float4 A = nd[0], B = nd[1];
+  if (shape < sc.ns) return intersect_sphere(r, make_float4(A.x, A.y, A.z, B.x), h);
+  const float4 C = nd[2];
+  const v3 e1 = xyz(B), e2 = xyz(C);
+  const v3 n = cross3(e1, e2);
+  const v3 ro = r.o - xyz(A);
+  const v3 q = cross3(ro, r.d);
+  const float d = 1.0f / dot3(r.d, n);
+  const float u = d * (-dot3(q, e2));
+  const float v = d * dot3(q, e1);
+  const bool quad = shape < sc.ns + sc.nq;
+  if (quad ? (u < 0.0f || u > 1.0f || v < 0.0f || v > 1.0f) : (u < 0.0f || v < 0.0f || u + v > 1.0f)) return false;
+  const float t = d * (-dot3(n, ro));
+  if (r.tmin <= t && t <= r.tmax) { h.t = t; h.u = u; h.v = v; return true; }
+  return false;
+}
+
 HJ_DEV bool intersect_shape(const DeviceScene& sc, const Ray& r, uint32_t shape, RawHit& h) {
   if (shape < sc.ns) return intersect_sphere(r, sc.spheres[shape], h);
   if (shape < sc.ns + sc.nq) return intersect_quad(sc, r, shape - sc.ns, h);
@@ -315,7 +335,13 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     { const unsigned long long m = __ballot(at_leaf); if (m && lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[3] += 1; ws[4] += __popcll(m); } }
 #endif
     if (at_leaf) {
-      if (intersect_shape(sc, r, shape, h)) {
+#if HJ_LEAF_INLINE
+      // the record of the leaf the lane stands on (cur has not moved): the line the box step fetched, or the LDS copy
+      const bool found = intersect_leaf(sc, r, shape, (cur < nhot ? s_nodes : sc.nodes) + 2 * cur, h);
+#else
+      const bool found = intersect_shape(sc, r, shape, h);
+#endif
+      if (found) {
         h.id = (int)shape;
         if (MODE == 1 || (MODE == 2 && any)) { active = false; pending = true; }   // occluded shadow ray (h.id >= 0 tells finish)
         else r.tmax = h.t - kEps;
@@ -817,7 +843,7 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
 #define HJ_TAIL1 128u    // rays of a round at which the workgroup shrinks to one wave (sweep 64..256: within 1 %)
 #endif
 #ifndef HJ_PATH_WAVES
-#define HJ_PATH_WAVES 6   // 80 VGPRs: measured 3-4 % faster than 5 (96 VGPRs) and than 8 (64 VGPRs, 33 spilled)
+#define HJ_PATH_WAVES 7   // 72 VGPRs; measured on the compacted-record kernel: 6 waves (80 VGPRs) -6 %, 8 waves (64 VGPRs) -2 %, 5 waves -5 %
 #endif
 template <bool USE_BVH>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(HJ_PATH_WAVES, 8))) void k_path_wavefront(BatchState st, DeviceScene sc, uint32_t max_bounces,

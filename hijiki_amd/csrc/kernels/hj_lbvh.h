@@ -4,10 +4,13 @@
 // (src/main.rs:199-231): one shape per leaf, pre-order numbering (left child = next record), every node stores
 // the box its PARENT kept for it (= the bounds of its own subtree), exit = the record that follows its subtree
 // (the root and every node on the right spine: 1 000 000).  This file produces the same FORMAT for a different
-// topology: shapes sorted along a 30-bit Morton curve of their centroids, hierarchy by longest common prefix
-// (Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees and k-d trees"), bounds by a
-// bottom-up pass.  The image does not depend on the topology except through epsilon-ties; the
-// quality of an LBVH is below the host's binned SAH, so this is the fast start-up path, not the default.
+// topology: shapes sorted along a Morton curve of their centroids (as many bits per axis as a 64-bit key leaves beside
+// the shape index: 14 for a million shapes), hierarchy by longest common prefix (Karras 2012, "Maximizing parallelism
+// in the construction of BVHs, octrees and k-d trees"), bounds by a bottom-up pass.  LARGE shapes (box area above
+// 1/64 of the scene's, e.g. the walls of the box around a mesh) are kept OUT of the Morton tree: sorted by centroid they
+// would sit deep inside it and blow the boxes of all their ancestors up to scene size; they go into a small SAH tree
+// that the host builds over them and the root of the Morton tree (hj_api.hip).  The image does not depend on the
+// topology except through epsilon-ties.
 //
 // Pre-order without a traversal: a subtree over k leaves has 2k - 1 records, so for a node whose subtree covers
 // the sorted leaves [first, first + k)
@@ -36,7 +39,7 @@ struct Tree {                 // working arrays, n = number of shapes
   float4* leaf_lo;            // [n] bounds of shape i (global shape index), w unused
   float4* leaf_hi;
   int* bounds;                // [6] scene bounds of the CENTROIDS as order-preserving ints (min xyz, max xyz)
-  unsigned long long* keys;   // [n] (morton << 32) | shape index
+  unsigned long long* keys;   // [n] large-shape flag (bit 63) | morton << idx_bits | shape index
   uint32_t* child;            // [2 * (n - 1)] left, right of internal node i
   uint32_t* first;            // [n - 1] first sorted leaf of internal node i
   uint32_t* count;            // [n - 1] leaves below internal node i
@@ -104,29 +107,43 @@ __global__ __launch_bounds__(256) void k_shape_boxes(Shapes s, Tree t, uint32_t 
   }
 }
 
-HJ_DEV uint32_t spread10(uint32_t v) {   // 10 bits -> every third bit
-  v = (v | (v << 16)) & 0x030000FFu;
-  v = (v | (v << 8)) & 0x0300F00Fu;
-  v = (v | (v << 4)) & 0x030C30C3u;
-  v = (v | (v << 2)) & 0x09249249u;
+HJ_DEV unsigned long long spread21(unsigned long long v) {   // 21 bits -> every third bit
+  v &= 0x1FFFFFull;
+  v = (v | (v << 32)) & 0x001F00000000FFFFull;
+  v = (v | (v << 16)) & 0x001F0000FF0000FFull;
+  v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+  v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
   return v;
 }
 
-__global__ __launch_bounds__(256) void k_morton_keys(Tree t, uint32_t n) {
+constexpr unsigned long long kBigShape = 1ull << 63;
+
+// idx_bits: bits of the shape index; axis_bits: Morton bits per axis (3 * axis_bits + idx_bits <= 63);
+// big_frac: shapes whose box area exceeds big_frac x the area of the centroid bounds are flagged (and counted in *nbig).
+__global__ __launch_bounds__(256) void k_morton_keys(Tree t, uint32_t n, uint32_t idx_bits, uint32_t axis_bits, float big_frac,
+                                                     uint32_t* nbig) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 lo = t.leaf_lo[i], hi = t.leaf_hi[i];
   const float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
-  uint32_t q[3];
+  unsigned long long q[3];
+  float ext[3];
+  const float scale = (float)(1u << axis_bits);
   for (int k = 0; k < 3; k++) {
     const float mn = unordered(t.bounds[k]), mx = unordered(t.bounds[3 + k]);
     const float e = mx - mn;
+    ext[k] = e > 0.f ? e : 0.f;
     float u = e > 0.f ? (c[k] - mn) / e : 0.f;
     u = u == u ? f_min(f_max(u, 0.f), 1.f) : 0.f;
-    q[k] = (uint32_t)f_min(u * 1024.0f, 1023.0f);
+    q[k] = (unsigned long long)f_min(u * scale, scale - 1.0f);
   }
-  const uint32_t code = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
-  t.keys[i] = ((unsigned long long)code << 32) | i;        // the index makes every key unique
+  const unsigned long long code = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+  const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+  const float area = dx * dy + dy * dz + dz * dx, scene = ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0];
+  const bool big = big_frac > 0.f && scene > 0.f && area > big_frac * scene;
+  if (big) atomicAdd(nbig, 1u);
+  t.keys[i] = (big ? kBigShape : 0ull) | (code << idx_bits) | i;        // the index makes every key unique
 }
 
 // Karras 2012, section 4: internal node i of the radix tree over the sorted (unique) keys.
@@ -175,7 +192,7 @@ HJ_DEV float4 ld_agent(const float4* p) {
 }
 
 // Bounds bottom-up: the second thread to arrive at a node owns it (no waiting: the first one simply leaves).
-__global__ __launch_bounds__(256) void k_refit(Tree t, uint32_t n) {
+__global__ __launch_bounds__(256) void k_refit(Tree t, uint32_t n, unsigned long long idx_mask) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   uint32_t p = t.parent[(n - 1) + k];
@@ -188,7 +205,7 @@ __global__ __launch_bounds__(256) void k_refit(Tree t, uint32_t n) {
     for (int c = 0; c < 2; c++) {
       const uint32_t ch = t.child[2 * node + c];
       if (ch & kLeafBit) {
-        const uint32_t shape = (uint32_t)(t.keys[ch & ~kLeafBit] & 0xFFFFFFFFull);
+        const uint32_t shape = (uint32_t)(t.keys[ch & ~kLeafBit] & idx_mask);
         lo[c] = t.leaf_lo[shape];
         hi[c] = t.leaf_hi[shape];
       } else {
@@ -203,7 +220,9 @@ __global__ __launch_bounds__(256) void k_refit(Tree t, uint32_t n) {
 }
 
 // One record of the reference's flattened array per tree node (internal nodes: threads [0, n-1), leaves: the rest).
-__global__ __launch_bounds__(256) void k_emit(Tree t, uint32_t n, uint32_t root_exit, hj_bvh_node* out) {
+// The tree occupies records [base, base + 2n - 1) of `out`; `end_exit` is the exit of its right spine.
+__global__ __launch_bounds__(256) void k_emit(Tree t, uint32_t n, uint32_t base, uint32_t end_exit, unsigned long long idx_mask,
+                                              hj_bvh_node* out) {
   const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t total = 2 * n - 1;
   if (id >= total) return;
@@ -212,11 +231,11 @@ __global__ __launch_bounds__(256) void k_emit(Tree t, uint32_t n, uint32_t root_
   const uint32_t first = leaf ? k : t.first[id], cnt = leaf ? 1u : t.count[id];
   uint32_t left_turns = 0;
   for (uint32_t p = t.parent[id]; p != kNoParent; p = t.parent[p & ~kLeafBit]) left_turns += p >> 31;
-  const uint32_t pos = 2 * first + left_turns, end = pos + 2 * cnt - 1;
+  const uint32_t pos = base + 2 * first + left_turns, end = pos + 2 * cnt - 1;
   float4 lo, hi;
   uint32_t shape = HJ_BVH_INNER;
   if (leaf) {
-    shape = (uint32_t)(t.keys[k] & 0xFFFFFFFFull);
+    shape = (uint32_t)(t.keys[k] & idx_mask);
     lo = t.leaf_lo[shape];
     hi = t.leaf_hi[shape];
   } else {
@@ -227,7 +246,7 @@ __global__ __launch_bounds__(256) void k_emit(Tree t, uint32_t n, uint32_t root_
   nd.aabb_min[0] = lo.x; nd.aabb_min[1] = lo.y; nd.aabb_min[2] = lo.z;
   nd.shape_index = shape;
   nd.aabb_max[0] = hi.x; nd.aabb_max[1] = hi.y; nd.aabb_max[2] = hi.z;
-  nd.exit_index = end >= total ? root_exit : end;           // right spine: the root's exit (src/main.rs:214-231)
+  nd.exit_index = end >= base + total ? end_exit : end;     // right spine: the exit of the subtree's root (src/main.rs:214-231)
   out[pos] = nd;
 }
 

@@ -20,7 +20,10 @@ EXPORTS = ("hj_context_create", "hj_context_destroy", "hj_last_error", "hj_versi
            "hj_scene_upload", "hj_framebuffer_create", "hj_framebuffer_clear", "hj_framebuffer_device_ptr",
            "hj_framebuffer_read", "hj_framebuffer_resolve", "hj_render_blocks", "hj_render_frame", "hj_block_seed",
            "hj_pass_offset", "hj_block_owner", "hj_debug_trace", "hj_debug_samples", "hj_reduce_framebuffers",
-           "hj_build_bvh_device")
+           "hj_build_bvh_device", "hj_render_frame_async", "hj_sync", "hj_set_progress_callback", "hj_device_count",
+           "hj_comm_create", "hj_comm_destroy", "hj_comm_reduce_framebuffers")
+
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
 
 
 def lib():
@@ -51,6 +54,16 @@ def lib():
         L.hj_render_frame.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.POINTER(abi.RenderOpts), C.POINTER(abi.RenderStats)]
         L.hj_reduce_framebuffers.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+        L.hj_render_frame_async.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                            C.POINTER(abi.RenderOpts)]
+        L.hj_sync.argtypes = [vp, C.POINTER(abi.RenderStats)]
+        L.hj_set_progress_callback.argtypes = [vp, PROGRESS_FN, vp, C.c_uint32]
+        L.hj_set_progress_callback.restype = None
+        L.hj_device_count.restype = C.c_int
+        L.hj_comm_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp)]
+        L.hj_comm_destroy.argtypes = [vp]
+        L.hj_comm_destroy.restype = None
+        L.hj_comm_reduce_framebuffers.argtypes = [vp, C.c_int]
         L.hj_debug_trace.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
         L.hj_debug_samples.argtypes = [vp, C.POINTER(abi.ImageBlock), C.POINTER(abi.RenderOpts), C.POINTER(C.c_float)]
         L.hj_build_bvh_device.argtypes = [vp, C.POINTER(abi.SceneDesc), C.POINTER(abi.BvhNode), C.c_size_t, C.POINTER(C.c_size_t)]
@@ -70,6 +83,36 @@ def reduce_framebuffers(renderers, root=0):
     rc = lib().hj_reduce_framebuffers(arr, len(renderers), root)
     if rc != abi.HJ_OK:
         raise abi.HijikiError(rc, lib().hj_last_error(renderers[root]._h).decode())
+
+
+def device_count():
+    return lib().hj_device_count()
+
+
+class Comm:
+    """hj_comm: the in-process contexts (one per GPU) + their RCCL communicators, made once and reused by every reduce."""
+
+    def __init__(self, renderers):
+        self.renderers = list(renderers)
+        self._h = C.c_void_p()
+        self._destroy = lib().hj_comm_destroy
+        arr = (C.c_void_p * len(self.renderers))(*[r._h for r in self.renderers])
+        rc = lib().hj_comm_create(arr, len(self.renderers), C.byref(self._h))
+        if rc != abi.HJ_OK:
+            raise abi.HijikiError(rc, lib().hj_last_error(self.renderers[0]._h).decode())
+
+    def reduce(self, root=0):
+        rc = lib().hj_comm_reduce_framebuffers(self._h, root)
+        if rc != abi.HJ_OK:
+            raise abi.HijikiError(rc, lib().hj_last_error(self.renderers[root]._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
 
 
 def default_opts():
@@ -139,6 +182,22 @@ class Renderer:
         self._check(lib().hj_render_frame(self._h, spp, master_seed, pass_begin, pass_end, rank, world,
                                           C.byref(opts) if opts is not None else None, C.byref(st)))
         return stats_dict(st)
+
+    def render_frame_async(self, spp, master_seed, pass_begin=0, pass_end=None, rank=0, world=1, opts=None):
+        """hj_render_frame on the context's worker thread; `sync()` waits for it and returns the statistics."""
+        pass_end = spp if pass_end is None else pass_end
+        self._check(lib().hj_render_frame_async(self._h, spp, master_seed, pass_begin, pass_end, rank, world,
+                                                C.byref(opts) if opts is not None else None))
+
+    def sync(self):
+        st = abi.RenderStats()
+        self._check(lib().hj_sync(self._h, C.byref(st)))
+        return stats_dict(st)
+
+    def set_progress(self, fn, interval_blocks=128):
+        """fn(blocks_done, blocks_total) whenever `interval_blocks` more ImageBlocks have completed; None = off."""
+        self._progress = PROGRESS_FN(lambda _u, d, t: fn(d, t)) if fn else PROGRESS_FN()
+        lib().hj_set_progress_callback(self._h, self._progress, None, interval_blocks)
 
     def build_bvh(self, compiled):
         """LBVH over the shapes of `compiled`, built on the device (hj_build_bvh_device): (2 * shapes - 1, 8) uint32

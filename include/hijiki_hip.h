@@ -252,13 +252,43 @@ int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed,
 int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* scene, hj_bvh_node* out_nodes, size_t capacity,
                         size_t* out_num_nodes /* may be NULL */);
 
+/* ------------------------------------------------- asynchronous frame, progress */
+
+/* hj_render_frame on a worker thread of the context: returns at once, hj_sync waits for the frame and returns its
+ * status and statistics.  One host thread can so keep one context per GPU rendering at the same time, and the drain of
+ * one context overlaps whatever the host does next (the reduce waits for all of them).  At most one frame in flight per
+ * context; every other call on the context must wait for hj_sync.  (No counterpart in the reference, whose submit loop
+ * src/main.rs:1316-1355 is synchronous with respect to the host but never waits for the device.) */
+int hj_render_frame_async(hj_context* ctx, uint32_t spp, uint64_t master_seed,
+                          uint32_t pass_begin, uint32_t pass_end, uint32_t rank, uint32_t world,
+                          const hj_render_opts* opts);
+int hj_sync(hj_context* ctx, hj_render_stats* stats /* may be NULL */);
+
+/* Replaces the window-title percentage the reference updates every `present_interval` blocks (src/main.rs:1335-1340):
+ * `fn(user, blocks_done, blocks_total)` is called from the thread that drives the render whenever at least
+ * `interval_blocks` more ImageBlocks have COMPLETED on the device (granularity: one wavefront batch), and once at the
+ * end of the call.  fn == NULL switches reporting off. */
+typedef void (*hj_progress_fn)(void* user, uint64_t blocks_done, uint64_t blocks_total);
+void hj_set_progress_callback(hj_context* ctx, hj_progress_fn fn, void* user, uint32_t interval_blocks);
+
+/* Number of HIP devices visible to the process (0 without a GPU). */
+int hj_device_count(void);
+
 /* ---------------------------------------------------------------- multi-GPU */
 
-/* New with the multi-GPU tile sharding (no counterpart in the reference): element-wise SUM of the framebuffers of
- * `n` contexts of THIS process (one per GPU, equal sizes) into ctxs[root], with one ncclReduce per GPU inside a
- * group call over xGMI (RCCL is loaded with dlopen on first use; n == 1 needs no RCCL).  Hosts that run one
- * process per GPU reduce the external framebuffer themselves instead (hijiki_amd/dist.py does, through
- * torch.distributed).  Resolve rgb/w only after the reduce. */
+/* New with the multi-GPU tile sharding (no counterpart in the reference).  A communicator holds the `n` contexts of
+ * THIS process (one per GPU) and their RCCL communicators (ncclCommInitAll once, reused by every reduce; RCCL is loaded
+ * with dlopen on first use, a copy the process has already mapped is reused; n == 1 needs no RCCL). */
+typedef struct hj_comm hj_comm;
+int hj_comm_create(hj_context* const* ctxs, int n, hj_comm** out_comm);
+void hj_comm_destroy(hj_comm* comm);
+/* Element-wise SUM of the framebuffers (equal sizes) into ctxs[root]: waits for frames in flight (hj_sync) on every
+ * context, then one ncclReduce per GPU inside a group call over xGMI.  Resolve rgb/w only after the reduce.  Errors
+ * are reported on ctxs[root].  Hosts that run one process per GPU reduce the external framebuffer themselves instead
+ * (hijiki_amd/dist.py does, through torch.distributed). */
+int hj_comm_reduce_framebuffers(hj_comm* comm, int root);
+/* The same without a communicator object: the communicators of the context list are created on the first call and
+ * kept until one of the contexts is destroyed. */
 int hj_reduce_framebuffers(hj_context* const* ctxs, int n, int root);
 
 /* ------------------------------------------------------------------- probes */

@@ -963,4 +963,45 @@ HJO_EXPORT void hjo_dielectric_probe(float eta, const float* n3, const float* wi
   out5[3] = 0.0f; out5[4] = (ext.x != 0.0f) ? 1.0f : 0.0f;
 }
 
+/* Probe of one shading step (render.glsl:94-135 without the visibility test): rays n x 8 (o, d, tMin, tMax) and one RNG
+ * state per ray -> out n x 20: [0] objectID (-1 miss), [1..3] T*evalBSDF*importance of the NEE sample with T = 1 (0 when
+ * the tests of render.glsl:121 reject it), [4..6] shadow direction, [7] shadow tMax, [8..10] wo, [11..13] sampleBSDF weight,
+ * [14] alive, [15] RNG state bits after the step, [16..18] extinction after the step, [19] emitted radiance .r if emissive. */
+HJO_EXPORT int hjo_shade_probe(const hj_scene_desc* sc, const float* rays, const uint32_t* rng_in, size_t n, float* out) {
+  hjo_counters c; memset(&c, 0, sizeof c);
+  scene_t S; S.sc = sc; S.ns = (uint32_t)sc->num_spheres; S.nq = (uint32_t)sc->num_quads;
+  S.nt = (uint32_t)sc->num_triangles; S.use_bvh = 1; S.ctr = &c;
+  for (size_t i = 0; i < n; i++) {
+    const float* r = &rays[i * 8];
+    float* o = &out[i * 20];
+    memset(o, 0, 80);
+    ray_t ray; ray.o = V(r[0], r[1], r[2]); ray.d = V(r[3], r[4], r[5]); ray.tmin = r[6]; ray.tmax = r[7];
+    its_t its; memset(&its, 0, sizeof its);
+    uint32_t rng = rng_in[i];
+    int32_t id = -1;
+    if (intersect_scene(&S, ray, &its, closest_ctr(&c))) {
+      id = its.id;
+      uint32_t mat = sc->materials[its.id];
+      uint32_t tag = mat >> HJ_MATERIAL_TAG_SHIFT, midx = mat & HJ_MATERIAL_INDEX_MASK;
+      if (tag == HJ_MAT_EMISSIVE) o[19] = sc->emissive[midx].power[0];
+      if (tag == HJ_MAT_DIFFUSE || tag == HJ_MAT_DIFFUSECBOARD) {
+        ray_t sh;
+        v3 imp = sample_emitter(&S, its.p, &rng, &sh);
+        o[4] = sh.d.x; o[5] = sh.d.y; o[6] = sh.d.z; o[7] = sh.tmax;
+        if (len3(imp) > M_EPSF && dot3(sh.d, its.n) > 0.0f) {
+          v3 f = v_mul(eval_bsdf(&S, mat, sh.d, &its), imp);
+          o[1] = f.x; o[2] = f.y; o[3] = f.z;
+        }
+      }
+      v3 wo = V(0, 0, 0), ext = V(0, 0, 0); int alive = 0;
+      v3 w = sample_bsdf(&S, mat, ray.d, &its, &rng, &wo, &ext, &alive);
+      o[8] = wo.x; o[9] = wo.y; o[10] = wo.z; o[11] = w.x; o[12] = w.y; o[13] = w.z; o[14] = (float)alive;
+      o[16] = ext.x; o[17] = ext.y; o[18] = ext.z;
+    }
+    memcpy(&o[0], &id, 4);
+    memcpy(&o[15], &rng, 4);
+  }
+  return HJ_OK;
+}
+
 HJO_EXPORT size_t hjo_sizeof_counters(void) { return sizeof(hjo_counters); }

@@ -74,6 +74,7 @@ def lib():
         L.hjo_recon_gauss.restype = C.c_float
         L.hjo_dielectric_probe.argtypes = [C.c_float, fp, fp, u32p, fp]
         L.hjo_dielectric_probe.restype = None
+        L.hjo_shade_probe.argtypes = [C.POINTER(abi.SceneDesc), fp, u32p, C.c_size_t, fp]
         L.hjo_sizeof_counters.restype = C.c_size_t
         assert L.hjo_sizeof_counters() == C.sizeof(Counters)
         _LIB = L
@@ -126,6 +127,15 @@ def intersect(compiled, rays, use_bvh=True, full=False):
                         _fp(fullbuf) if full else None)
     ids = hits[:, 0].copy().view(np.int32)
     return (ids, hits[:, 1], hits[:, 2], hits[:, 3]) + ((fullbuf,) if full else ())
+
+
+def shade_probe(compiled, rays, rng_states):
+    """One shading step per ray (hjo_shade_probe): returns the (n, 20) float32 record array, ids (int32), RNG after (uint32)."""
+    rays = np.ascontiguousarray(rays, np.float32)
+    rng = np.ascontiguousarray(rng_states, np.uint32)
+    out = np.zeros((len(rays), 20), np.float32)
+    lib().hjo_shade_probe(C.byref(compiled.desc), _fp(rays), rng.ctypes.data_as(C.POINTER(C.c_uint32)), len(rays), _fp(out))
+    return out, out[:, 0].copy().view(np.int32), out[:, 15].copy().view(np.uint32)
 
 
 def camera_rays(camera, width, height, pix_xy):

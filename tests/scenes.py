@@ -1,0 +1,73 @@
+"""Scenes shared by the tests (built through the host Scene API, i.e. the reference's Shape / Material model)."""
+import numpy as np
+
+from hijiki_amd import host
+
+
+def rich_scene(seed=7):
+    """Every shape kind and every material kind: quad enclosure (one quad light), spheres (one of them a light, a mirror,
+    a clear and a TINTED dielectric, a checkerboard), a triangle soup with random shading normals (one triangle light)."""
+    rng = np.random.default_rng(seed)
+    s = host.Scene()
+    s.set_camera((0.05, 0.9, 3.3), (-0.02, 0.01, 0.0, 0.9997), 38.0)
+    white, red, blue = s.add_diffuse((0.7, 0.7, 0.7)), s.add_diffuse((0.6, 0.1, 0.1)), s.add_diffuse((0.1, 0.2, 0.6))
+    cb = s.add_diffuse_cboard((0.9, 0.9, 0.2), 0.13, (0.1, 0.2, 0.8), 0.21)
+    mirror, glass = s.add_mirror(), s.add_dielectric(1.5)
+    tinted = s.add_dielectric(1.33, extinction=(0.5, 1.5, 3.0))
+    lq, ls, lt = s.add_emissive((20, 18, 15)), s.add_emissive((9, 12, 14)), s.add_emissive((14, 6, 6))
+    s.add_quad((-1.2, 0, 1.2), (2.4, 0, 0), (0, 0, -2.4), white)
+    s.add_quad((-1.2, 0, -1.2), (2.4, 0, 0), (0, 2.0, 0), cb)
+    s.add_quad((-1.2, 0, 1.2), (0, 0, -2.4), (0, 2.0, 0), red)
+    s.add_quad((1.2, 0, -1.2), (0, 0, 2.4), (0, 2.0, 0), blue)
+    s.add_quad((-0.4, 1.99, -0.4), (0.8, 0, 0), (0, 0, 0.8), lq)
+    s.add_sphere((0.55, 1.45, 0.3), 0.12, ls)
+    s.add_sphere((-0.55, 0.35, 0.1), 0.35, mirror)
+    s.add_sphere((0.45, 0.3, 0.45), 0.3, glass)
+    s.add_sphere((0.0, 0.95, -0.3), 0.25, tinted)
+    s.add_sphere((0.6, 0.25, -0.5), 0.25, cb)
+    nv = 24
+    pos = rng.uniform([-0.9, 0.05, -0.9], [0.9, 1.5, 0.9], (nv, 3)).astype(np.float32)
+    nrm = rng.normal(size=(nv, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    base = s.add_vertices(pos, nrm, rng.uniform(0, 1, (nv, 2)).astype(np.float32))
+    mats = [white, red, cb, mirror, glass, tinted, lt]
+    for i in range(14):
+        a, b, c = (int(x) for x in rng.choice(nv, 3, replace=False))
+        s.add_triangle(base + a, base + b, base + c, mats[i % len(mats)])
+    return s.compile()
+
+
+FURNACE_L = 2.0          # radiance of the enclosure
+FURNACE_RHO = 0.6        # albedo of the sphere inside
+
+
+def furnace_scene():
+    """A diffuse sphere (albedo rho) inside a closed box of six emissive quads of radiance L facing inward, camera
+    inside the box.  Incident radiance on the sphere is L from every direction, so its outgoing radiance is exactly
+    rho * L everywhere (the sphere is convex: it never sees itself), estimated by next-event estimation over uniformly
+    sampled quads (sampleQuad is unbiased; triangle lights would bring in randBarycentric's degeneracy).  The bounce ray
+    ends on a wall and adds nothing (wasDiscrete is false after a diffuse bounce): expected image = rho * L on the
+    sphere, L where the camera sees the walls."""
+    s = host.Scene()
+    s.set_camera((0.0, 0.0, 2.5), (0.0, 0.0, 0.0, 1.0), 40.0)
+    lamp = s.add_emissive((FURNACE_L, FURNACE_L, FURNACE_L))
+    a = 3.0
+    # cross(edge1, edge2) points INTO the box for every wall (sampleEmitter is one-sided: scene.glsl:80-83)
+    s.add_quad((-a, -a, -a), (0, 0, 2 * a), (2 * a, 0, 0), lamp)      # floor y = -a, normal +y
+    s.add_quad((-a, a, -a), (2 * a, 0, 0), (0, 0, 2 * a), lamp)       # ceiling, normal -y
+    s.add_quad((-a, -a, -a), (2 * a, 0, 0), (0, 2 * a, 0), lamp)      # back z = -a, normal +z
+    s.add_quad((-a, -a, a), (0, 2 * a, 0), (2 * a, 0, 0), lamp)       # front z = +a, normal -z
+    s.add_quad((-a, -a, -a), (0, 2 * a, 0), (0, 0, 2 * a), lamp)      # left x = -a, normal +x
+    s.add_quad((a, -a, -a), (0, 0, 2 * a), (0, 2 * a, 0), lamp)       # right, normal -x
+    s.add_sphere((0.0, 0.0, 0.0), 0.6, s.add_diffuse((FURNACE_RHO,) * 3))
+    return s.compile()
+
+
+def furnace_masks(W, H):
+    """Pixels safely inside the sphere's disc / safely on the walls for the furnace camera (fov 40 deg, distance 2.5)."""
+    ys, xs = np.mgrid[0:H, 0:W]
+    s = np.tan(np.radians(20.0)) / (0.5 * W)
+    x, y = (xs + 0.5 - 0.5 * W) * s, (ys + 0.5 - 0.5 * H) * s
+    r = np.sqrt(x * x + y * y)
+    r_disc = 0.6 / np.sqrt(2.5 ** 2 - 0.6 ** 2)             # tan of the sphere's angular radius
+    return r < 0.8 * r_disc, r > 1.25 * r_disc

@@ -1,0 +1,75 @@
+"""SURVEY.md section 4 "Integration": converged images and a white furnace.
+
+The fixtures tests/golden/converged_<scene>_128x128x4096.npz were rendered by the float64 numpy restatement of the GLSL
+(tests/golden/make_converged.py), not by the oracle: resolved mean image + standard error of the mean per pixel (from 16
+groups of passes).  The oracle (CPU) and the HIP path (GPU) render the same 4096 passes (same ImageBlock list) in binary32
+and must land inside a 4-sigma Monte-Carlo interval everywhere - and, because the sample sequences are the same, far inside
+it on average (a binary32 rounding flips a branch on a fraction of a per cent of the paths, nothing else differs).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+from hijiki_amd import host
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+KINDS = {"cbox": host.SYNTH_CBOX, "spheres": host.SYNTH_CBOX_SPHERES}
+
+
+def _fixture(kind):
+    path = os.path.join(GOLD, f"converged_{kind}_128x128x4096.npz")
+    assert os.path.exists(path), f"{path} missing: run tests/golden/make_converged.py"
+    return np.load(path)
+
+
+def _check_converged(img, g, what):
+    mean, sem = g["mean"].astype(np.float64), g["sem"].astype(np.float64)
+    assert np.isfinite(img).all()
+    band = 4.0 * sem + 1e-3 * mean + 1e-5
+    out = np.abs(img - mean) > band
+    assert not out.any(), f"{what}: {int(out.sum())} values outside the 4-sigma interval, worst {np.abs(img - mean)[out].max()}"
+    rel = np.abs(img - mean).sum() / mean.sum()
+    assert rel < 2e-3, f"{what}: mean relative difference {rel}"          # Monte-Carlo noise alone would allow ~1e-2
+    assert abs(img.mean() - mean.mean()) < 2e-4 * mean.mean()
+
+
+@pytest.mark.parametrize("kind", ["cbox", "spheres"])
+def test_oracle_matches_converged_float64_image(oracle, kind):
+    g = _fixture(kind)
+    W, H, spp, seed = (int(g[k]) for k in ("width", "height", "spp", "seed"))
+    cs = host.Scene.synthetic(KINDS[kind]).compile()
+    acc, _, _ = oracle.render_blocks(cs, host.make_blocks(W, H, spp, seed), W, H)
+    _check_converged(oracle.resolve(acc).astype(np.float64), g, f"oracle {kind}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cbox", "spheres"])
+def test_hip_matches_converged_float64_image(gpu_renderer, kind):
+    """BASELINE configs 2 and 3's scenes, 128 x 128, 4096 spp, HIP path vs the float64 numpy image."""
+    g = _fixture(kind)
+    W, H, spp, seed = (int(g[k]) for k in ("width", "height", "spp", "seed"))
+    r = gpu_renderer
+    r.upload_scene(host.Scene.synthetic(KINDS[kind]).compile())
+    r.create_framebuffer(W, H)
+    r.render_frame(spp, seed)
+    a = r.read().astype(np.float64)
+    _check_converged(a[..., :3] / a[..., 3:4], g, f"hip {kind}")
+
+
+@pytest.mark.gpu
+def test_white_furnace_hip(gpu_renderer):
+    """Closed emissive box around a diffuse sphere (tests/scenes.py): radiance rho * L on the sphere, L on the walls."""
+    W = H = 128
+    r = gpu_renderer
+    r.upload_scene(scenes.furnace_scene())
+    r.create_framebuffer(W, H)
+    r.render_frame(1024, 5)
+    a = r.read().astype(np.float64)
+    img = a[..., :3] / a[..., 3:4]
+    disc, wall = scenes.furnace_masks(W, H)
+    assert np.abs(img[wall] - scenes.FURNACE_L).max() < 1e-5
+    want = scenes.FURNACE_RHO * scenes.FURNACE_L
+    assert abs(img[disc].mean() - want) < 5e-4 * want               # 1024 spp x ~2000 pixels
+    assert np.abs(img[disc] - want).max() < 0.2 * want              # every pixel (its own noise: sigma about 3 %)

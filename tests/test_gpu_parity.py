@@ -431,6 +431,91 @@ def test_config2_full_size_properties(gpu_renderer, cbox):
         np.testing.assert_allclose(total, a, rtol=5e-5, atol=1e-5)
 
 
+def _frame_properties(r, W, H, spp, seed, split_at, virtual_ranks=0, rtol=5e-5):
+    """Size-independent properties of a whole frame at a BASELINE configuration's own size: sane statistics, bitwise
+    run-to-run determinism, additivity over pass ranges (the framebuffer is a running sum in block order) and, when
+    asked, `virtual_ranks`-way tile sharding (each rank's share rendered in turn on this GPU) summing to the frame."""
+    r.create_framebuffer(W, H)
+    st = r.render_frame(spp, seed)
+    a = r.read()
+    assert st["paths"] == W * H * spp
+    assert st["closest_rays"] >= st["paths"] and st["hits"] <= st["closest_rays"]
+    assert st["unoccluded_shadow_rays"] <= st["shadow_rays"]
+    assert np.isfinite(a).all() and (a[..., 3] > 0).all()
+    rgb = a[..., :3] / a[..., 3:4]
+    assert 0.02 < rgb.mean() < 2.0 and rgb.min() >= 0
+    r.clear()
+    r.render_frame(spp, seed, pass_begin=0, pass_end=split_at)
+    r.render_frame(spp, seed, pass_begin=split_at, pass_end=spp)
+    assert (bits(r.read()) == bits(a)).all(), "pass ranges [0,a) + [a,spp) != one call"
+    if virtual_ranks:
+        total = np.zeros((H, W, 4), np.float64)
+        paths = 0
+        for rank in range(virtual_ranks):
+            r.clear()
+            paths += r.render_frame(spp, seed, rank=rank, world=virtual_ranks)["paths"]
+            total += r.read()
+        assert paths == st["paths"]
+        np.testing.assert_allclose(total, a, rtol=rtol, atol=1e-5)
+    return st, a
+
+
+def test_config3_full_size_properties(gpu_renderer, cbox_spheres):
+    """BASELINE.json configs[2] at FULL size: cbox + mirror sphere + dielectric sphere, 1024 x 1024, 1024 spp
+    (1.07 G paths; the divergent-BSDF configuration)."""
+    gpu_renderer.upload_scene(cbox_spheres)
+    st, _ = _frame_properties(gpu_renderer, 1024, 1024, 1024, 1, split_at=300, virtual_ranks=8)
+    assert st["closest_rays"] > 3.3 * st["paths"]          # specular chains: longer paths than the diffuse box (3.05)
+    gpu_renderer.create_framebuffer(64, 64)
+
+
+@pytest.fixture(scope="module")
+def mesh_1m():
+    """BASELINE.json configs[3]'s scene: 1 000 000 triangles -> 1 999 999 nodes (> the reference's hard-coded root exit
+    of 1 000 000, src/main.rs:231)."""
+    cs = host.Scene.synthetic(host.SYNTH_CBOX_MESH, mesh_triangles=1000000).compile()
+    assert len(cs.bvh) > 1000000 and int(cs.bvh[0, 7]) == len(cs.bvh)
+    return cs
+
+
+def test_config4_million_triangles_bit_exact(gpu_renderer, oracle, mesh_1m):
+    """configs[3]'s scene against the oracle, SAH tree and device-built LBVH: both have more than 10^6 nodes, the
+    case where the root's exit index is the node count instead of the reference's 1 000 000."""
+    cs = mesh_1m
+    W = H = 128
+    blocks = host.make_blocks(W, H, 1, 3)
+    want, ctr, _ = oracle.render_blocks(cs, blocks, W, H)
+    got, st = render(gpu_renderer, cs, W, H, blocks)
+    assert_same(got, want, "1M mesh, SAH tree")
+    assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"]
+    assert ctr["nodes"] / ctr["closest_calls"] > 50
+    sah = cs.bvh.copy()
+    nodes = gpu_renderer.build_bvh(cs)
+    assert len(nodes) == len(sah) and int(nodes[0, 7]) == len(nodes)
+    cs.set_bvh(nodes)
+    try:
+        want, _, _ = oracle.render_blocks(cs, blocks, W, H)
+        got, _ = render(gpu_renderer, cs, W, H, blocks)
+        assert_same(got, want, "1M mesh, device-built tree")
+    finally:
+        cs.set_bvh(sah)
+
+
+def test_config4_full_size_properties(gpu_renderer, mesh_1m):
+    """configs[3] at FULL size: 1 M triangles, 2048 x 2048, 256 spp (1.07 G paths; deep BVH traversal)."""
+    gpu_renderer.upload_scene(mesh_1m)
+    st, _ = _frame_properties(gpu_renderer, 2048, 2048, 256, 1, split_at=100)
+    gpu_renderer.create_framebuffer(64, 64)
+
+
+def test_config5_frame_size_eight_virtual_ranks(gpu_renderer, cbox):
+    """configs[4]'s frame (cbox 4096 x 4096, 1024 blocks per pass, 268 MB framebuffer) at 64 of its 4096 spp, the
+    8-rank tile sharding rendered rank by rank on this GPU and summed.  (The 8-GPU run itself needs the 8-GPU node.)"""
+    gpu_renderer.upload_scene(cbox)
+    _frame_properties(gpu_renderer, 4096, 4096, 64, 2, split_at=24, virtual_ranks=8)
+    gpu_renderer.create_framebuffer(64, 64)              # release the 268 MB buffer for the tests that follow
+
+
 def test_large_mesh_and_large_frame(gpu_renderer, oracle):
     """configs[3]/[4] shapes at reduced sample counts: a 200 k-triangle mesh (deep tree) bit-exact against the oracle,
     and a 4096 x 4096 frame (1024 blocks per pass, 268 MB framebuffer) sharded 8 ways."""
@@ -571,3 +656,73 @@ def test_in_process_reduce_entry_point(gpu_renderer, cbox_small):
     with pytest.raises(abi.HijikiError) as e:
         device.reduce_framebuffers([r, r], root=0)            # two contexts on one GPU
     assert e.value.status == abi.HJ_ERR_INVALID
+
+
+def test_async_frame_progress_and_comm_object(gpu_renderer, cbox_small):
+    """hj_render_frame_async + hj_sync == hj_render_frame bit for bit; the progress callback counts completed blocks
+    up to the total; an hj_comm over one context reduces to a no-op and waits for the frame in flight."""
+    r = gpu_renderer
+    r.upload_scene(cbox_small)
+    W, H, spp = 384, 256, 40
+    r.create_framebuffer(W, H)
+    r.render_frame(spp, 3)
+    want = r.read()
+    seen = []
+    r.set_progress(lambda done, total: seen.append((done, total)), interval_blocks=16)
+    try:
+        r.clear()
+        r.render_frame_async(spp, 3)
+        with pytest.raises(abi.HijikiError) as e:
+            r.render_frame_async(spp, 3)                      # one frame in flight per context
+        assert e.value.status == abi.HJ_ERR_STATE
+        st = r.sync()
+        assert st["paths"] == W * H * spp
+        assert (bits(r.read()) == bits(want)).all()
+        total = 6 * spp                                       # 3 x 2 blocks per pass
+        assert seen and seen[-1] == (total, total)
+        assert all(a[0] < b[0] for a, b in zip(seen, seen[1:])) and all(t == total for _, t in seen)
+        comm = device.Comm([r])
+        r.clear()
+        r.render_frame_async(spp, 3)
+        comm.reduce(0)                                        # joins the frame in flight
+        assert (bits(r.read()) == bits(want)).all()
+        assert r.sync()["paths"] in (0, W * H * spp)          # already joined by the reduce: nothing pending
+        comm.close()
+    finally:
+        r.set_progress(None)
+
+
+@pytest.mark.skipif(device.device_count() < 2 if os.path.exists(device.HIP_LIB_PATH) else True,
+                    reason="needs two or more GPUs in this process (hipGetDeviceCount() >= 2)")
+def test_in_process_multi_gpu_frame(cbox):
+    """The C-ABI multi-GPU path, whenever the box has the GPUs: one context per GPU, every rank's share rendered
+    concurrently (hj_render_frame_async), one RCCL reduce through a reused hj_comm, against the 1-GPU frame."""
+    n = min(8, device.device_count())
+    W = H = 512
+    spp = 64
+    rs = [device.Renderer(i) for i in range(n)]
+    try:
+        for r in rs:
+            r.upload_scene(cbox)
+            r.create_framebuffer(W, H)
+        rs[0].render_frame(spp, 1)
+        full = rs[0].read()
+        comm = device.Comm(rs)
+        for rep in range(2):                                  # the communicators are reused by the second frame
+            for r in rs:
+                r.clear()
+            for i, r in enumerate(rs):
+                r.render_frame_async(spp, 1, rank=i, world=n)
+            comm.reduce(0)
+            got = rs[0].read()
+            np.testing.assert_allclose(got, full, rtol=5e-5, atol=1e-5)
+        for r in rs:
+            r.clear()
+        for i, r in enumerate(rs):
+            r.render_frame(spp, 1, rank=i, world=n)
+        device.reduce_framebuffers(rs, root=0)                # the form without a communicator object (cached inside)
+        np.testing.assert_allclose(rs[0].read(), full, rtol=5e-5, atol=1e-5)
+        comm.close()
+    finally:
+        for r in rs:
+            r.close()

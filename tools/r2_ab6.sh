@@ -1,0 +1,7 @@
+#!/bin/bash
+export GPU_MAX_HW_QUEUES=8
+out=gpurun_out/r2_ab6; mkdir -p $out
+timeout 1500 python -m pytest tests -m gpu -x -q --durations=5 --deselect tests/test_converged.py::test_hip_matches_converged_float64_image > $out/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $out/pytest.log; tail -12 $out/pytest.log
+echo "== C2"; tools/ab_variants.sh noinl cur hot384 hot512 2>&1 | tee $out/c2.txt
+echo "== C3"; PROBE_ARGS="--kind 1 --spp 256" tools/ab_variants.sh noinl cur hot384 hot512 2>&1 | tee $out/c3.txt
+echo "== C4"; PROBE_ARGS="--kind 2 --tris 1000000 --size 2048 --spp 32" tools/ab_variants.sh noinl cur hot384 hot512 2>&1 | tee $out/c4.txt

@@ -1,0 +1,116 @@
+"""Turns rocprofv3 CSVs into the numbers bench.py's roofline block quotes (and back-checks them).
+
+    roofline_inputs.py trace KERNEL_TRACE.csv STEPS     k_path_wavefront launches: average, and the average + exclusive
+                                                        (union of intervals) time over the last STEPS frames
+    roofline_inputs.py pmc COUNTER_COLLECTION.csv       per-kernel sums of every counter in the file (CSV on stdout)
+    roofline_inputs.py build DIR CONFIG                 DIR/pmc_pass*.csv (+ kernel_trace_summary.txt, walk stats JSON)
+                                                        -> the roofline_inputs JSON on stdout
+
+`build` is what tools/profile_config.sh runs last; the JSON it prints is committed as profiles/<TAG>_<CONFIG>_roofline_inputs.json
+and read by bench.py.  HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE come
+from separate passes; on gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes, so wide reads are doubled - the
+16-byte-per-lane gathers of this kernel are an uncalibrated width, so both the raw and the doubled figure are kept and
+`hbm_bytes_per_path` (what bench.py quotes as `traffic`) is the doubled (upper) one.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+PATHS = {"c2": 1024 * 1024 * 512, "c3": 1024 * 1024 * 1024, "c4": 2048 * 2048 * 256}
+
+
+def cmd_trace(path, steps):
+    rows = [r for r in csv.DictReader(open(path)) if "k_path_wavefront" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    iv = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
+    d = [(b - a) / 1e6 for a, b in iv]
+    per_frame = len(d) // (steps + 1) if steps else len(d)      # the run has 1 warm-up frame + STEPS timed frames
+    n = per_frame * steps if steps else len(d)
+    tail = iv[-n:]
+    busy, ca, cb = 0, None, None
+    for a, b in tail:
+        if cb is None or a > cb:
+            if cb is not None:
+                busy += cb - ca
+            ca, cb = a, b
+        else:
+            cb = max(cb, b)
+    busy += cb - ca
+    print(f"k_path_wavefront launches {len(d)}; all: avg {sum(d)/len(d):.4f} ms; last {n} (timed region): avg {sum(d[-n:])/n:.4f} ms "
+          f"min {min(d[-n:]):.3f} max {max(d[-n:]):.3f}; exclusive (union of intervals) {busy/1e6:.3f} ms = {busy/1e6/n:.4f} ms per launch")
+
+
+def cmd_pmc(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    names = []
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        c = r["Counter_Name"]
+        if c not in names:
+            names.append(c)
+        agg[k][c] += float(r["Counter_Value"])
+        cnt[(k, c)] += 1
+    print("kernel,launches," + ",".join(names))
+    for k in sorted(agg):
+        print(f"{k},{max(cnt[(k, c)] for c in names)}," + ",".join(f"{agg[k][c]:.0f}" for c in names))
+
+
+def cmd_build(d, cfg):
+    c = {}
+    launches = 0
+    for f in sorted(glob.glob(os.path.join(d, "pmc_pass*.csv"))):
+        for r in csv.DictReader(open(f)):
+            if "k_path_wavefront" not in r["kernel"]:
+                continue
+            launches = max(launches, int(r["launches"]))
+            for k, v in r.items():
+                if k not in ("kernel", "launches"):
+                    c[k] = float(v)
+    paths = PATHS[cfg]
+    out = {"config": cfg, "kernel": "k_path_wavefront", "paths_per_frame": paths, "launches_per_frame": launches,
+           "command": f"tools/profile_config.sh: rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py --config {cfg} --steps 1 --warmup 0 --no-cpu-baseline, one pass per group, GPU_MAX_HW_QUEUES=8",
+           "counters": {k: v for k, v in sorted(c.items())}}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:      # rocprofv3 reports both in KiB
+        fetch, write = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
+        out["fetch_bytes_per_path_raw"] = fetch / paths
+        out["write_bytes_per_path"] = write / paths
+        out["hbm_bytes_per_path_raw"] = (fetch + write) / paths
+        out["hbm_bytes_per_path"] = (2 * fetch + write) / paths
+    lim = {}
+    if c.get("SQ_INSTS_VALU"):
+        lim["valu_lanes_per_instruction"] = round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"], 2)
+    if c.get("SQ_WAVE_CYCLES"):
+        for k, n in (("SQ_ACTIVE_INST_VALU", "valu_issue_share_of_wave_cycles"), ("SQ_WAIT_ANY", "waiting_share_of_wave_cycles"),
+                     ("SQ_WAIT_INST_ANY", "issue_stall_share_of_wave_cycles"), ("SQ_ACTIVE_INST_VMEM", "vmem_issue_share_of_wave_cycles")):
+            if k in c:
+                lim[n] = round(c[k] / c["SQ_WAVE_CYCLES"], 4)
+    if c.get("TCC_HIT_sum") is not None and (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) > 0:
+        lim["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
+    ws = os.path.join(d, "walk_stats.json")
+    if os.path.exists(ws):
+        w = json.load(open(ws))
+        lim["walk_lanes_per_box_step"] = round(w["lanes_per_box_step"], 1)
+        lim["walk_lanes_per_leaf_phase"] = round(w["lanes_per_leaf_phase"], 1)
+        out["walk"] = w
+        if cfg == "c4":   # scene data of the 1 M-triangle mesh (96 MB) is not cache-resident: nodes outside the LDS copy + triangle records
+            out["scene_bytes_per_ray"] = 32.0 * w["cold_node_steps_per_ray"] + 48.0 * w["leaf_tests_per_ray"]
+    lim["name"] = ("dependent fetch latency of the BVH walk at partially filled waves (VALU instructions execute with "
+                   f"{lim.get('valu_lanes_per_instruction', '?')} of 64 lanes; waves wait {100 * lim.get('waiting_share_of_wave_cycles', 0):.0f} % of their cycles)")
+    out["limiter"] = lim
+    t = os.path.join(d, "kernel_trace_summary.txt")
+    if os.path.exists(t):
+        out["kernel_trace_summary"] = open(t).read().strip()
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "trace":
+        cmd_trace(sys.argv[2], int(sys.argv[3]))
+    elif sys.argv[1] == "pmc":
+        cmd_pmc(sys.argv[2])
+    else:
+        cmd_build(sys.argv[2], sys.argv[3])
