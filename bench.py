@@ -21,7 +21,8 @@ Prints ONE JSON line on rank 0 with the contract fields plus
                  EXCLUSIVE time per launch (union of the launches' HIP-event intervals / launches: launches of the three
                  batch slots overlap).  It can not exceed the peak, and bytes/step / ms_per_step is printed beside it
                  (`achieved_wall`).  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes under profiles/
-                 (tools/roofline_inputs.py regenerates that file from the CSVs).  `limiter` says what the counters say
+                 (tools/roofline_inputs.py regenerates that file from the CSVs; FETCH_SIZE corrected as calibrated in
+                 profiles/r02_fetch_size_calibration.txt: gathers exact, wide coalesced reads counted at half).  `limiter` says what the counters say
                  binds the kernel when it is not HBM.
   cpu_baseline - the CPU oracle ("Nori-style" port) timed on this host on a bounded sample of the same workload
 """
@@ -71,6 +72,14 @@ def implemented_bytes(st):
     b += first_hits * 16           # first-hit normal + depth
     b += P * (2 * 16 * (20 * 20) / (16 * 16))   # reconstruction: both sample layers, 20x20 staged per 16x16 tile
     return b
+
+
+def coalesced_read_bytes(st):
+    """The part of implemented_bytes() that is READ as wide coalesced 16-byte-per-lane streams (records in queue order):
+    rocprofv3's FETCH_SIZE counts these at half their size on gfx950 (MI355X_MICROARCH.md, section HBM), while it counts
+    the 64-byte sectors of 16/32/48-byte gathers exactly (profiles/r02_fetch_size_calibration.txt)."""
+    P, C, S, Hh = st["paths"], st["closest_rays"], st["shadow_rays"], st["hits"]
+    return C * (2 * 16) + C * (2 * 16) + Hh * (4 * 16) + S * (2 * 16) + P * (2 * 16 * (20 * 20) / (16 * 16))
 
 
 def roofline_inputs(config):
@@ -250,9 +259,14 @@ def main():
         busy_ms = agg["path_busy_ms"] or (1e3 * elapsed)             # exclusive GPU time of the path kernels, rank 0
         excl_ms = busy_ms / launches
         achieved = alg / launches / (excl_ms * 1e-3) / 1e9
+        # HBM traffic from the PMC passes: WRITE_SIZE is exact; FETCH_SIZE is exact for this kernel's gathers and counts
+        # wide coalesced reads at half their size, so the other half of the coalesced reads is added back (never more
+        # than the counter itself).  The raw and the fully doubled figures stay in the inputs file.
         traffic = traffic_per_launch = None
-        if inputs and inputs.get("hbm_bytes_per_path"):
-            traffic_per_launch = inputs["hbm_bytes_per_path"] * agg["paths"] / launches
+        if inputs and inputs.get("fetch_bytes_per_path_raw") is not None:
+            fetch = inputs["fetch_bytes_per_path_raw"] * agg["paths"]
+            fetch += min(fetch, 0.5 * coalesced_read_bytes(agg))
+            traffic_per_launch = (fetch + inputs["write_bytes_per_path"] * agg["paths"]) / launches
             traffic = round(traffic_per_launch / (excl_ms * 1e-3) / 1e9, 1)
         out["roofline"] = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

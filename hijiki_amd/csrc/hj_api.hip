@@ -809,6 +809,7 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", 4, 1, 1 << 20);   // >= 1, or the walk would never advance
     d.refill_min = (uint32_t)env_int("HJ_REFILL_MIN", (int)hj::kRefillMin, 1, 64);
     d.cold_burst = (uint32_t)env_int("HJ_COLD_BURST", 2, 1, 1 << 20);
+    d.leaf_min = (uint32_t)env_int("HJ_LEAF_MIN", 32, 1, 64);
     HJ_UP(upload(ctx, dev.data(), dev.size(), &d.nodes));
   }
   HJ_UP(upload(ctx, isect.data(), isect.size(), &d.tri_isect));

@@ -48,7 +48,8 @@ struct DeviceScene {
   uint32_t num_hot;             // nodes [0, num_hot) are the LDS-cached ones (<= kHotNodes)
   uint32_t inner_burst;         // max box steps per round of the persistent walk before leaf tests run
   uint32_t refill_min;          // free lanes that trigger a ray refill
-  uint32_t cold_burst;          // max HBM-node steps per round of the persistent walk
+  uint32_t cold_burst;          // max HBM-node steps per round of the persistent walk (HJ_WALK_SPLIT)
+  uint32_t leaf_min;            // lanes with a postponed leaf test that make the wave run the tests (HJ_WALK_SPEC)
   const float4* tri_isect;
   const float4* tri_shade;
   const float4* spheres;        // hj_sphere

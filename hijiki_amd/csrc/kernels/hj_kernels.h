@@ -218,6 +218,9 @@ HJ_DEV bool traverse(const DeviceScene& sc, Ray r, RawHit& h) {
 // Each ray still performs exactly the reference's pre-order skip-link walk (scene.glsl:97-133).
 //   fetch(i, slot, ray)   loads queue entry i
 //   finish(done, slot, h) wave-convergent: called when some lanes are done; `done` lanes have a final result
+#ifndef HJ_WALK_SPEC
+#define HJ_WALK_SPEC 0    // 1 = postponed leaf tests (see trace_persistent): bit-exact, measured -10 % (cbox) / -12 % (1 M triangles)
+#endif
 #ifndef HJ_WALK_SPLIT
 #define HJ_WALK_SPLIT 0   // 1 = separate ds_read (hot) and global (cold) box-step phases: measured -12 % (cbox) / -30 % (1 M triangles), DESIGN.md
 #endif
@@ -246,6 +249,10 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
   uint32_t slot = 0, cur = 0;
   Ray r; r.o = V(0, 0, 0); r.d = V(0, 0, 0); r.tmin = 0.f; r.tmax = 0.f;
   v3 inv = V(0, 0, 0), off = V(0, 0, 0);
+#if HJ_WALK_SPEC
+  bool lf_has = false;               // a leaf whose shape test is postponed: (lf_shape, lf_ex)
+  uint32_t lf_shape = 0, lf_ex = 0;
+#endif
   RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
 #ifdef HJ_WALK_STATS
   unsigned long long ws[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -275,6 +282,9 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
             inv = V(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
             off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
             cur = sc.root; h.id = -1; active = true;
+#if HJ_WALK_SPEC
+            lf_has = false;
+#endif
           }
         }
         exhausted = base + nidle >= n;
@@ -287,6 +297,57 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     const unsigned long long t_b = clock64();
     HJ_STAT(10, t_b - t_a);
 #endif
+#if HJ_WALK_SPEC
+    // POSTPONED LEAF TESTS.  A lane that reaches a leaf does not stop: it notes the leaf (lf_shape, lf_ex) and walks on
+    // from the leaf's exit with its CURRENT tMax, until it reaches a second leaf or the end of the tree (then it is
+    // `blocked`).  The wave runs the shape tests when a lane is blocked or leaf_min lanes have one waiting, i.e. with
+    // many lanes at once instead of the ~15 that happen to stand on a leaf after every burst of box steps.  Exact: a
+    // test that MISSES changes nothing, so the steps taken meanwhile are the reference's steps; a test that HITS
+    // lowers tMax, so the lane goes back to the leaf's exit (its state there is fully known: cur = lf_ex, tMax = t -
+    // eps) and walks from there again - the steps it took in between are discarded, the reference never sees them.
+    uint32_t burst = sc.inner_burst;
+    bool blocked = false;
+    while (active && !blocked && cur < nn && burst != 0) {
+      const float4* __restrict__ nd = (cur < nhot ? s_nodes : sc.nodes) + 2 * cur;
+#ifdef HJ_WALK_STATS
+      { const unsigned long long m = __ballot(true), mc = __ballot(cur >= nhot);
+        if (lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[1] += 1; ws[2] += __popcll(m); ws[14] += __popcll(mc); } }
+#endif
+      const float4 n0 = nd[0], n1 = nd[1];
+      uint32_t a = 0, ex = 0, nxt = cur;
+      const bool leaf = node_step(n0, n1, inv, off, r, nxt, a, ex);     // inner node: nxt = left child or exit
+      blocked = leaf && lf_has;                                         // second leaf: wait for the tests (cur stays)
+      const bool note = leaf && !lf_has;
+      lf_shape = note ? a : lf_shape;
+      lf_ex = note ? ex : lf_ex;
+      lf_has = lf_has || leaf;
+      cur = leaf ? (note ? ex : cur) : nxt;
+      burst--;
+    }
+    if (active && !lf_has && cur >= nn) { active = false; pending = true; }   // walked off the end of the tree
+#ifdef HJ_WALK_STATS
+    const unsigned long long t_c = clock64();
+    HJ_STAT(11, t_c - t_b);
+#endif
+    {
+      const unsigned long long waiting = __ballot(active && lf_has);
+      const unsigned long long must = __ballot(active && lf_has && (blocked || cur >= nn));
+      if (waiting != 0 && (must != 0 || (uint32_t)__popcll(waiting) >= sc.leaf_min)) {
+#ifdef HJ_WALK_STATS
+        if (lane == (uint32_t)__ffsll((long long)waiting) - 1u) { ws[3] += 1; ws[4] += __popcll(waiting); }
+#endif
+        if (active && lf_has) {
+          lf_has = false;
+          if (intersect_shape(sc, r, lf_shape, h)) {
+            h.id = (int)lf_shape;
+            if (MODE == 1 || (MODE == 2 && any)) { active = false; pending = true; }   // occluded shadow ray (h.id >= 0 tells finish)
+            else { r.tmax = h.t - kEps; cur = lf_ex; }               // back to the leaf's exit with the new tMax
+          }
+          if (active && cur >= nn) { active = false; pending = true; }
+        }
+      }
+    }
+#else
     uint32_t shape = 0, ex = 0;
     bool at_leaf = false;
     uint32_t burst = sc.inner_burst;       // lanes standing on a leaf wait at most this many box steps of the others
@@ -348,6 +409,7 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
       }
       cur = ex;
     }
+#endif
     HJ_STAT(12, clock64() - t_c);
   }
 #ifdef HJ_WALK_STATS

@@ -1,5 +1,6 @@
 #!/bin/bash
 # ab_variants.sh "name[:ENV=VAL,...]" ... : best of 3 C2 frames per variant library (hijiki_amd/lib/var_NAME.so; "cur" = the built library), two rounds
+export GPU_MAX_HW_QUEUES=8   # before rocprofv3 / python start: the tool library initialises HIP first, later settings are ignored
 for round in 1 2; do
   for spec in "$@"; do
     name=${spec%%:*}; envs=""; [[ "$spec" == *:* ]] && envs=$(echo "${spec#*:}" | tr ',' ' ')

@@ -1,5 +1,6 @@
 #!/bin/bash
 # HBM traffic of the path kernel on the 1 M-triangle mesh (config 4 scene), 2048^2 x 16 spp: FETCH_SIZE and WRITE_SIZE passes
+export GPU_MAX_HW_QUEUES=8   # before rocprofv3 / python start: the tool library initialises HIP first, later settings are ignored
 root=$(pwd); out=$root/gpurun_out/c4; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # pmc_split.sh OUT "C1 C2" ... : like pmc_passes.sh but over the SPLIT stage kernels (one launch per stage per bounce), so that
 # counters can be attributed to k_shade / k_trace_closest / k_trace_shadow separately.  64-spp cbox frame.
+export GPU_MAX_HW_QUEUES=8   # before rocprofv3 / python start: the tool library initialises HIP first, later settings are ignored
 out=$1; shift
 root=$(pwd)
 cd /tmp && export TMPDIR=/tmp

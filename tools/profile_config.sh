@@ -26,6 +26,14 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACT
 done
 rm -rf $out/stats
 cd $root
+# walk statistics of the same workload (diagnostic build with counters: tools/build_variant.sh stats -DHJ_WALK_STATS)
+if [ -f hijiki_amd/lib/var_stats.so ]; then
+  case $cfg in
+    c2) HJ_STATS_SPP=512 timeout 300 python3 tools/walk_stats.py 0 --json $out/walk_stats.json > $out/walk_stats.txt 2>&1 ;;
+    c3) HJ_STATS_SPP=256 timeout 300 python3 tools/walk_stats.py 1 --json $out/walk_stats.json > $out/walk_stats.txt 2>&1 ;;
+    c4) HJ_STATS_SPP=32 HJ_STATS_SIZE=2048 HJ_STATS_TRIS=1000000 timeout 300 python3 tools/walk_stats.py 2 --json $out/walk_stats.json > $out/walk_stats.txt 2>&1 ;;
+  esac
+fi
 timeout 400 python3 bench.py --config $cfg --steps 5 > $out/bench.json 2> $out/bench.err || echo "bench failed"
 python3 tools/roofline_inputs.py build $out $cfg > $out/roofline_inputs.json
 head -6 $out/kernel_stats.csv; cat $out/pmc_pass*.csv | grep -i "k_path\|^kernel" ; cat $out/roofline_inputs.json; tail -1 $out/bench.json | cut -c1-400

@@ -1,6 +1,7 @@
 #!/bin/bash
 # profile_round.sh TAG : the three rocprofv3 runs behind profiles/<TAG>_* (kernel stats, FETCH_SIZE, WRITE_SIZE), each under a timeout.
 # Run from the repo root on the GPU box; results land in gpurun_out/<TAG>/ (copy what you want judged into profiles/).
+export GPU_MAX_HW_QUEUES=8   # before rocprofv3 / python start: the tool library initialises HIP first, later settings are ignored
 tag=$1
 root=$(pwd); out=$root/gpurun_out/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp

@@ -9,8 +9,9 @@
 `build` is what tools/profile_config.sh runs last; the JSON it prints is committed as profiles/<TAG>_<CONFIG>_roofline_inputs.json
 and read by bench.py.  HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE come
 from separate passes; on gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes, so wide reads are doubled - the
-16-byte-per-lane gathers of this kernel are an uncalibrated width, so both the raw and the doubled figure are kept and
-`hbm_bytes_per_path` (what bench.py quotes as `traffic`) is the doubled (upper) one.
+gathers of this kernel are another width; tools/fetch_calib.sh calibrated them (profiles/r02_fetch_size_calibration.txt):
+random 16- / 32-byte gathers are counted as the 64-byte sectors they fetch, i.e. exactly.  Both the raw and the fully
+doubled figure are kept here; bench.py adds back only the under-counted half of the reads it knows to be coalesced.
 """
 import collections
 import csv
