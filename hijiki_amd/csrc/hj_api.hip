@@ -810,6 +810,9 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     d.refill_min = (uint32_t)env_int("HJ_REFILL_MIN", (int)hj::kRefillMin, 1, 64);
     d.cold_burst = (uint32_t)env_int("HJ_COLD_BURST", 2, 1, 1 << 20);
     d.leaf_min = (uint32_t)env_int("HJ_LEAF_MIN", 32, 1, 64);
+    d.burst_max = std::max<uint32_t>(d.inner_burst, (uint32_t)env_int("HJ_BURST_MAX", (int)d.inner_burst, 1, 1 << 20));
+    d.leaf_go = (uint32_t)env_int("HJ_LEAF_GO", 24, 1, 65);
+    d.step_min = (uint32_t)env_int("HJ_STEP_MIN", 16, 0, 64);
     HJ_UP(upload(ctx, dev.data(), dev.size(), &d.nodes));
   }
   HJ_UP(upload(ctx, isect.data(), isect.size(), &d.tri_isect));
@@ -961,11 +964,13 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
   run.tm = Timer{ctx, (run.o.flags & HJ_RENDER_TIME_KERNELS) != 0};
   run.split = (run.o.flags & HJ_RENDER_SPLIT_KERNELS) != 0;
   // Default batch: large batches amortise the latency-bound tail of a batch (measured: cbox+mirror+glass 700 ->
-  // 960 Mpaths/s from 512 to 2048 blocks), but at least ~8 batches should exist so that the slots can overlap.
+  // 960 Mpaths/s from 512 to 2048 blocks, +2-3 % more at 4096), but at least ~8 batches should exist so that the slots
+  // can overlap.  Path state does not grow with the batch (pool), only the sample buffers do (0.5 GB per 1024 blocks).
   const size_t n = total_blocks;
+  static const size_t batch_cap = (size_t)env_int("HJ_BATCH_CAP", 8192, 64, 8192);
   run.batch = run.o.batch_blocks ? run.o.batch_blocks
-                                 : (uint32_t)std::min<size_t>(2048, std::max<size_t>(256, ((n + 7) / 8 + 63) / 64 * 64));
-  run.batch = std::min<uint32_t>(run.batch, 4096u);
+                                 : (uint32_t)std::min<size_t>(batch_cap, std::max<size_t>(256, ((n + 7) / 8 + 63) / 64 * 64));
+  run.batch = std::min<uint32_t>(run.batch, run.split ? 2048u : 8192u);   // the split path keeps every sample of a batch in flight
   rc = sync_all(ctx);
   if (rc != HJ_OK) return rc;
   ctx->blocks_total = total_blocks;
@@ -1412,103 +1417,158 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
   const size_t sub_total = 2 * (size_t)m - 1;
   // src/main.rs:231 hard-codes 1 000 000 for the root's exit; larger trees get the node count (see host/scene.cpp)
   const uint32_t root_exit = total > HJ_BVH_ROOT_EXIT ? (uint32_t)total : HJ_BVH_ROOT_EXIT;
-  uint32_t sub_base = 0, sub_exit = root_exit;
-  std::vector<std::pair<uint32_t, hj_bvh_node>> top_records; // (position, record) of the host-built part
-  if (nbig != 0) {
-    // boxes of the large shapes (the rules of k_shape_boxes / src/shape.rs:13-20,46-54, src/main.rs:74-79) on the host
-    std::vector<unsigned long long> big_keys(nbig);
-    HJ_HIP(ctx, hipMemcpy(big_keys.data(), t.keys + m, sizeof(unsigned long long) * nbig, hipMemcpyDeviceToHost));
-    struct Item { float lo[3], hi[3]; uint32_t shape; uint32_t records; float weight; };
-    std::vector<Item> items(nbig + 1);
-    std::vector<float4> blo(n), bhi(n);
-    HJ_HIP(ctx, hipMemcpy(blo.data(), t.leaf_lo, sizeof(float4) * n, hipMemcpyDeviceToHost));
-    HJ_HIP(ctx, hipMemcpy(bhi.data(), t.leaf_hi, sizeof(float4) * n, hipMemcpyDeviceToHost));
-    for (uint32_t k = 0; k < nbig; k++) {
-      const uint32_t shp = (uint32_t)(big_keys[k] & idx_mask);
+  const dim3 grid_m((m + 255u) / 256u), grid_sub(((uint32_t)sub_total + 255u) / 256u);
+  hipLaunchKernelGGL(hj::lbvh::k_hierarchy, grid_m, blk, 0, st, t, m);
+  hipLaunchKernelGGL(hj::lbvh::k_refit, grid_m, blk, 0, st, t, m, idx_mask);
+  // ---- clusters of the Morton tree (HJ_LBVH_CLUSTER leaves at most; 0 = the whole tree is one cluster)
+  const uint32_t cmax_env = (uint32_t)env_int("HJ_LBVH_CLUSTER", 64, 0, 1 << 20);
+  const uint32_t cmax = cmax_env == 0 ? m : cmax_env;
+  hj::lbvh::Clusters cl{};
+  {
+    uint32_t* base_w = nullptr; uint32_t* exit_w = nullptr;
+    HJ_DEVBUF(cl.count, uint32_t, 1);
+    HJ_DEVBUF(cl.slot_of, uint32_t, sub_total);
+    HJ_DEVBUF(cl.node, uint32_t, m);
+    HJ_DEVBUF(cl.lo, float4, m);
+    HJ_DEVBUF(cl.hi, float4, m);
+    HJ_DEVBUF(base_w, uint32_t, m);
+    HJ_DEVBUF(exit_w, uint32_t, m);
+    cl.base = base_w; cl.exit = exit_w;
+    HJ_HIP(ctx, hipMemsetAsync(cl.count, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(hj::lbvh::k_mark_clusters, grid_sub, blk, 0, st, t, m, cmax, idx_mask, cl);
+  }
+  uint32_t K = 0;
+  HJ_HIP(ctx, hipMemcpyAsync(&K, cl.count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HJ_HIP(ctx, hipStreamSynchronize(st));
+  // ---- the top of the tree on the host: binned SAH over the K clusters and the nbig large shapes
+  struct Item { float lo[3], hi[3]; uint32_t shape; uint32_t cluster; uint32_t records; float weight; };
+  std::vector<Item> items(K + nbig);
+  {
+    std::vector<float4> clo(K), chi(K);
+    HJ_HIP(ctx, hipMemcpy(clo.data(), cl.lo, sizeof(float4) * K, hipMemcpyDeviceToHost));
+    HJ_HIP(ctx, hipMemcpy(chi.data(), cl.hi, sizeof(float4) * K, hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < K; k++) {
       Item& it = items[k];
-      it.lo[0] = blo[shp].x; it.lo[1] = blo[shp].y; it.lo[2] = blo[shp].z;
-      it.hi[0] = bhi[shp].x; it.hi[1] = bhi[shp].y; it.hi[2] = bhi[shp].z;
-      it.shape = shp; it.records = 1; it.weight = 1.0f;
+      it.lo[0] = clo[k].x; it.lo[1] = clo[k].y; it.lo[2] = clo[k].z;
+      it.hi[0] = chi[k].x; it.hi[1] = chi[k].y; it.hi[2] = chi[k].z;
+      const uint32_t cnt = __builtin_bit_cast(uint32_t, chi[k].w);
+      it.shape = HJ_BVH_INNER; it.cluster = k; it.records = 2 * cnt - 1; it.weight = (float)cnt;
     }
-    // item nbig = the whole Morton tree; its box = union of the small shapes' boxes (exactly what the refit computes)
-    {
-      std::vector<unsigned long long> small_keys(m);
-      HJ_HIP(ctx, hipMemcpy(small_keys.data(), t.keys, sizeof(unsigned long long) * m, hipMemcpyDeviceToHost));
-      Item& it = items[nbig];
-      for (int k = 0; k < 3; k++) { it.lo[k] = INFINITY; it.hi[k] = -INFINITY; }
-      for (uint32_t k = 0; k < m; k++) {
-        const uint32_t shp = (uint32_t)(small_keys[k] & idx_mask);
-        const float lo3[3] = {blo[shp].x, blo[shp].y, blo[shp].z}, hi3[3] = {bhi[shp].x, bhi[shp].y, bhi[shp].z};
-        for (int a = 0; a < 3; a++) { it.lo[a] = std::fmin(it.lo[a], lo3[a]); it.hi[a] = std::fmax(it.hi[a], hi3[a]); }
+    if (nbig != 0) {   // boxes of the large shapes: the ones k_shape_boxes computed (src/shape.rs:13-20,46-54, src/main.rs:74-79)
+      std::vector<unsigned long long> big_keys(nbig);
+      HJ_HIP(ctx, hipMemcpy(big_keys.data(), t.keys + m, sizeof(unsigned long long) * nbig, hipMemcpyDeviceToHost));
+      for (uint32_t k = 0; k < nbig; k++) {
+        const uint32_t shp = (uint32_t)(big_keys[k] & idx_mask);
+        float4 lo, hi;
+        HJ_HIP(ctx, hipMemcpy(&lo, t.leaf_lo + shp, sizeof(float4), hipMemcpyDeviceToHost));
+        HJ_HIP(ctx, hipMemcpy(&hi, t.leaf_hi + shp, sizeof(float4), hipMemcpyDeviceToHost));
+        Item& it = items[K + k];
+        it.lo[0] = lo.x; it.lo[1] = lo.y; it.lo[2] = lo.z; it.hi[0] = hi.x; it.hi[1] = hi.y; it.hi[2] = hi.z;
+        it.shape = shp; it.cluster = 0; it.records = 1; it.weight = 1.0f;
       }
-      it.shape = HJ_BVH_INNER; it.records = (uint32_t)sub_total; it.weight = 2.0f * std::log2((float)m + 1.0f);
     }
-    // exhaustive SAH over <= 257 items: for every axis sort by centroid, sweep all splits, keep the cheapest
-    auto area_of = [](const float* lo, const float* hi) {
-      const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-      return (dx >= 0 && dy >= 0 && dz >= 0) ? dx * dy + dy * dz + dz * dx : 0.f;
-    };
+  }
+  std::vector<std::pair<uint32_t, hj_bvh_node>> top_records; // (position, record) of the host-built part
+  std::vector<uint32_t> cbase(K, 0), cexit(K, 0);
+  {
     struct Builder {
       std::vector<Item>& items;
       std::vector<std::pair<uint32_t, hj_bvh_node>>& out;
-      decltype(area_of)& area;
-      uint32_t sub_base = 0, sub_exit = 0;
-      void box_of(const std::vector<uint32_t>& set, size_t a, size_t b, float* lo, float* hi) {
-        for (int k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
-        for (size_t i = a; i < b; i++)
-          for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], items[set[i]].lo[k]); hi[k] = std::fmax(hi[k], items[set[i]].hi[k]); }
+      std::vector<uint32_t>& cbase;
+      std::vector<uint32_t>& cexit;
+      std::vector<uint32_t> ids;
+      static float area(const float* lo, const float* hi) {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return (dx >= 0 && dy >= 0 && dz >= 0) ? dx * dy + dy * dz + dz * dx : 0.f;
       }
-      uint32_t records(const std::vector<uint32_t>& set) { uint32_t r = 0; for (uint32_t i : set) r += items[i].records; return r + (uint32_t)set.size() - 1; }
-      void emit(std::vector<uint32_t> set, uint32_t pos, uint32_t exit) {
-        if (set.size() == 1) {
-          const Item& it = items[set[0]];
-          if (it.shape == HJ_BVH_INNER) { sub_base = pos; sub_exit = exit; return; }
+      static void grow(float* lo, float* hi, const Item& it) {
+        for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], it.lo[k]); hi[k] = std::fmax(hi[k], it.hi[k]); }
+      }
+      // records of the subtree over ids[a, b): the items' own records + one inner record per split
+      uint32_t records(size_t a, size_t b) const {
+        uint32_t r = (uint32_t)(b - a) - 1;
+        for (size_t i = a; i < b; i++) r += items[ids[i]].records;
+        return r;
+      }
+      void emit(size_t a, size_t b, uint32_t pos, uint32_t exit, int depth = 0) {       // pre-order (src/main.rs:203-231)
+        if (b - a == 1) {
+          const Item& it = items[ids[a]];
+          if (it.shape == HJ_BVH_INNER) { cbase[it.cluster] = pos; cexit[it.cluster] = exit; return; }
           hj_bvh_node nd;
           for (int k = 0; k < 3; k++) { nd.aabb_min[k] = it.lo[k]; nd.aabb_max[k] = it.hi[k]; }
           nd.shape_index = it.shape; nd.exit_index = exit;
           out.emplace_back(pos, nd);
           return;
         }
-        float best = INFINITY; int best_axis = 0; size_t best_split = 1;
-        std::vector<uint32_t> sorted[3];
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = a; i < b; i++) {
+          const Item& it = items[ids[i]];
+          grow(lo, hi, it);
+          for (int k = 0; k < 3; k++) { const float c = it.lo[k] + it.hi[k]; clo[k] = std::fmin(clo[k], c); chi[k] = std::fmax(chi[k], c); }
+        }
+        // binned SAH, 16 bins per axis: cost = area(L) * weight(L) + area(R) * weight(R)
+        constexpr int B = 16;
+        float best = INFINITY; int best_axis = -1, best_bin = 0;
         for (int ax = 0; ax < 3; ax++) {
-          sorted[ax] = set;
-          std::stable_sort(sorted[ax].begin(), sorted[ax].end(), [&](uint32_t a, uint32_t b) {
-            return items[a].lo[ax] + items[a].hi[ax] < items[b].lo[ax] + items[b].hi[ax]; });
-          for (size_t sp = 1; sp < set.size(); sp++) {
-            float lo[3], hi[3], wl = 0.f, wr = 0.f;
-            box_of(sorted[ax], 0, sp, lo, hi);
-            for (size_t i = 0; i < sp; i++) wl += items[sorted[ax][i]].weight;
-            const float al = area(lo, hi);
-            box_of(sorted[ax], sp, set.size(), lo, hi);
-            for (size_t i = sp; i < set.size(); i++) wr += items[sorted[ax][i]].weight;
-            const float cost = al * wl + area(lo, hi) * wr;
-            if (cost < best) { best = cost; best_axis = ax; best_split = sp; }
+          const float ext = chi[ax] - clo[ax];
+          if (!(ext > 0.f)) continue;
+          float blo[B][3], bhi[B][3], bw[B];
+          for (int q = 0; q < B; q++) { bw[q] = 0.f; for (int k = 0; k < 3; k++) { blo[q][k] = INFINITY; bhi[q][k] = -INFINITY; } }
+          for (size_t i = a; i < b; i++) {
+            const Item& it = items[ids[i]];
+            int q = (int)(((it.lo[ax] + it.hi[ax]) - clo[ax]) / ext * (float)B);
+            q = q < 0 ? 0 : q >= B ? B - 1 : q;
+            grow(blo[q], bhi[q], it);
+            bw[q] += it.weight;
+          }
+          float rlo[B][3], rhi[B][3], rw[B];
+          float alo[3] = {INFINITY, INFINITY, INFINITY}, ahi[3] = {-INFINITY, -INFINITY, -INFINITY}, aw = 0.f;
+          for (int q = B - 1; q >= 1; q--) {
+            for (int k = 0; k < 3; k++) { alo[k] = std::fmin(alo[k], blo[q][k]); ahi[k] = std::fmax(ahi[k], bhi[q][k]); }
+            aw += bw[q];
+            for (int k = 0; k < 3; k++) { rlo[q][k] = alo[k]; rhi[q][k] = ahi[k]; }
+            rw[q] = aw;
+          }
+          float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY}, lw = 0.f;
+          for (int q = 0; q < B - 1; q++) {
+            for (int k = 0; k < 3; k++) { llo[k] = std::fmin(llo[k], blo[q][k]); lhi[k] = std::fmax(lhi[k], bhi[q][k]); }
+            lw += bw[q];
+            if (lw == 0.f || rw[q + 1] == 0.f) continue;
+            const float cost = area(llo, lhi) * lw + area(rlo[q + 1], rhi[q + 1]) * rw[q + 1];
+            if (cost < best) { best = cost; best_axis = ax; best_bin = q; }
           }
         }
-        const std::vector<uint32_t>& o = sorted[best_axis];
-        std::vector<uint32_t> left(o.begin(), o.begin() + (std::ptrdiff_t)best_split), right(o.begin() + (std::ptrdiff_t)best_split, o.end());
+        size_t mid;
+        if (best_axis < 0 || depth > 256) {
+          mid = a + (b - a) / 2;                                         // all centroids equal (or a degenerate chain): halves in list order
+        } else {
+          const float ext = chi[best_axis] - clo[best_axis];
+          auto left_of = [&](uint32_t id) {
+            const Item& it = items[id];
+            int q = (int)(((it.lo[best_axis] + it.hi[best_axis]) - clo[best_axis]) / ext * (float)B);
+            q = q < 0 ? 0 : q >= B ? B - 1 : q;
+            return q <= best_bin;
+          };
+          mid = (size_t)(std::stable_partition(ids.begin() + (std::ptrdiff_t)a, ids.begin() + (std::ptrdiff_t)b, left_of) - ids.begin());
+          if (mid == a || mid == b) mid = a + (b - a) / 2;
+        }
         hj_bvh_node nd;
-        float lo[3], hi[3];
-        box_of(set, 0, set.size(), lo, hi);
         for (int k = 0; k < 3; k++) { nd.aabb_min[k] = lo[k]; nd.aabb_max[k] = hi[k]; }
         nd.shape_index = HJ_BVH_INNER; nd.exit_index = exit;
         out.emplace_back(pos, nd);
-        const uint32_t right_pos = pos + 1 + records(left);
-        emit(left, pos + 1, right_pos);                        // exit of a left child = its sibling (src/main.rs:214-231)
-        emit(right, right_pos, exit);                          // a right child inherits its parent's exit
+        const uint32_t right_pos = pos + 1 + records(a, mid);
+        emit(a, mid, pos + 1, right_pos, depth + 1);                   // exit of a left child = its sibling
+        emit(mid, b, right_pos, exit, depth + 1);                      // a right child inherits its parent's exit
       }
-    } builder{items, top_records, area_of};
-    std::vector<uint32_t> all(nbig + 1);
-    for (uint32_t k = 0; k <= nbig; k++) all[k] = k;
-    builder.emit(all, 0, root_exit);
-    sub_base = builder.sub_base;
-    sub_exit = builder.sub_exit;
+    } builder{items, top_records, cbase, cexit, {}};
+    builder.ids.resize(items.size());
+    for (size_t k = 0; k < items.size(); k++) builder.ids[k] = (uint32_t)k;
+    builder.emit(0, items.size(), 0, root_exit);
   }
-  const dim3 grid_m((m + 255u) / 256u), grid_sub(((uint32_t)sub_total + 255u) / 256u);
-  hipLaunchKernelGGL(hj::lbvh::k_hierarchy, grid_m, blk, 0, st, t, m);
-  hipLaunchKernelGGL(hj::lbvh::k_refit, grid_m, blk, 0, st, t, m, idx_mask);
-  hipLaunchKernelGGL(hj::lbvh::k_emit, grid_sub, blk, 0, st, t, m, sub_base, sub_exit, idx_mask, d_out);
+  HJ_HIP(ctx, hipMemcpyAsync(const_cast<uint32_t*>(cl.base), cbase.data(), sizeof(uint32_t) * K, hipMemcpyHostToDevice, st));
+  HJ_HIP(ctx, hipMemcpyAsync(const_cast<uint32_t*>(cl.exit), cexit.data(), sizeof(uint32_t) * K, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(hj::lbvh::k_emit_clusters, grid_sub, blk, 0, st, t, m, cl, idx_mask, d_out);
   HJ_HIP(ctx, hipGetLastError());
   HJ_HIP(ctx, hipMemcpyAsync(out_nodes, d_out, sizeof(hj_bvh_node) * total, hipMemcpyDeviceToHost, st));
   HJ_HIP(ctx, hipStreamSynchronize(st));

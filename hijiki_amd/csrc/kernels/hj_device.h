@@ -50,6 +50,7 @@ struct DeviceScene {
   uint32_t refill_min;          // free lanes that trigger a ray refill
   uint32_t cold_burst;          // max HBM-node steps per round of the persistent walk (HJ_WALK_SPLIT)
   uint32_t leaf_min;            // lanes with a postponed leaf test that make the wave run the tests (HJ_WALK_SPEC)
+  uint32_t burst_max, leaf_go, step_min;   // adaptive burst (HJ_ADAPTIVE_BURST): see trace_persistent
   const float4* tri_isect;
   const float4* tri_shade;
   const float4* spheres;        // hj_sphere

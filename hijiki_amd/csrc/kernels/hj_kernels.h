@@ -218,6 +218,9 @@ HJ_DEV bool traverse(const DeviceScene& sc, Ray r, RawHit& h) {
 // Each ray still performs exactly the reference's pre-order skip-link walk (scene.glsl:97-133).
 //   fetch(i, slot, ray)   loads queue entry i
 //   finish(done, slot, h) wave-convergent: called when some lanes are done; `done` lanes have a final result
+#ifndef HJ_ADAPTIVE_BURST
+#define HJ_ADAPTIVE_BURST 0   // 1 = wave-uniform box-step loop that extends the burst while few lanes stand on a leaf: measured -3 ... -6 %
+#endif
 #ifndef HJ_WALK_SPEC
 #define HJ_WALK_SPEC 0    // 1 = postponed leaf tests (see trace_persistent): bit-exact, measured -10 % (cbox) / -12 % (1 M triangles)
 #endif
@@ -376,6 +379,33 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
 #endif
     }
 #else
+#if HJ_ADAPTIVE_BURST
+    // Wave-uniform loop: after `inner_burst` box steps the wave goes on stepping (up to burst_max steps) while few lanes
+    // stand on a leaf (< leaf_go) and many still step (>= step_min): leaf tests then run with more lanes, less often.
+    uint32_t extra = sc.burst_max - sc.inner_burst;
+    for (;;) {
+      const bool stepping = active && cur < nn && !at_leaf;
+      const unsigned long long ms = __ballot(stepping);
+      if (ms == 0) break;
+      if (burst == 0) {
+        if (extra == 0) break;
+        const uint32_t nl = (uint32_t)__popcll(__ballot(active && at_leaf));
+        if (nl >= sc.leaf_go || (uint32_t)__popcll(ms) < sc.step_min) break;
+        extra--;
+        burst = 1;
+      }
+      if (stepping) {
+        const float4* __restrict__ nd = (cur < nhot ? s_nodes : sc.nodes) + 2 * cur;
+#ifdef HJ_WALK_STATS
+        { const unsigned long long m = __ballot(true), mc = __ballot(cur >= nhot);
+          if (lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[1] += 1; ws[2] += __popcll(m); ws[14] += __popcll(mc); } }
+#endif
+        const float4 n0 = nd[0], n1 = nd[1];
+        at_leaf = node_step(n0, n1, inv, off, r, cur, shape, ex);
+      }
+      burst--;
+    }
+#else
     while (active && cur < nn && !at_leaf && burst != 0) {
       // hot node: LDS copy, same 32-byte record layout as in HBM, so that ONE address select feeds both 16-byte
       // loads (FLAT loads of base + 32*cur and +16; a per-array `if` compiled to two exec-masked address blocks)
@@ -388,6 +418,7 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
       at_leaf = node_step(n0, n1, inv, off, r, cur, shape, ex);
       burst--;
     }
+#endif
 #endif
     if (active && !at_leaf && cur >= nn) { active = false; pending = true; }   // walked off the end of the tree
 #ifdef HJ_WALK_STATS
@@ -531,6 +562,9 @@ HJ_DEV v3 checkerboard(const DeviceScene& sc, uint32_t idx, float u, float v) {
 // A path workgroup owns queue segment g in every queue, so the stages of one bounce need only workgroup
 // barriers between them.  The same stage functions are used by the split per-stage kernels and by the fused
 // persistent kernel k_path_wavefront (one launch per batch: camera rays, then the bounce loop).
+
+// A value every lane of the wave reads from the same LDS word: keep it in a scalar register (an LDS load lands in a VGPR).
+HJ_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 struct WgShared {                 // LDS of a path workgroup (8.3 KB)
   uint32_t head;                  // next unread entry of the merged queue being walked
@@ -730,7 +764,7 @@ HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uin
 #pragma unroll
   for (uint32_t k = 0; k < kNumTags; k++) {
     base[k] = 0;
-    for (uint32_t w = 0; w < wave; w++) base[k] += sh.wcnt[w][k];
+    for (uint32_t w = 0; w < wave; w++) base[k] += uni(sh.wcnt[w][k]);
   }
   for (uint32_t row = r0; row < r1; row++) {
     const uint32_t i = row * 64u + lane;
@@ -761,7 +795,7 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
   const uint32_t np = parity ^ 1u;
   // one material tag at a time: every wave shades ONE tag (no divergent BSDF switch)
   for (uint32_t tag = 0; tag < kNumTags; tag++) {
-    const uint32_t n = sh.cnt_hit[tag];
+    const uint32_t n = uni(sh.cnt_hit[tag]);
     const uint32_t* __restrict__ q = st.q_hit + ((size_t)tag * G + g) * st.pool;
     for (uint32_t base = wave * 64u; base < n; base += waves * 64u) {
     const uint32_t i = base + lane;
@@ -922,7 +956,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
     wg_sync(waves);
     for (uint32_t parity = 0;; parity ^= 1u) {
       // top-up: new camera paths behind the continuing ones, whole 64-sample groups while they fit
-      const uint32_t n0 = sh.n_ray[parity];
+      const uint32_t n0 = uni(sh.n_ray[parity]);
       const uint32_t ngen = min(groups_left, (st.pool - n0) >> 6);
       if (ngen != 0) {
         stage_gen_camera(st, sc, g, sh, parity, n0, k_next, ngen, waves);
@@ -930,7 +964,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
         groups_left -= ngen;
         wg_sync(waves);
       }
-      const uint32_t n = n0 + sh.n_gen, ns = sh.n_shadow;
+      const uint32_t n = n0 + uni(sh.n_gen), ns = uni(sh.n_shadow);
       if (n + ns == 0) {
         if (groups_left == 0) break;
         continue;                            // every sample of the new groups lay outside its block: next groups
@@ -955,8 +989,8 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
       if (n != 0) stage_shade(st, sc, g, parity, max_bounces, rr_start, sh, waves);
       total_closest += n;
       total_shadow += ns;
-      for (uint32_t k = 0; k < kNumTags; k++) total_hits += sh.cnt_hit[k];
-      total_unocc += sh.n_unocc;
+      for (uint32_t k = 0; k < kNumTags; k++) total_hits += uni(sh.cnt_hit[k]);
+      total_unocc += uni(sh.n_unocc);
       wg_sync(waves);
 #ifdef HJ_WALK_STATS
       if (threadIdx.x == 0) {
@@ -1128,7 +1162,8 @@ __global__ __launch_bounds__(256) void k_reconstruct(BatchState st, const float*
         const int e = (py + 2 + dy) * TS + (px + 2 + dx);
         const float4 nd = s_nd[e];
         const v3 no = xyz(nd) - nc;
-        w *= hj_exp(-(dot3(no, no) * 2.0f));
+        const float dn = dot3(no, no) * 2.0f;
+        if (dn != 0.0f) w *= hj_exp(-dn);     // equal normals (flat walls: most taps): hj_exp(-0) == 1 exactly, the product is w
         const float4 c = s_rgb[e];
         const float v0 = w * c.x, v1 = w * c.y, v2 = w * c.z, v3_ = w * c.w;
         if (v0 != v0 || v1 != v1 || v2 != v2 || v3_ != v3_) continue;

@@ -9,7 +9,8 @@
 // in the construction of BVHs, octrees and k-d trees"), bounds by a bottom-up pass.  LARGE shapes (box area above
 // 1/64 of the scene's, e.g. the walls of the box around a mesh) are kept OUT of the Morton tree: sorted by centroid they
 // would sit deep inside it and blow the boxes of all their ancestors up to scene size; they go into a small SAH tree
-// that the host builds over them and the root of the Morton tree (hj_api.hip).  The image does not depend on the
+// that the host builds over them and over the CLUSTERS of the Morton tree (its subtrees of at most 64 leaves; hj_api.hip),
+// so that only the lowest levels keep the Morton splits.  The image does not depend on the
 // topology except through epsilon-ties.
 //
 // Pre-order without a traversal: a subtree over k leaves has 2k - 1 records, so for a node whose subtree covers
@@ -217,6 +218,80 @@ __global__ __launch_bounds__(256) void k_refit(Tree t, uint32_t n, unsigned long
     t.node_hi[node] = make_float4(f_max(hi[0].x, hi[1].x), f_max(hi[0].y, hi[1].y), f_max(hi[0].z, hi[1].z), 0.f);
     p = t.parent[node];
   }
+}
+
+// CLUSTERS: the Morton tree is cut into subtrees of at most `cmax` leaves (node ids: internal node i = i, sorted leaf k =
+// n - 1 + k).  The host builds a SAH tree over the clusters' boxes (and the large shapes), so only the lowest levels keep
+// the Morton splits (an HLBVH in the sense of Garanzha et al. 2011, with the host doing the top levels).
+constexpr uint32_t kNoCluster = 0xFFFFFFFFu;
+struct Clusters {
+  uint32_t* count;        // [1] number of clusters
+  uint32_t* slot_of;      // [2n - 1] cluster number of a node that is a cluster root, kNoCluster otherwise
+  uint32_t* node;         // [n] root node id of cluster k
+  float4* lo;             // [n] box of cluster k, w = bits of its first sorted leaf
+  float4* hi;             //                        w = bits of its leaf count
+  const uint32_t* base;   // [K] position of the cluster's first record in the output (from the host)
+  const uint32_t* exit;   // [K] exit of the cluster's right spine
+};
+
+__global__ __launch_bounds__(256) void k_mark_clusters(Tree t, uint32_t n, uint32_t cmax, unsigned long long idx_mask, Clusters c) {
+  const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= 2 * n - 1) return;
+  const bool leaf = id >= n - 1;
+  const uint32_t cnt = leaf ? 1u : t.count[id];
+  const uint32_t p = t.parent[id];
+  const uint32_t pcnt = p == kNoParent ? 0xFFFFFFFFu : t.count[p & ~kLeafBit];
+  uint32_t slot = kNoCluster;
+  if (cnt <= cmax && pcnt > cmax) {
+    slot = atomicAdd(c.count, 1u);
+    c.node[slot] = id;
+    float4 lo, hi;
+    uint32_t first;
+    if (leaf) {
+      const uint32_t shape = (uint32_t)(t.keys[id - (n - 1)] & idx_mask);
+      lo = t.leaf_lo[shape]; hi = t.leaf_hi[shape]; first = id - (n - 1);
+    } else {
+      lo = t.node_lo[id]; hi = t.node_hi[id]; first = t.first[id];
+    }
+    lo.w = __uint_as_float(first); hi.w = __uint_as_float(cnt);
+    c.lo[slot] = lo; c.hi[slot] = hi;
+  }
+  c.slot_of[id] = slot;
+}
+
+// Records of the nodes INSIDE the clusters (the nodes above the cluster roots are replaced by the host's tree):
+// position = base of the cluster + the pre-order position inside the cluster's subtree (see the top of this file).
+__global__ __launch_bounds__(256) void k_emit_clusters(Tree t, uint32_t n, Clusters c, unsigned long long idx_mask, hj_bvh_node* out) {
+  const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= 2 * n - 1) return;
+  uint32_t root = id, turns = 0;
+  while (c.slot_of[root] == kNoCluster) {
+    const uint32_t p = t.parent[root];
+    if (p == kNoParent) return;                               // above the clusters
+    turns += p >> 31;
+    root = p & ~kLeafBit;
+  }
+  const uint32_t slot = c.slot_of[root];
+  const uint32_t rfirst = __float_as_uint(c.lo[slot].w), rcnt = __float_as_uint(c.hi[slot].w);
+  const bool leaf = id >= n - 1;
+  const uint32_t k = leaf ? id - (n - 1) : 0;
+  const uint32_t first = leaf ? k : t.first[id], cnt = leaf ? 1u : t.count[id];
+  const uint32_t base = c.base[slot];
+  const uint32_t pos = base + 2 * (first - rfirst) + turns, end = pos + 2 * cnt - 1;
+  float4 lo, hi;
+  uint32_t shape = HJ_BVH_INNER;
+  if (leaf) {
+    shape = (uint32_t)(t.keys[k] & idx_mask);
+    lo = t.leaf_lo[shape]; hi = t.leaf_hi[shape];
+  } else {
+    lo = t.node_lo[id]; hi = t.node_hi[id];
+  }
+  hj_bvh_node nd;
+  nd.aabb_min[0] = lo.x; nd.aabb_min[1] = lo.y; nd.aabb_min[2] = lo.z;
+  nd.shape_index = shape;
+  nd.aabb_max[0] = hi.x; nd.aabb_max[1] = hi.y; nd.aabb_max[2] = hi.z;
+  nd.exit_index = end >= base + 2 * rcnt - 1 ? c.exit[slot] : end;
+  out[pos] = nd;
 }
 
 // One record of the reference's flattened array per tree node (internal nodes: threads [0, n-1), leaves: the rest).

@@ -30,8 +30,8 @@ cd $root
 if [ -f hijiki_amd/lib/var_stats.so ]; then
   case $cfg in
     c2) HJ_STATS_SPP=512 timeout 300 python3 tools/walk_stats.py 0 --json $out/walk_stats.json > $out/walk_stats.txt 2>&1 ;;
-    c3) HJ_STATS_SPP=256 timeout 300 python3 tools/walk_stats.py 1 --json $out/walk_stats.json > $out/walk_stats.txt 2>&1 ;;
-    c4) HJ_STATS_SPP=32 HJ_STATS_SIZE=2048 HJ_STATS_TRIS=1000000 timeout 300 python3 tools/walk_stats.py 2 --json $out/walk_stats.json > $out/walk_stats.txt 2>&1 ;;
+    c3) HJ_STATS_SPP=1024 timeout 300 python3 tools/walk_stats.py 1 --json $out/walk_stats.json > $out/walk_stats.txt 2>&1 ;;
+    c4) HJ_STATS_SPP=256 HJ_STATS_SIZE=2048 HJ_STATS_TRIS=1000000 timeout 300 python3 tools/walk_stats.py 2 --json $out/walk_stats.json > $out/walk_stats.txt 2>&1 ;;
   esac
 fi
 timeout 400 python3 bench.py --config $cfg --steps 5 > $out/bench.json 2> $out/bench.err || echo "bench failed"

@@ -1,6 +1,6 @@
 """Wave-level occupancy of the walk's phases (needs the diagnostic build: tools/build_variant.sh stats -DHJ_WALK_STATS).
 
-    python tools/walk_stats.py KIND [MAX_BOUNCES] [--json OUT]     env: HJ_STATS_SPP (16), HJ_STATS_SIZE (1024), HJ_STATS_TRIS
+    python tools/walk_stats.py KIND [MAX_BOUNCES] [--json OUT]     env: HJ_STATS_SPP (512 = the batch sizes of the benchmark; small frames give small batches and emptier waves), HJ_STATS_SIZE (1024), HJ_STATS_TRIS
 """
 import sys, os, json, ctypes as C
 os.environ.setdefault("HIJIKI_HIP_LIB", "hijiki_amd/lib/var_stats.so")
@@ -13,7 +13,7 @@ if "--json" in argv:
     del argv[argv.index("--json"):argv.index("--json") + 2]
 kind = int(argv[0]) if len(argv) > 0 else host.SYNTH_CBOX
 max_bounces = int(argv[1]) if len(argv) > 1 else 0     # 1 = camera rays and their shadow rays only
-spp = int(os.environ.get("HJ_STATS_SPP", "16")); size = int(os.environ.get("HJ_STATS_SIZE", "1024"))
+spp = int(os.environ.get("HJ_STATS_SPP", "512")); size = int(os.environ.get("HJ_STATS_SIZE", "1024"))
 cs = host.Scene.synthetic(kind, mesh_triangles=int(os.environ.get("HJ_STATS_TRIS", "0"))).compile()
 r = device.Renderer(0); r.upload_scene(cs); r.create_framebuffer(size, size)
 L = device.lib()
