@@ -813,7 +813,27 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     d.burst_max = std::max<uint32_t>(d.inner_burst, (uint32_t)env_int("HJ_BURST_MAX", (int)d.inner_burst, 1, 1 << 20));
     d.leaf_go = (uint32_t)env_int("HJ_LEAF_GO", 24, 1, 65);
     d.step_min = (uint32_t)env_int("HJ_STEP_MIN", 16, 0, 64);
-    HJ_UP(upload(ctx, dev.data(), dev.size(), &d.nodes));
+    // The walk adds 32 * index to the low word of the array's address without a carry (kernels/hj_kernels.h): the
+    // array must not cross a 4 GiB boundary.  Allocate twice the size and start at the boundary if it would.
+    {
+      const size_t bytes = std::max<size_t>(dev.size() * sizeof(float4), 16);
+      if (bytes >= (1ull << 32)) { release_scene(ctx); return set_error(ctx, HJ_ERR_UNSUPPORTED, "BVH of %zu records: the device node array is limited to 4 GiB", M); }
+      ctx->scene_bufs.emplace_back();
+      DevBuf& b = ctx->scene_bufs.back();
+      HJ_UP(dev_alloc(ctx, b, bytes));
+      uintptr_t start = reinterpret_cast<uintptr_t>(b.p);
+      if ((start >> 32) != ((start + bytes - 1) >> 32)) {
+        b.release();
+        HJ_UP(dev_alloc(ctx, b, 2 * bytes));
+        start = reinterpret_cast<uintptr_t>(b.p);
+        if ((start >> 32) != ((start + bytes - 1) >> 32)) start = ((start >> 32) + 1) << 32;
+      }
+      if (hipMemcpy(reinterpret_cast<void*>(start), dev.data(), dev.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess) {
+        release_scene(ctx);
+        return set_error(ctx, HJ_ERR_DEVICE, "node upload failed");
+      }
+      d.nodes = reinterpret_cast<const float4*>(start);
+    }
   }
   HJ_UP(upload(ctx, isect.data(), isect.size(), &d.tri_isect));
   HJ_UP(upload(ctx, shade.data(), shade.size(), &d.tri_shade));

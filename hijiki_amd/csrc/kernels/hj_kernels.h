@@ -80,7 +80,8 @@ struct RawHit { float t, u, v; int id; };
 
 // reference shader/shapes/triangle.glsl:15-52 on the pre-gathered record
 HJ_DEV bool intersect_triangle(const DeviceScene& sc, const Ray& r, uint32_t ix, RawHit& h) {
-  const float4 A = sc.tri_isect[3 * ix + 0], B = sc.tri_isect[3 * ix + 1], C = sc.tri_isect[3 * ix + 2];
+  const float4* __restrict__ rec = sc.tri_isect + 3 * (size_t)ix;      // one address, three offsets
+  const float4 A = rec[0], B = rec[1], C = rec[2];
   const v3 a = xyz(A), ab = xyz(B), ac = xyz(C);
   const v3 n = cross3(ab, ac);
   const v3 ro = r.o - a;
@@ -109,7 +110,8 @@ HJ_DEV bool intersect_sphere(const Ray& r, float4 sp, RawHit& h) {
 }
 // reference shader/shapes/quad.glsl:7-25
 HJ_DEV bool intersect_quad(const DeviceScene& sc, const Ray& r, uint32_t ix, RawHit& h) {
-  const v3 o = xyz(sc.quads[3 * ix + 0]), e1 = xyz(sc.quads[3 * ix + 1]), e2 = xyz(sc.quads[3 * ix + 2]);
+  const float4* __restrict__ rec = sc.quads + 3 * (size_t)ix;
+  const v3 o = xyz(rec[0]), e1 = xyz(rec[1]), e2 = xyz(rec[2]);
   const v3 n = cross3(e1, e2);
   const v3 ro = r.o - o;
   const v3 q = cross3(ro, r.d);
@@ -218,6 +220,9 @@ HJ_DEV bool traverse(const DeviceScene& sc, Ray r, RawHit& h) {
 // Each ray still performs exactly the reference's pre-order skip-link walk (scene.glsl:97-133).
 //   fetch(i, slot, ray)   loads queue entry i
 //   finish(done, slot, h) wave-convergent: called when some lanes are done; `done` lanes have a final result
+#ifndef HJ_WALK_MASKED_FETCH
+#define HJ_WALK_MASKED_FETCH 0   // 1 = ds_read for the lanes on LDS-resident nodes + global loads for the others, one wait (inline asm): same speed as FLAT
+#endif
 #ifndef HJ_ADAPTIVE_BURST
 #define HJ_ADAPTIVE_BURST 0   // 1 = wave-uniform box-step loop that extends the burst while few lanes stand on a leaf: measured -3 ... -6 %
 #endif
@@ -252,6 +257,15 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
   uint32_t slot = 0, cur = 0;
   Ray r; r.o = V(0, 0, 0); r.d = V(0, 0, 0); r.tmin = 0.f; r.tmax = 0.f;
   v3 inv = V(0, 0, 0), off = V(0, 0, 0);
+  // base addresses of the node array and of its LDS copy as opaque VGPR values (see the box-step loop)
+  uint32_t nb_glo, nb_ghi, nb_llo, nb_lhi;
+  {
+    const uint64_t gb = reinterpret_cast<uint64_t>(sc.nodes), lb = reinterpret_cast<uint64_t>(s_nodes);
+    asm volatile("v_mov_b32 %0, %1" : "=v"(nb_glo) : "s"((uint32_t)gb));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(nb_ghi) : "s"((uint32_t)(gb >> 32)));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(nb_llo) : "s"((uint32_t)lb));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(nb_lhi) : "s"((uint32_t)(lb >> 32)));
+  }
 #if HJ_WALK_SPEC
   bool lf_has = false;               // a leaf whose shape test is postponed: (lf_shape, lf_ex)
   uint32_t lf_shape = 0, lf_ex = 0;
@@ -408,13 +422,36 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
 #else
     while (active && cur < nn && !at_leaf && burst != 0) {
       // hot node: LDS copy, same 32-byte record layout as in HBM, so that ONE address select feeds both 16-byte
-      // loads (FLAT loads of base + 32*cur and +16; a per-array `if` compiled to two exec-masked address blocks)
-      const float4* __restrict__ nd = (cur < nhot ? s_nodes : sc.nodes) + 2 * cur;
+      // loads (FLAT loads of base + 32*cur and +16; a per-array `if` compiled to two exec-masked address blocks).
+      // The two base addresses sit in four VGPRs (nb_*): v_cndmask cannot take a scalar source beside VCC, and the
+      // compiler otherwise re-creates them with four v_mov per step.
+      // Neither array crosses a 4 GiB boundary (hj_scene_upload places the node array so; the LDS aperture cannot),
+      // so the low word never carries into the high one: cmp + 2 cndmask + 1 shift-add instead of ten instructions.
+      const bool hot = cur < nhot;
 #ifdef HJ_WALK_STATS
       { const unsigned long long m = __ballot(true), mc = __ballot(cur >= nhot);     // [14] lane-steps on nodes outside the LDS copy
         if (lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[1] += 1; ws[2] += __popcll(m); ws[14] += __popcll(mc); } }
 #endif
+#if HJ_WALK_MASKED_FETCH
+      // The lanes on a hot node read the LDS copy with ds_read (LDS pipeline), the others the HBM array with global
+      // loads (texture path) - two exec-masked instruction pairs issued back to back and ONE wait for both, instead of
+      // FLAT loads that send every lane through the texture addresser.  Hand-written: the compiler would wait inside
+      // each branch (the LDS and the global latency in series).
+      f4s v0, v1;
+      if (hot) {
+        const uint32_t la = nb_llo + (cur << 5);
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(v0), "=&v"(v1) : "v"(la));
+      } else {
+        const uint64_t ga = ((uint64_t)nb_ghi << 32) | (uint64_t)(nb_glo + (cur << 5));
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(v0), "=&v"(v1) : "v"(ga));
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(v0), "+v"(v1));
+      const float4 n0 = make_float4(v0.x, v0.y, v0.z, v0.w), n1 = make_float4(v1.x, v1.y, v1.z, v1.w);
+#else
+      const uint32_t a_lo = (hot ? nb_llo : nb_glo) + (cur << 5), a_hi = hot ? nb_lhi : nb_ghi;
+      const float4* __restrict__ nd = reinterpret_cast<const float4*>(((uint64_t)a_hi << 32) | (uint64_t)a_lo);
       const float4 n0 = nd[0], n1 = nd[1];
+#endif
       at_leaf = node_step(n0, n1, inv, off, r, cur, shape, ex);
       burst--;
     }
@@ -459,8 +496,8 @@ struct Its { v3 p, n, ft, fb; float u, v; };   // frame = [ft fb n]
 
 // reference shader/shapes/triangle.glsl:54-78
 HJ_DEV void populate_triangle(const DeviceScene& sc, uint32_t ix, float hu, float hv, Its& its) {
-  const float4 A = sc.tri_shade[4 * ix + 0], B = sc.tri_shade[4 * ix + 1], C = sc.tri_shade[4 * ix + 2],
-               Vv = sc.tri_shade[4 * ix + 3];
+  const float4* __restrict__ rec = sc.tri_shade + 4 * (size_t)ix;
+  const float4 A = rec[0], B = rec[1], C = rec[2], Vv = rec[3];
   const float l0 = (1.0f - hu) - hv, l1 = hu, l2 = hv;
   const v3 ns = (xyz(A) * l0 + xyz(B) * l1) + xyz(C) * l2;
   its.n = normalize3(ns);

@@ -1,0 +1,5 @@
+#!/bin/bash
+export GPU_MAX_HW_QUEUES=8
+out=gpurun_out/r2_ab12; mkdir -p $out
+echo "== C2"; tools/ab_variants.sh cur s_ilp s_memcl s_iter 2>&1 | tee $out/c2.txt
+echo "== C4"; PROBE_ARGS="--kind 2 --tris 1000000 --size 2048 --spp 32" tools/ab_variants.sh cur s_ilp s_memcl 2>&1 | tee $out/c4.txt
