@@ -411,6 +411,8 @@ int stage_blocks(hj_context* ctx, hj_context::BatchSlot& sl, const hj_image_bloc
   st = sl.st;
   st.blocks = static_cast<const hj_image_block*>(sl.d_blocks.p);
   st.num_blocks = nb;
+  static const int xcd_env = env_int("HJ_XCD_DEAL", 0, 0, 1);
+  st.xcd_deal = (xcd_env && !all_in_flight && st.num_wg == 2048u && hj::kSlotsPerBlock / 64u == 256u) ? 1u : 0u;
   std::memcpy(sl.h_blocks, blocks, sizeof(hj_image_block) * nb);
   HJ_HIP(ctx, hipMemcpyAsync(sl.d_blocks.p, sl.h_blocks, sizeof(hj_image_block) * nb, hipMemcpyHostToDevice, sl.stream));
   return HJ_OK;
@@ -708,67 +710,17 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
       }
     }
     auto resolve = [&](size_t i) { while (i < N && del[i]) i++; return i; };   // first kept node of a subtree
-    // Records: an inner node takes one 32-byte slot; a leaf takes one slot, or (HJ_LEAF_INLINE) two slots that hold
-    // the shape itself (kernels/hj_device.h), so that the leaf test needs no fetch from another array.
-    auto slots_of = [&](size_t i) -> uint32_t { return (HJ_LEAF_INLINE && s->bvh[i].shape_index != HJ_BVH_INNER) ? 2u : 1u; };
     std::vector<uint32_t> order, map(N, 0);
     for (size_t i = 0; i < N; i++) if (!del[i]) order.push_back((uint32_t)i);
+    const size_t M = order.size();
+    const uint32_t hot = (uint32_t)std::min<size_t>(hj::kHotNodes, M);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return sa[a] > sa[b]; });
     std::vector<char> is_hot(N, 0);
-    uint32_t hot = 0;                                            // slots of the LDS-resident prefix
-    for (uint32_t x : order) {                                   // largest area first; a leaf never straddles the boundary
-      if (hot + slots_of(x) > hj::kHotNodes) { if (hot + 1 > hj::kHotNodes) break; else continue; }
-      map[x] = hot; is_hot[x] = 1; hot += slots_of(x);
-    }
-    // The other nodes: TREELET order.  A treelet is one 128-byte cache line (4 slots): a node and as many of its
-    // descendants as fit, the largest (= most often visited) first; treelets follow each other depth first.  A step
-    // from a node to one of its children then mostly stays inside the line the walk has just fetched, where the plain
-    // pre-order keeps only the left spine together.  (Measured on the 1 M-triangle scene: within 1 % of the plain pre-order at 4, 8 and 16 slots, so the default is 0 = pre-order.)
+    for (size_t k = 0; k < hot; k++) { map[order[k]] = (uint32_t)k; is_hot[order[k]] = 1; }
+    // the other nodes keep their pre-order (a treelet-blocked order - a node and its largest descendants per 128-byte
+    // line - was measured on the 1 M-triangle scene: within 1 % at 4, 8 and 16 records per treelet)
     uint32_t next = hot;
-    const uint32_t tl = (uint32_t)env_int("HJ_TREELET_SLOTS", 0, 0, 64);
-    if (tl < 2) {
-      for (size_t i = 0; i < N; i++) if (!del[i] && !is_hot[i]) { map[i] = next; next += slots_of(i); }
-    } else {
-      auto subtree_end = [&](size_t i) { return (size_t)std::min<uint64_t>(s->bvh[i].exit_index, N); };
-      auto for_children = [&](size_t i, auto&& fn) {           // kept children of kept inner node i, in visiting order
-        if (s->bvh[i].shape_index != HJ_BVH_INNER) return;
-        const size_t end = subtree_end(i);
-        for (size_t c = resolve(i + 1); c < end; c = resolve(subtree_end(c))) fn(c);
-      };
-      next = (next + tl - 1) / tl * tl;                        // lines start at multiples of the treelet size
-      std::vector<size_t> roots;                               // treelet roots still to place (LIFO = depth first)
-      if (N) roots.push_back(resolve(0));
-      std::vector<std::pair<float, size_t>> heap;
-      std::vector<size_t> later;
-      while (!roots.empty()) {
-        const size_t root = roots.back();
-        roots.pop_back();
-        uint32_t budget = tl;
-        heap.clear();
-        later.clear();
-        heap.emplace_back(sa[root], root);
-        bool first = true;
-        while (!heap.empty()) {
-          std::pop_heap(heap.begin(), heap.end());
-          const size_t x = heap.back().second;
-          heap.pop_back();
-          if (is_hot[x]) {                                     // lives in the LDS prefix: only its children need a place
-            for_children(x, [&](size_t c) { heap.emplace_back(sa[c], c); std::push_heap(heap.begin(), heap.end()); });
-            continue;
-          }
-          if (slots_of(x) > budget && !first) { later.push_back(x); continue; }
-          first = false;
-          map[x] = next;
-          next += slots_of(x);
-          budget -= std::min(budget, slots_of(x));
-          for_children(x, [&](size_t c) { heap.emplace_back(sa[c], c); std::push_heap(heap.begin(), heap.end()); });
-        }
-        next = (next + tl - 1) / tl * tl;
-        std::sort(later.begin(), later.end(), std::greater<size_t>());     // popped in pre-order
-        for (size_t x : later) roots.push_back(x);
-      }
-    }
-    const size_t M = next;                                       // slots in all
+    for (size_t i = 0; i < N; i++) if (!del[i] && !is_hot[i]) map[i] = next++;
     std::vector<float4> dev(2 * M, make_float4(0.f, 0.f, 0.f, 0.f));
     for (size_t i = 0; i < N; i++) {
       if (del[i]) continue;
@@ -784,35 +736,12 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
       float4* rec = &dev[2 * (size_t)map[i]];
       rec[0] = make_float4(nd.aabb_min[0], nd.aabb_min[1], nd.aabb_min[2], __builtin_bit_cast(float, a));
       rec[1] = make_float4(nd.aabb_max[0], nd.aabb_max[1], nd.aabb_max[2], __builtin_bit_cast(float, b));
-      if (slots_of(i) == 2) {                  // leaf boxes are never tested (scene.glsl:105-119): the shape takes their place
-        const uint32_t sh = nd.shape_index;
-        if (sh < s->num_spheres) {
-          const hj_sphere& sp = s->spheres[sh];
-          rec[0].x = sp.center[0]; rec[0].y = sp.center[1]; rec[0].z = sp.center[2];
-          rec[1].x = sp.radius; rec[1].y = 0.f; rec[1].z = 0.f;
-        } else if (sh < s->num_spheres + s->num_quads) {
-          const hj_quad& q = s->quads[sh - s->num_spheres];
-          rec[0].x = q.origin[0]; rec[0].y = q.origin[1]; rec[0].z = q.origin[2];
-          rec[1].x = q.edge1[0]; rec[1].y = q.edge1[1]; rec[1].z = q.edge1[2];
-          rec[2] = make_float4(q.edge2[0], q.edge2[1], q.edge2[2], 0.f);
-        } else {
-          const size_t t = sh - s->num_spheres - s->num_quads;
-          rec[0].x = isect[3 * t].x; rec[0].y = isect[3 * t].y; rec[0].z = isect[3 * t].z;            // a
-          rec[1].x = isect[3 * t + 1].x; rec[1].y = isect[3 * t + 1].y; rec[1].z = isect[3 * t + 1].z;   // b - a
-          rec[2] = isect[3 * t + 2];                                                                   // c - a
-        }
-      }
     }
     d.num_nodes = (uint32_t)M;
     d.root = N ? map[0] : 0u;
     d.num_hot = hot;
     d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", 4, 1, 1 << 20);   // >= 1, or the walk would never advance
     d.refill_min = (uint32_t)env_int("HJ_REFILL_MIN", (int)hj::kRefillMin, 1, 64);
-    d.cold_burst = (uint32_t)env_int("HJ_COLD_BURST", 2, 1, 1 << 20);
-    d.leaf_min = (uint32_t)env_int("HJ_LEAF_MIN", 32, 1, 64);
-    d.burst_max = std::max<uint32_t>(d.inner_burst, (uint32_t)env_int("HJ_BURST_MAX", (int)d.inner_burst, 1, 1 << 20));
-    d.leaf_go = (uint32_t)env_int("HJ_LEAF_GO", 24, 1, 65);
-    d.step_min = (uint32_t)env_int("HJ_STEP_MIN", 16, 0, 64);
     // The walk adds 32 * index to the low word of the array's address without a carry (kernels/hj_kernels.h): the
     // array must not cross a 4 GiB boundary.  Allocate twice the size and start at the boundary if it would.
     {

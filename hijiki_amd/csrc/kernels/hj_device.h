@@ -18,9 +18,6 @@ constexpr uint32_t kEmitRecF4 = 7;
 #endif
 constexpr uint32_t kHotNodes = HJ_HOT_NODES;
 constexpr uint32_t kInnerFlag = 0x80000000u;
-#ifndef HJ_LEAF_INLINE
-#define HJ_LEAF_INLINE 0    // 1 = leaves carry their shape in the node array (two 32-byte slots): measured -3 % (cbox), -1 % (1 M triangles)
-#endif
 
 // Scene data in HBM.  `nodes` are 32-byte records (two float4 per node) derived from the reference's
 // skip-link array (same tree, same boxes, same visiting order) but RE-INDEXED: the kHotNodes nodes with the
@@ -29,12 +26,6 @@ constexpr uint32_t kInnerFlag = 0x80000000u;
 // record" no longer holds, links are explicit:
 //   n0 = (aabb_min.xyz, A)   A = shape index for a leaf, 0x80000000 | left-child index for an inner node
 //   n1 = (aabb_max.xyz, B)   B = exit index (>= num_nodes ends the walk)
-// A LEAF record (HJ_LEAF_INLINE) takes TWO consecutive 32-byte slots and holds the shape itself where an inner node
-// holds its box (a leaf's box is never tested, scene.glsl:105-119):
-//   triangle: (a.xyz, A) (b-a .xyz, B) (c-a .xyz, -) (-)     quad: (origin, A) (edge1, B) (edge2, -) (-)
-//   sphere:   (centre.xyz, A) (radius, -, -, B)
-// so the leaf test reads the line the box step has just fetched instead of a record of another array (one dependent
-// fetch fewer per leaf).  Indices (left child, exit, root, num_nodes, num_hot) count 32-byte slots.
 // The walk starts at `root`.  Triangles are additionally pre-gathered per
 // triangle so that a leaf test is ONE dependent fetch instead of the
 // reference's index -> vertex chain (shader/shapes/triangle.glsl:16-18):
@@ -48,9 +39,6 @@ struct DeviceScene {
   uint32_t num_hot;             // nodes [0, num_hot) are the LDS-cached ones (<= kHotNodes)
   uint32_t inner_burst;         // max box steps per round of the persistent walk before leaf tests run
   uint32_t refill_min;          // free lanes that trigger a ray refill
-  uint32_t cold_burst;          // max HBM-node steps per round of the persistent walk (HJ_WALK_SPLIT)
-  uint32_t leaf_min;            // lanes with a postponed leaf test that make the wave run the tests (HJ_WALK_SPEC)
-  uint32_t burst_max, leaf_go, step_min;   // adaptive burst (HJ_ADAPTIVE_BURST): see trace_persistent
   const float4* tri_isect;
   const float4* tri_shade;
   const float4* spheres;        // hj_sphere
@@ -112,6 +100,7 @@ struct BatchState {
   uint32_t capacity;             // samples allocated
   uint32_t num_wg;               // grid size of every stage kernel
   uint32_t pool;                 // positions per workgroup, multiple of 64
+  uint32_t xcd_deal;             // sample groups dealt per XCD (hj_kernels.h: wg_group)
 };
 
 }  // namespace hj

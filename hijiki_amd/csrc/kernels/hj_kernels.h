@@ -124,26 +124,6 @@ HJ_DEV bool intersect_quad(const DeviceScene& sc, const Ray& r, uint32_t ix, Raw
   return false;
 }
 
-// The leaf test on an inline leaf record (hj_device.h): the same arithmetic as intersect_triangle / _quad / _sphere on
-// values that are copies of the ones those read.
-HJ_DEV bool intersect_leaf(const DeviceScene& sc, const Ray& r, uint32_t shape, const float4* __restrict__ nd, RawHit& h) {
-  const float4 A = nd[0], B = nd[1];
-  if (shape < sc.ns) return intersect_sphere(r, make_float4(A.x, A.y, A.z, B.x), h);
-  const float4 C = nd[2];
-  const v3 e1 = xyz(B), e2 = xyz(C);
-  const v3 n = cross3(e1, e2);
-  const v3 ro = r.o - xyz(A);
-  const v3 q = cross3(ro, r.d);
-  const float d = 1.0f / dot3(r.d, n);
-  const float u = d * (-dot3(q, e2));
-  const float v = d * dot3(q, e1);
-  const bool quad = shape < sc.ns + sc.nq;
-  if (quad ? (u < 0.0f || u > 1.0f || v < 0.0f || v > 1.0f) : (u < 0.0f || v < 0.0f || u + v > 1.0f)) return false;
-  const float t = d * (-dot3(n, ro));
-  if (r.tmin <= t && t <= r.tmax) { h.t = t; h.u = u; h.v = v; return true; }
-  return false;
-}
-
 HJ_DEV bool intersect_shape(const DeviceScene& sc, const Ray& r, uint32_t shape, RawHit& h) {
   if (shape < sc.ns) return intersect_sphere(r, sc.spheres[shape], h);
   if (shape < sc.ns + sc.nq) return intersect_quad(sc, r, shape - sc.ns, h);
@@ -220,25 +200,13 @@ HJ_DEV bool traverse(const DeviceScene& sc, Ray r, RawHit& h) {
 // Each ray still performs exactly the reference's pre-order skip-link walk (scene.glsl:97-133).
 //   fetch(i, slot, ray)   loads queue entry i
 //   finish(done, slot, h) wave-convergent: called when some lanes are done; `done` lanes have a final result
-#ifndef HJ_WALK_MASKED_FETCH
-#define HJ_WALK_MASKED_FETCH 0   // 1 = ds_read for the lanes on LDS-resident nodes + global loads for the others, one wait (inline asm): same speed as FLAT
-#endif
-#ifndef HJ_ADAPTIVE_BURST
-#define HJ_ADAPTIVE_BURST 0   // 1 = wave-uniform box-step loop that extends the burst while few lanes stand on a leaf: measured -3 ... -6 %
-#endif
-#ifndef HJ_WALK_SPEC
-#define HJ_WALK_SPEC 0    // 1 = postponed leaf tests (see trace_persistent): bit-exact, measured -10 % (cbox) / -12 % (1 M triangles)
-#endif
-#ifndef HJ_WALK_SPLIT
-#define HJ_WALK_SPLIT 0   // 1 = separate ds_read (hot) and global (cold) box-step phases: measured -12 % (cbox) / -30 % (1 M triangles), DESIGN.md
-#endif
 constexpr uint32_t kRefillMin = 32;   // sweep on the fused kernel: 16 -> 1.39, 32..48 -> 1.43 Gpaths/s, 64 -> 1.24
 
 #ifdef HJ_WALK_STATS
 // Diagnostic build only (tools/build_variant.sh stats -DHJ_WALK_STATS): wave-level occupancy of the walk's phases.
 // [0] outer iterations [1] inner wave-steps [2] lanes in them [3] leaf phases [4] lanes in them [5] refills
 // [6] lanes refilled [7] lanes active at the start of an outer iteration
-__device__ unsigned long long g_walk_stats[16];   // [8] cold wave-steps [9] lanes in them (HJ_WALK_SPLIT)
+__device__ unsigned long long g_walk_stats[16];   // [10..12] wave cycles by phase, [13] total, [14] lane-steps on nodes outside the LDS copy
 // rounds of the fused kernel by size bucket b (rays of the round in [64 * 4^b / 4, 64 * 4^b), b = 0..7):
 // [b] rounds, [8 + b] rays, [16 + b] wave-cycles (wall clock of the round x waves of the workgroup still alive)
 __device__ unsigned long long g_round_stats[24];
@@ -266,10 +234,6 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     asm volatile("v_mov_b32 %0, %1" : "=v"(nb_llo) : "s"((uint32_t)lb));
     asm volatile("v_mov_b32 %0, %1" : "=v"(nb_lhi) : "s"((uint32_t)(lb >> 32)));
   }
-#if HJ_WALK_SPEC
-  bool lf_has = false;               // a leaf whose shape test is postponed: (lf_shape, lf_ex)
-  uint32_t lf_shape = 0, lf_ex = 0;
-#endif
   RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
 #ifdef HJ_WALK_STATS
   unsigned long long ws[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -299,9 +263,6 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
             inv = V(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
             off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
             cur = sc.root; h.id = -1; active = true;
-#if HJ_WALK_SPEC
-            lf_has = false;
-#endif
           }
         }
         exhausted = base + nidle >= n;
@@ -314,112 +275,9 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     const unsigned long long t_b = clock64();
     HJ_STAT(10, t_b - t_a);
 #endif
-#if HJ_WALK_SPEC
-    // POSTPONED LEAF TESTS.  A lane that reaches a leaf does not stop: it notes the leaf (lf_shape, lf_ex) and walks on
-    // from the leaf's exit with its CURRENT tMax, until it reaches a second leaf or the end of the tree (then it is
-    // `blocked`).  The wave runs the shape tests when a lane is blocked or leaf_min lanes have one waiting, i.e. with
-    // many lanes at once instead of the ~15 that happen to stand on a leaf after every burst of box steps.  Exact: a
-    // test that MISSES changes nothing, so the steps taken meanwhile are the reference's steps; a test that HITS
-    // lowers tMax, so the lane goes back to the leaf's exit (its state there is fully known: cur = lf_ex, tMax = t -
-    // eps) and walks from there again - the steps it took in between are discarded, the reference never sees them.
-    uint32_t burst = sc.inner_burst;
-    bool blocked = false;
-    while (active && !blocked && cur < nn && burst != 0) {
-      const float4* __restrict__ nd = (cur < nhot ? s_nodes : sc.nodes) + 2 * cur;
-#ifdef HJ_WALK_STATS
-      { const unsigned long long m = __ballot(true), mc = __ballot(cur >= nhot);
-        if (lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[1] += 1; ws[2] += __popcll(m); ws[14] += __popcll(mc); } }
-#endif
-      const float4 n0 = nd[0], n1 = nd[1];
-      uint32_t a = 0, ex = 0, nxt = cur;
-      const bool leaf = node_step(n0, n1, inv, off, r, nxt, a, ex);     // inner node: nxt = left child or exit
-      blocked = leaf && lf_has;                                         // second leaf: wait for the tests (cur stays)
-      const bool note = leaf && !lf_has;
-      lf_shape = note ? a : lf_shape;
-      lf_ex = note ? ex : lf_ex;
-      lf_has = lf_has || leaf;
-      cur = leaf ? (note ? ex : cur) : nxt;
-      burst--;
-    }
-    if (active && !lf_has && cur >= nn) { active = false; pending = true; }   // walked off the end of the tree
-#ifdef HJ_WALK_STATS
-    const unsigned long long t_c = clock64();
-    HJ_STAT(11, t_c - t_b);
-#endif
-    {
-      const unsigned long long waiting = __ballot(active && lf_has);
-      const unsigned long long must = __ballot(active && lf_has && (blocked || cur >= nn));
-      if (waiting != 0 && (must != 0 || (uint32_t)__popcll(waiting) >= sc.leaf_min)) {
-#ifdef HJ_WALK_STATS
-        if (lane == (uint32_t)__ffsll((long long)waiting) - 1u) { ws[3] += 1; ws[4] += __popcll(waiting); }
-#endif
-        if (active && lf_has) {
-          lf_has = false;
-          if (intersect_shape(sc, r, lf_shape, h)) {
-            h.id = (int)lf_shape;
-            if (MODE == 1 || (MODE == 2 && any)) { active = false; pending = true; }   // occluded shadow ray (h.id >= 0 tells finish)
-            else { r.tmax = h.t - kEps; cur = lf_ex; }               // back to the leaf's exit with the new tMax
-          }
-          if (active && cur >= nn) { active = false; pending = true; }
-        }
-      }
-    }
-#else
     uint32_t shape = 0, ex = 0;
     bool at_leaf = false;
     uint32_t burst = sc.inner_burst;       // lanes standing on a leaf wait at most this many box steps of the others
-#if HJ_WALK_SPLIT
-    // Two box-step phases per round.  HOT: nodes [0, nhot) are read from the workgroup's LDS copy with ds_read
-    // (latency ~100 cycles): lanes standing on a cold node or a leaf sit these steps out.  COLD: lanes standing on
-    // a node of the HBM array take up to cold_burst steps with global loads (several hundred cycles each).  With one
-    // FLAT load for both (the previous form) every wave-step waited for its slowest lane, i.e. for a global fetch,
-    // although five of six node visits are hot.
-    while (active && !at_leaf && cur < nhot && burst != 0) {
-      const float4 n0 = s_nodes[2 * cur], n1 = s_nodes[2 * cur + 1];
-      at_leaf = node_step(n0, n1, inv, off, r, cur, shape, ex);
-      burst--;
-#ifdef HJ_WALK_STATS
-      { const unsigned long long m = __ballot(true); if (lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[1] += 1; ws[2] += __popcll(m); } }
-#endif
-    }
-    uint32_t cburst = sc.cold_burst;
-    while (active && !at_leaf && cur >= nhot && cur < nn && cburst != 0) {
-      const float4* __restrict__ nd = sc.nodes + 2 * cur;
-      const float4 n0 = nd[0], n1 = nd[1];
-      at_leaf = node_step(n0, n1, inv, off, r, cur, shape, ex);
-      cburst--;
-#ifdef HJ_WALK_STATS
-      { const unsigned long long m = __ballot(true); if (lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[8] += 1; ws[9] += __popcll(m); } }
-#endif
-    }
-#else
-#if HJ_ADAPTIVE_BURST
-    // Wave-uniform loop: after `inner_burst` box steps the wave goes on stepping (up to burst_max steps) while few lanes
-    // stand on a leaf (< leaf_go) and many still step (>= step_min): leaf tests then run with more lanes, less often.
-    uint32_t extra = sc.burst_max - sc.inner_burst;
-    for (;;) {
-      const bool stepping = active && cur < nn && !at_leaf;
-      const unsigned long long ms = __ballot(stepping);
-      if (ms == 0) break;
-      if (burst == 0) {
-        if (extra == 0) break;
-        const uint32_t nl = (uint32_t)__popcll(__ballot(active && at_leaf));
-        if (nl >= sc.leaf_go || (uint32_t)__popcll(ms) < sc.step_min) break;
-        extra--;
-        burst = 1;
-      }
-      if (stepping) {
-        const float4* __restrict__ nd = (cur < nhot ? s_nodes : sc.nodes) + 2 * cur;
-#ifdef HJ_WALK_STATS
-        { const unsigned long long m = __ballot(true), mc = __ballot(cur >= nhot);
-          if (lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[1] += 1; ws[2] += __popcll(m); ws[14] += __popcll(mc); } }
-#endif
-        const float4 n0 = nd[0], n1 = nd[1];
-        at_leaf = node_step(n0, n1, inv, off, r, cur, shape, ex);
-      }
-      burst--;
-    }
-#else
     while (active && cur < nn && !at_leaf && burst != 0) {
       // hot node: LDS copy, same 32-byte record layout as in HBM, so that ONE address select feeds both 16-byte
       // loads (FLAT loads of base + 32*cur and +16; a per-array `if` compiled to two exec-masked address blocks).
@@ -432,31 +290,12 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
       { const unsigned long long m = __ballot(true), mc = __ballot(cur >= nhot);     // [14] lane-steps on nodes outside the LDS copy
         if (lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[1] += 1; ws[2] += __popcll(m); ws[14] += __popcll(mc); } }
 #endif
-#if HJ_WALK_MASKED_FETCH
-      // The lanes on a hot node read the LDS copy with ds_read (LDS pipeline), the others the HBM array with global
-      // loads (texture path) - two exec-masked instruction pairs issued back to back and ONE wait for both, instead of
-      // FLAT loads that send every lane through the texture addresser.  Hand-written: the compiler would wait inside
-      // each branch (the LDS and the global latency in series).
-      f4s v0, v1;
-      if (hot) {
-        const uint32_t la = nb_llo + (cur << 5);
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(v0), "=&v"(v1) : "v"(la));
-      } else {
-        const uint64_t ga = ((uint64_t)nb_ghi << 32) | (uint64_t)(nb_glo + (cur << 5));
-        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(v0), "=&v"(v1) : "v"(ga));
-      }
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(v0), "+v"(v1));
-      const float4 n0 = make_float4(v0.x, v0.y, v0.z, v0.w), n1 = make_float4(v1.x, v1.y, v1.z, v1.w);
-#else
       const uint32_t a_lo = (hot ? nb_llo : nb_glo) + (cur << 5), a_hi = hot ? nb_lhi : nb_ghi;
       const float4* __restrict__ nd = reinterpret_cast<const float4*>(((uint64_t)a_hi << 32) | (uint64_t)a_lo);
       const float4 n0 = nd[0], n1 = nd[1];
-#endif
       at_leaf = node_step(n0, n1, inv, off, r, cur, shape, ex);
       burst--;
     }
-#endif
-#endif
     if (active && !at_leaf && cur >= nn) { active = false; pending = true; }   // walked off the end of the tree
 #ifdef HJ_WALK_STATS
     const unsigned long long t_c = clock64();
@@ -464,12 +303,7 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     { const unsigned long long m = __ballot(at_leaf); if (m && lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[3] += 1; ws[4] += __popcll(m); } }
 #endif
     if (at_leaf) {
-#if HJ_LEAF_INLINE
-      // the record of the leaf the lane stands on (cur has not moved): the line the box step fetched, or the LDS copy
-      const bool found = intersect_leaf(sc, r, shape, (cur < nhot ? s_nodes : sc.nodes) + 2 * cur, h);
-#else
       const bool found = intersect_shape(sc, r, shape, h);
-#endif
       if (found) {
         h.id = (int)shape;
         if (MODE == 1 || (MODE == 2 && any)) { active = false; pending = true; }   // occluded shadow ray (h.id >= 0 tells finish)
@@ -477,7 +311,6 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
       }
       cur = ex;
     }
-#endif
     HJ_STAT(12, clock64() - t_c);
   }
 #ifdef HJ_WALK_STATS
@@ -629,10 +462,20 @@ HJ_DEV void wg_sync(uint32_t waves) {
   }
 }
 
-// Sample groups of workgroup g: group k of its sequence is global group g + k * num_wg.
+// Sample groups of workgroup g (a group = 64 consecutive samples of a block row; 256 groups per block).
+//   round-robin deal: group k of its sequence is global group g + k * num_wg (every workgroup samples the whole image);
+//   XCD deal (st.xcd_deal, needs num_wg == 2048): workgroups are dispatched round-robin over the 8 XCDs, so workgroup g
+//   runs on XCD g & 7 (an affinity, used for speed only).  It takes group g >> 3 of every block b with b & 7 == g & 7:
+//   an XCD then traces the camera rays (and their shadow rays) of one eighth of the block positions - vertical stripes of
+//   the image - and its L2 holds that part of a large scene instead of all of it.
 HJ_DEV uint32_t wg_num_groups(const BatchState& st, uint32_t g) {
+  if (st.xcd_deal) return st.num_blocks > (g & 7u) ? (st.num_blocks - (g & 7u) + 7u) / 8u : 0u;
   const uint32_t groups = (st.num_blocks * kSlotsPerBlock + 63u) / 64u;
   return groups > g ? (groups - g + st.num_wg - 1u) / st.num_wg : 0u;
+}
+HJ_DEV uint32_t wg_group(const BatchState& st, uint32_t g, uint32_t k) {
+  if (st.xcd_deal) return (8u * k + (g & 7u)) * (kSlotsPerBlock / 64u) + (g >> 3);
+  return g + k * st.num_wg;
 }
 
 // reference shader/render.glsl:26-36,149-162: camera paths for groups [k0, k0 + ngen) of this workgroup's sample
@@ -640,12 +483,11 @@ HJ_DEV uint32_t wg_num_groups(const BatchState& st, uint32_t g) {
 // caller guarantees n0 + 64 * ngen <= pool).
 HJ_DEV void stage_gen_camera(const BatchState& st, const DeviceScene& sc, uint32_t g, WgShared& sh, uint32_t parity,
                              uint32_t n0, uint32_t k0, uint32_t ngen, uint32_t waves) {
-  const uint32_t G = st.num_wg;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t total = st.num_blocks * kSlotsPerBlock;
   const uint32_t seg = g * st.pool + n0;
   for (uint32_t k = k0 + wave; k < k0 + ngen; k += waves) {
-    const uint32_t smp = (g + k * G) * 64u + lane;
+    const uint32_t smp = wg_group(st, g, k) * 64u + lane;
     bool valid = smp < total;
     hj_image_block b;
     uint32_t lx = 0, ly = 0;
