@@ -3,8 +3,10 @@
     roofline_inputs.py trace KERNEL_TRACE.csv STEPS     k_path_wavefront launches: average, and the average + exclusive
                                                         (union of intervals) time over the last STEPS frames
     roofline_inputs.py pmc COUNTER_COLLECTION.csv       per-kernel sums of every counter in the file (CSV on stdout)
-    roofline_inputs.py build DIR CONFIG                 DIR/pmc_pass*.csv (+ kernel_trace_summary.txt, walk stats JSON)
-                                                        -> the roofline_inputs JSON on stdout
+    roofline_inputs.py build DIR CONFIG [PREFIX]        DIR/[PREFIX]pmc_pass*.csv (+ kernel_trace_summary.txt, walk stats JSON)
+                                                        -> the roofline_inputs JSON on stdout;
+                                                        `build profiles c2 r02_c2_` regenerates profiles/r02_c2_roofline_inputs.json
+                                                        from the committed CSVs (tests/test_roofline_inputs.py checks exactly that)
 
 `build` is what tools/profile_config.sh runs last; the JSON it prints is committed as profiles/<TAG>_<CONFIG>_roofline_inputs.json
 and read by bench.py.  HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE come
@@ -60,17 +62,28 @@ def cmd_pmc(path):
         print(f"{k},{max(cnt[(k, c)] for c in names)}," + ",".join(f"{agg[k][c]:.0f}" for c in names))
 
 
-def cmd_build(d, cfg):
-    c = {}
-    launches = 0
-    for f in sorted(glob.glob(os.path.join(d, "pmc_pass*.csv"))):
-        for r in csv.DictReader(open(f)):
-            if "k_path_wavefront" not in r["kernel"]:
+def read_passes(files):
+    """{counter: sum over the k_path_wavefront launches}, launches - from the per-pass CSVs `cmd_pmc` writes, or from the
+    file profiles/<TAG>_<CONFIG>_pmc_passes.csv that holds them one after the other (a header line before each)."""
+    c, launches = {}, 0
+    for f in files:
+        header = None
+        for row in csv.reader(open(f)):
+            if not row:
                 continue
-            launches = max(launches, int(r["launches"]))
-            for k, v in r.items():
-                if k not in ("kernel", "launches"):
+            if row[0] == "kernel":
+                header = row
+            elif header and "k_path_wavefront" in row[0] and len(row) == len(header):
+                launches = max(launches, int(row[1]))
+                for k, v in zip(header[2:], row[2:]):
                     c[k] = float(v)
+    return c, launches
+
+
+def cmd_build(d, cfg, prefix=""):
+    """`d` = a directory of tools/profile_config.sh, or (with `prefix` = "<TAG>_<CONFIG>_") profiles/ itself."""
+    files = sorted(glob.glob(os.path.join(d, prefix + "pmc_pass*.csv")))
+    c, launches = read_passes(files)
     paths = PATHS[cfg]
     out = {"config": cfg, "kernel": "k_path_wavefront", "paths_per_frame": paths, "launches_per_frame": launches,
            "command": f"tools/profile_config.sh: rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py --config {cfg} --steps 1 --warmup 0 --no-cpu-baseline, one pass per group, GPU_MAX_HW_QUEUES=8",
@@ -91,7 +104,7 @@ def cmd_build(d, cfg):
                 lim[n] = round(c[k] / c["SQ_WAVE_CYCLES"], 4)
     if c.get("TCC_HIT_sum") is not None and (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) > 0:
         lim["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
-    ws = os.path.join(d, "walk_stats.json")
+    ws = os.path.join(d, prefix + "walk_stats.json")
     if os.path.exists(ws):
         w = json.load(open(ws))
         lim["walk_lanes_per_box_step"] = round(w["lanes_per_box_step"], 1)
@@ -102,7 +115,7 @@ def cmd_build(d, cfg):
     lim["name"] = ("dependent fetch latency of the BVH walk at partially filled waves (VALU instructions execute with "
                    f"{lim.get('valu_lanes_per_instruction', '?')} of 64 lanes; waves wait {100 * lim.get('waiting_share_of_wave_cycles', 0):.0f} % of their cycles)")
     out["limiter"] = lim
-    t = os.path.join(d, "kernel_trace_summary.txt")
+    t = os.path.join(d, prefix + "kernel_trace_summary.txt")
     if os.path.exists(t):
         out["kernel_trace_summary"] = open(t).read().strip()
     print(json.dumps(out, indent=1))
@@ -113,5 +126,7 @@ if __name__ == "__main__":
         cmd_trace(sys.argv[2], int(sys.argv[3]))
     elif sys.argv[1] == "pmc":
         cmd_pmc(sys.argv[2])
+    elif len(sys.argv) > 4:
+        cmd_build(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         cmd_build(sys.argv[2], sys.argv[3])
