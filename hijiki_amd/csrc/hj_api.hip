@@ -439,8 +439,9 @@ int enqueue_batch_fused(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::
   // HJ_LDS_PAD_KB (diagnostic): unused dynamic LDS that lowers the number of resident workgroups per CU without
   // touching the code, to measure how the frame rate scales with occupancy.
   static const size_t lds_pad = (size_t)env_int("HJ_LDS_PAD_KB", 0, 0, 64) * 1024;
-  if (o.use_bvh) hipLaunchKernelGGL(hj::k_path_wavefront<true>, grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
-  else hipLaunchKernelGGL(hj::k_path_wavefront<false>, grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  if (!o.use_bvh) hipLaunchKernelGGL((hj::k_path_wavefront<false, false>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  else if (ctx->scene.has_pairs) hipLaunchKernelGGL((hj::k_path_wavefront<true, true>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  else hipLaunchKernelGGL((hj::k_path_wavefront<true, false>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
   tm.end(ev, sl.stream);
   if (reconstruct) {
     rc = enqueue_reconstruct(ctx, sl, other, st, nb, o, tm);
@@ -709,6 +710,36 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
         anc[l] = anc[r] = del[i] ? anc[i] : sa[i];
       }
     }
+    // Pair nodes (kernels/hj_kernels.h leaf_test): an inner node whose two children are triangle leaves keeps its
+    // record, the two leaves lose theirs (nothing but the pair's own walk ever reaches them: the left one is the
+    // node's first child, the right one the left one's exit) and their triangles go side by side into `pairs`.
+    std::vector<uint32_t> pair_of(N, 0xFFFFFFFFu);
+    std::vector<float4> pairs;
+    // Worth it on large scenes (1 M triangles: +7 %: a fifth fewer dependent fetch rounds per ray, most of them trips
+    // beyond the L2).  On cache-resident scenes the longer leaf phase (two tests while the rest of the wave waits) costs
+    // more than the rounds save: -7 % on the 6 k-triangle box, -5 % at 60 k triangles, -2 % at 200 k.  So small trees keep
+    // plain leaves and run the kernel instantiation without the pair code.  HJ_PAIR_LEAVES = 0 / 1 forces; default:
+    // trees of >= HJ_PAIR_MIN_NODES records.
+    const int pair_env = env_int("HJ_PAIR_LEAVES", -1, -1, 1);
+    if (pair_env == 1 || (pair_env < 0 && N >= (size_t)env_int("HJ_PAIR_MIN_NODES", 1000000, 0, 1 << 30))) {
+      const size_t first_tri = s->num_spheres + s->num_quads;
+      for (size_t i = 0; i + 2 < N; i++) {
+        if (s->bvh[i].shape_index != HJ_BVH_INNER) continue;
+        const size_t l = i + 1, r = s->bvh[l].exit_index;
+        if (r >= N || r != l + 1) continue;
+        const uint32_t sl = s->bvh[l].shape_index, sr = s->bvh[r].shape_index;
+        if (sl == HJ_BVH_INNER || sr == HJ_BVH_INNER || sl < first_tri || sr < first_tri) continue;
+        if (s->bvh[r].exit_index != s->bvh[i].exit_index) continue;      // (a well-formed tree: the right child's exit is its parent's)
+        pair_of[i] = (uint32_t)(pairs.size() / 6);
+        for (uint32_t sh : {sl, sr}) {
+          const size_t t = sh - first_tri;
+          float4 a = isect[3 * t];
+          a.w = __builtin_bit_cast(float, sh);
+          pairs.push_back(a); pairs.push_back(isect[3 * t + 1]); pairs.push_back(isect[3 * t + 2]);
+        }
+        del[l] = del[r] = 1;                                              // no records for the two leaves
+      }
+    }
     auto resolve = [&](size_t i) { while (i < N && del[i]) i++; return i; };   // first kept node of a subtree
     std::vector<uint32_t> order, map(N, 0);
     for (size_t i = 0; i < N; i++) if (!del[i]) order.push_back((uint32_t)i);
@@ -727,6 +758,7 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
       const hj_bvh_node& nd = s->bvh[i];
       uint32_t a;
       if (nd.shape_index != HJ_BVH_INNER) a = nd.shape_index;
+      else if (pair_of[i] != 0xFFFFFFFFu) a = hj::kInnerFlag | hj::kPairFlag | pair_of[i];
       else {
         const size_t l = resolve(i + 1);                                             // left child = next pre-order record
         a = hj::kInnerFlag | (l < N ? map[l] : (uint32_t)M);
@@ -737,6 +769,8 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
       rec[0] = make_float4(nd.aabb_min[0], nd.aabb_min[1], nd.aabb_min[2], __builtin_bit_cast(float, a));
       rec[1] = make_float4(nd.aabb_max[0], nd.aabb_max[1], nd.aabb_max[2], __builtin_bit_cast(float, b));
     }
+    HJ_UP(upload(ctx, pairs.data(), pairs.size(), &d.tri_pair));
+    d.has_pairs = pairs.empty() ? 0u : 1u;
     d.num_nodes = (uint32_t)M;
     d.root = N ? map[0] : 0u;
     d.num_hot = hot;

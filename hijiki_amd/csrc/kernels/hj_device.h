@@ -18,13 +18,17 @@ constexpr uint32_t kEmitRecF4 = 7;
 #endif
 constexpr uint32_t kHotNodes = HJ_HOT_NODES;
 constexpr uint32_t kInnerFlag = 0x80000000u;
+constexpr uint32_t kPairFlag = 0x40000000u;    // with kInnerFlag: an inner node whose two children are triangle leaves
+constexpr uint32_t kIndexMask = 0x3FFFFFFFu;
 
 // Scene data in HBM.  `nodes` are 32-byte records (two float4 per node) derived from the reference's
 // skip-link array (same tree, same boxes, same visiting order) but RE-INDEXED: the kHotNodes nodes with the
 // largest surface area come first (every workgroup keeps a copy of them in LDS: on cbox 64 nodes take 77 % of
 // all node fetches, 256 take 84 %), the rest follow in the original pre-order.  Because "left child = next
 // record" no longer holds, links are explicit:
-//   n0 = (aabb_min.xyz, A)   A = shape index for a leaf, 0x80000000 | left-child index for an inner node
+//   n0 = (aabb_min.xyz, A)   A = shape index for a leaf, 0x80000000 | left-child index for an inner node,
+//                            0xC0000000 | pair index for an inner node over two triangle leaves (those two leaves
+//                            have no records of their own: hj_kernels.h leaf_test)
 //   n1 = (aabb_max.xyz, B)   B = exit index (>= num_nodes ends the walk)
 // The walk starts at `root`.  Triangles are additionally pre-gathered per
 // triangle so that a leaf test is ONE dependent fetch instead of the
@@ -40,6 +44,7 @@ struct DeviceScene {
   uint32_t inner_burst;         // max box steps per round of the persistent walk before leaf tests run
   uint32_t refill_min;          // free lanes that trigger a ray refill
   const float4* tri_isect;
+  const float4* tri_pair;       // 6 x float4 per pair node: (a, b-a, c-a) of the left and of the right triangle, shape indices in [0].w, [3].w
   const float4* tri_shade;
   const float4* spheres;        // hj_sphere
   const float4* quads;          // hj_quad as 3 x float4
@@ -54,6 +59,7 @@ struct DeviceScene {
   const float4* emissive;
   uint32_t ns, nq, nt, num_emitters;
   uint32_t has_extinction;      // any dielectric with non-zero extinction
+  uint32_t has_pairs;           // the node array holds pair nodes (tri_pair)
   hj_camera camera;
   float tan_half_fov;           // (float)tan(radians(fov/2)) evaluated in double on the host
 };

@@ -130,10 +130,63 @@ HJ_DEV bool intersect_shape(const DeviceScene& sc, const Ray& r, uint32_t shape,
   return intersect_triangle(sc, r, shape - sc.ns - sc.nq, h);
 }
 
+// triangle.glsl:15-52 on record values (a, b - a, c - a)
+HJ_DEV bool triangle_test(const Ray& r, float4 A, float4 B, float4 C, RawHit& h) {
+  const v3 ab = xyz(B), ac = xyz(C);
+  const v3 n = cross3(ab, ac);
+  const v3 ro = r.o - xyz(A);
+  const v3 q = cross3(ro, r.d);
+  const float d = 1.0f / dot3(r.d, n);
+  const float u = d * (-dot3(q, ac));
+  const float v = d * dot3(q, ab);
+  if (u < 0.0f || v < 0.0f || u + v > 1.0f) return false;
+  const float t = d * (-dot3(n, ro));
+  if (r.tmin <= t && t <= r.tmax) { h.t = t; h.u = u; h.v = v; return true; }
+  return false;
+}
+
+// What the walk does when it stands on a leaf: `a` is the first word of the node the lane stopped at.
+//   leaf record:  a = shape index                      -> one shape test (scene.glsl:105-119)
+//   PAIR record:  a = kInnerFlag | kPairFlag | pair    -> an inner node whose two children are triangle leaves, entered:
+//                 the reference now visits the left leaf, tests its triangle, goes to its exit = the right leaf, tests
+//                 that one with the tMax the first test left, and goes on to the right leaf's exit = the pair's own
+//                 exit.  Both triangles sit side by side in sc.tri_pair (their shape indices in the w lanes), so the two
+//                 node fetches and one of the two leaf phases of that sequence are gone; the tests and their order
+//                 are the same.
+// Returns true when the ray is finished (an any-hit ray that hit).
+template <bool PAIRS>
+HJ_DEV bool leaf_test(const DeviceScene& sc, Ray& r, uint32_t a, RawHit& h, bool any) {
+  if (!PAIRS || (a & kInnerFlag) == 0u) {
+    if (intersect_shape(sc, r, a, h)) {
+      h.id = (int)a;
+      if (any) return true;
+      r.tmax = h.t - kEps;
+    }
+    return false;
+  }
+  const float4* __restrict__ rec = sc.tri_pair + 6 * (size_t)(a & kIndexMask);
+  const float4 A = rec[0], B = rec[1], C = rec[2], D = rec[3], E = rec[4], F = rec[5];
+  // (computing both triangles' (u, v, t) side by side without the early returns was measured: 1 % slower on the 1 M-triangle
+  // scene - most tests end at the u / v check)
+  if (triangle_test(r, A, B, C, h)) {
+    h.id = (int)__float_as_uint(A.w);
+    if (any) return true;
+    r.tmax = h.t - kEps;
+  }
+  if (triangle_test(r, D, E, F, h)) {
+    h.id = (int)__float_as_uint(D.w);
+    if (any) return true;
+    r.tmax = h.t - kEps;
+  }
+  return false;
+}
+
 // One node of the walk (scene.glsl:103-131).  Both 16-byte halves are consumed and the box test is evaluated
 // BEFORE the leaf/inner decision, with selects only (no branch for the compiler to sink the loads behind): one
 // memory round trip per node.  For a leaf the box result is ignored (leaf boxes are never tested upstream).
-// Returns true when `cur` is a leaf (a = shape index); otherwise advances cur to the left child or the exit.
+// Returns true when the lane has to stop for shape tests (a leaf: a = shape index; a pair node it enters: a = the
+// node's first word); otherwise advances cur to the left child or the exit.
+template <bool PAIRS>
 HJ_DEV bool node_step(float4 n0, float4 n1, v3 inv, v3 off, const Ray& r, uint32_t& cur, uint32_t& a, uint32_t& ex) {
   const float tnx = fmaf(n0.x, inv.x, off.x), tpx = fmaf(n1.x, inv.x, off.x);
   const float tny = fmaf(n0.y, inv.y, off.y), tpy = fmaf(n1.y, inv.y, off.y);
@@ -143,10 +196,11 @@ HJ_DEV bool node_step(float4 n0, float4 n1, v3 inv, v3 off, const Ray& r, uint32
   const bool enter = (t0 < t1 + kEps && t0 < r.tmax && t1 > r.tmin);
   a = __float_as_uint(n0.w);
   ex = __float_as_uint(n1.w);
-  const bool leaf = (a & kInnerFlag) == 0u;
-  const uint32_t nxt = enter ? (a & ~kInnerFlag) : ex;
-  cur = leaf ? cur : nxt;
-  return leaf;
+  // the lane stops on a leaf, and on a pair node whose box it enters (leaf_test)
+  const bool stop = (a & kInnerFlag) == 0u || (PAIRS && (a & kPairFlag) != 0u && enter);
+  const uint32_t nxt = enter ? (a & kIndexMask) : ex;
+  cur = stop ? cur : nxt;
+  return stop;
 }
 
 // reference shader/scene.glsl:97-158.  ANYHIT: stop at the first accepted hit
@@ -168,14 +222,10 @@ HJ_DEV bool traverse(const DeviceScene& sc, Ray r, RawHit& h) {
       bool at_leaf = false;
       while (cur < nn && !at_leaf) {
         const float4 n0 = sc.nodes[2 * cur], n1 = sc.nodes[2 * cur + 1];
-        at_leaf = node_step(n0, n1, inv, off, r, cur, a, ex);
+        at_leaf = node_step<true>(n0, n1, inv, off, r, cur, a, ex);
       }
       if (!at_leaf) break;
-      if (intersect_shape(sc, r, a, h)) {   // leaf boxes are never tested (scene.glsl:105-119)
-        h.id = (int)a;
-        if (ANYHIT) return true;
-        r.tmax = h.t - kEps;
-      }
+      if (leaf_test<true>(sc, r, a, h, ANYHIT)) return true;   // leaf boxes are never tested (scene.glsl:105-119)
       cur = ex;
     }
   } else {
@@ -216,7 +266,9 @@ __device__ unsigned long long g_round_stats[24];
 #endif
 
 // MODE 0: closest-hit rays, 1: any-hit (shadow) rays, 2: both kinds in one queue (fetch says which per ray).
-template <int MODE, class Fetch, class Finish>
+// PAIRS: the scene has pair nodes (leaf_test); without them the code for them is not even compiled in (it costs 4 % on
+// a scene that has none).
+template <int MODE, bool PAIRS, class Fetch, class Finish>
 HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head, const float4* s_nodes,
                              Fetch fetch, Finish finish) {
   const uint32_t lane = __lane_id();
@@ -250,24 +302,32 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     const unsigned long long idle = __ballot(!active);
     const uint32_t nidle = (uint32_t)__popcll(idle);
     if (nidle >= sc.refill_min || nidle == 64u) {
-      if (__ballot(pending) != 0) finish(pending, slot, h, any);
-      pending = false;
+      // The loads of the NEW rays are issued first, the results of the finished ones are written (and, for an unoccluded
+      // shadow ray, its sample read, added to and written) after them: both memory round trips are then in flight
+      // together, and the wait for the new rays does not include the stores (vmcnt retires in order: only what was
+      // issued BEFORE a load has to complete with it).
+      bool got = false, any2 = any;
+      uint32_t slot2 = 0;
+      Ray r2; r2.o = V(0, 0, 0); r2.d = V(0, 0, 0); r2.tmin = 0.f; r2.tmax = 0.f;
       if (!exhausted) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(s_head, nidle);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (!active) {
           const uint32_t my = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-          if (my < n) {
-            fetch(my, slot, r, any);
-            inv = V(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-            off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
-            cur = sc.root; h.id = -1; active = true;
-          }
+          if (my < n) { fetch(my, slot2, r2, any2); got = true; }
         }
         exhausted = base + nidle >= n;
-        HJ_STAT(5, 1); HJ_STAT(6, __popcll(__ballot(active)) - (64 - (int)nidle));
       }
+      if (__ballot(pending) != 0) finish(pending, slot, h, any);
+      pending = false;
+      if (got) {
+        slot = slot2; any = any2; r = r2;
+        inv = V(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+        off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
+        cur = sc.root; h.id = -1; active = true;
+      }
+      HJ_STAT(5, 1); HJ_STAT(6, __popcll(__ballot(got)));
     }
     if (__ballot(active) == 0) break;
     HJ_STAT(0, 1); HJ_STAT(7, __popcll(__ballot(active)));
@@ -293,22 +353,18 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
       const uint32_t a_lo = (hot ? nb_llo : nb_glo) + (cur << 5), a_hi = hot ? nb_lhi : nb_ghi;
       const float4* __restrict__ nd = reinterpret_cast<const float4*>(((uint64_t)a_hi << 32) | (uint64_t)a_lo);
       const float4 n0 = nd[0], n1 = nd[1];
-      at_leaf = node_step(n0, n1, inv, off, r, cur, shape, ex);
+      at_leaf = node_step<PAIRS>(n0, n1, inv, off, r, cur, shape, ex);
       burst--;
     }
     if (active && !at_leaf && cur >= nn) { active = false; pending = true; }   // walked off the end of the tree
 #ifdef HJ_WALK_STATS
     const unsigned long long t_c = clock64();
     HJ_STAT(11, t_c - t_b);
-    { const unsigned long long m = __ballot(at_leaf); if (m && lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[3] += 1; ws[4] += __popcll(m); } }
+    { const unsigned long long m = __ballot(at_leaf), mp = __ballot(at_leaf && (shape & kInnerFlag) != 0u);   // [15] shape records fetched (a pair: two)
+      if (m && lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[3] += 1; ws[4] += __popcll(m); ws[15] += __popcll(m) + __popcll(mp); } }
 #endif
     if (at_leaf) {
-      const bool found = intersect_shape(sc, r, shape, h);
-      if (found) {
-        h.id = (int)shape;
-        if (MODE == 1 || (MODE == 2 && any)) { active = false; pending = true; }   // occluded shadow ray (h.id >= 0 tells finish)
-        else r.tmax = h.t - kEps;
-      }
+      if (leaf_test<PAIRS>(sc, r, shape, h, MODE == 1 || (MODE == 2 && any))) { active = false; pending = true; }   // occluded shadow ray (h.id >= 0 tells finish)
       cur = ex;
     }
     HJ_STAT(12, clock64() - t_c);
@@ -554,7 +610,7 @@ HJ_DEV void linear_scan(const DeviceScene& sc, Ray r, RawHit& h, bool any) {
 // bounce k-1 is added during this phase, emission of bounce k in the shade that follows the barrier.  A closest-hit
 // ray only records its hit (objectID -1 = miss); an unoccluded shadow ray adds its NEE radiance (render.glsl:122-124).
 // Needs sh.head == 0 and the hot nodes loaded (synced).
-template <bool USE_BVH>
+template <bool USE_BVH, bool PAIRS>
 HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t n,
                                uint32_t ns, WgShared& sh) {
   const uint32_t seg = g * st.pool;
@@ -584,7 +640,7 @@ HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint
     unocc += (uint32_t)__popcll(__ballot(add));
   };
   if (USE_BVH) {
-    trace_persistent<2>(sc, n + ns, &sh.head, sh.nodes, fetch, finish);
+    trace_persistent<2, PAIRS>(sc, n + ns, &sh.head, sh.nodes, fetch, finish);
   } else {
     const uint32_t lane = threadIdx.x & 63u;
     for (;;) {
@@ -820,7 +876,7 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
 #ifndef HJ_PATH_WAVES
 #define HJ_PATH_WAVES 7   // 72 VGPRs; measured on the compacted-record kernel: 6 waves (80 VGPRs) -6 %, 8 waves (64 VGPRs) -2 %, 5 waves -5 %
 #endif
-template <bool USE_BVH>
+template <bool USE_BVH, bool PAIRS>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(HJ_PATH_WAVES, 8))) void k_path_wavefront(BatchState st, DeviceScene sc, uint32_t max_bounces,
                                                                   uint32_t rr_start) {
   __shared__ WgShared sh;
@@ -862,7 +918,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
       if (threadIdx.x == 0) { sh.head = 0; sh.n_ray[parity ^ 1u] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; }
       if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
       wg_sync(waves);
-      stage_trace_merged<USE_BVH>(st, sc, g, parity, n, ns, sh);
+      stage_trace_merged<USE_BVH, PAIRS>(st, sc, g, parity, n, ns, sh);
       compact_hits_by_tag(st, sc, g, n, sh, waves);
       wg_sync(waves);
       if (n != 0) stage_shade(st, sc, g, parity, max_bounces, rr_start, sh, waves);
@@ -920,7 +976,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_trace_closest(BatchState st, 
   if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
   if (USE_BVH && n != 0) load_hot_nodes(sc, sh);
   __syncthreads();
-  stage_trace_merged<USE_BVH>(st, sc, g, parity, n, 0, sh);
+  stage_trace_merged<USE_BVH, true>(st, sc, g, parity, n, 0, sh);
   compact_hits_by_tag(st, sc, g, n, sh, blockDim.x >> 6);
   __syncthreads();
   if (threadIdx.x < kNumTags) st.cnt_hit[g * kNumTags + threadIdx.x] = sh.cnt_hit[threadIdx.x];
@@ -940,7 +996,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_trace_shadow(BatchState st, D
   if (threadIdx.x == 0) { sh.head = 0; sh.n_unocc = 0; }
   if (USE_BVH && ns != 0) load_hot_nodes(sc, sh);
   __syncthreads();
-  stage_trace_merged<USE_BVH>(st, sc, g, 0, 0, ns, sh);
+  stage_trace_merged<USE_BVH, true>(st, sc, g, 0, 0, ns, sh);
   __syncthreads();
   if (threadIdx.x == 0) st.acc_unoccluded[g] += sh.n_unocc;
 }

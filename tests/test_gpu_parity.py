@@ -726,3 +726,36 @@ def test_in_process_multi_gpu_frame(cbox):
     finally:
         for r in rs:
             r.close()
+
+
+def test_pair_nodes_forced_on_small_scenes(gpu_renderer, oracle, cbox, cbox_spheres):
+    """Pair nodes (an inner node over two triangle leaves tested in one stop of the walk) are switched on by tree size;
+    forced on here for the small scenes: frames, raw hits and any-hit results stay bit-identical to the oracle's."""
+    old = os.environ.get("HJ_PAIR_LEAVES")
+    os.environ["HJ_PAIR_LEAVES"] = "1"
+    try:
+        for cs, name in ((cbox, "cbox"), (cbox_spheres, "spheres")):
+            W, H = 192, 128
+            blocks = host.make_blocks(W, H, 3, 23)
+            want, ctr, _ = oracle.render_blocks(cs, blocks, W, H)
+            got, st = render(gpu_renderer, cs, W, H, blocks)
+            assert_same(got, want, f"pair nodes, {name}")
+            assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"]
+        rs = np.random.RandomState(5)
+        n = 20000
+        o = np.stack([rs.uniform(-0.9, 0.9, n), rs.uniform(0.1, 1.5, n), rs.uniform(-0.9, 0.9, n)], 1)
+        d = rs.normal(size=(n, 3))
+        d /= np.linalg.norm(d, axis=1)[:, None]
+        rays = np.concatenate([o, d, np.full((n, 1), 1e-4), np.full((n, 1), np.inf)], 1).astype(np.float32)
+        gpu_renderer.upload_scene(cbox)
+        ids, t, u, v = gpu_renderer.trace(rays)
+        wi, wt, wu, wv = oracle.intersect(cbox, rays)
+        assert (ids == wi).all() and (bits(t) == bits(wt)).all() and (bits(u) == bits(wu)).all() and (bits(v) == bits(wv)).all()
+        occluded = gpu_renderer.trace(rays, any_hit=True)[0] >= 0
+        assert (occluded == (wi >= 0)).all()
+    finally:
+        if old is None:
+            del os.environ["HJ_PAIR_LEAVES"]
+        else:
+            os.environ["HJ_PAIR_LEAVES"] = old
+        gpu_renderer.upload_scene(cbox)

@@ -6,4 +6,4 @@ name=$1; shift
   -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall -Wno-unused-function "$@" \
   hijiki_amd/csrc/hj_api.hip hijiki_amd/csrc/host/blockgen.cpp -ldl -o hijiki_amd/lib/var_$name.so \
   -Rpass-analysis=kernel-resource-usage 2> hijiki_amd/lib/var_$name.txt
-grep -A11 "k_path_wavefrontILb1" hijiki_amd/lib/var_$name.txt | grep -E "VGPRs|Scratch|Occupancy" | tr '\n' ' '; echo
+grep -A11 "k_path_wavefrontILb1ELb0" hijiki_amd/lib/var_$name.txt | grep -E "VGPRs|Scratch|Occupancy" | tr '\n' ' '; echo

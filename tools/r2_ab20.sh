@@ -1,0 +1,7 @@
+#!/bin/bash
+export GPU_MAX_HW_QUEUES=8
+out=gpurun_out/r2_ab20; mkdir -p $out
+timeout 1500 python -m pytest tests -m gpu -x -q > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $out/pytest.log
+echo "== C2"; tools/ab_variants.sh cur:HJ_PAIR_LEAVES=0 cur:HJ_PAIR_LEAVES=1 2>&1 | tee $out/c2.txt
+echo "== C3"; PROBE_ARGS="--kind 1 --spp 256" tools/ab_variants.sh cur:HJ_PAIR_LEAVES=0 cur:HJ_PAIR_LEAVES=1 2>&1 | tee $out/c3.txt
+for tr in 60000 200000 1000000; do echo "== mesh $tr"; PROBE_ARGS="--kind 2 --tris $tr --size 2048 --spp 32" tools/ab_variants.sh cur:HJ_PAIR_LEAVES=0 cur:HJ_PAIR_LEAVES=1 2>&1 | tee $out/mesh_$tr.txt; done

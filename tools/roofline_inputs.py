@@ -57,9 +57,10 @@ def cmd_pmc(path):
             names.append(c)
         agg[k][c] += float(r["Counter_Value"])
         cnt[(k, c)] += 1
-    print("kernel,launches," + ",".join(names))
+    w = csv.writer(sys.stdout, lineterminator="\n")             # kernel names hold commas ("k<true, false>"): quoted
+    w.writerow(["kernel", "launches"] + names)
     for k in sorted(agg):
-        print(f"{k},{max(cnt[(k, c)] for c in names)}," + ",".join(f"{agg[k][c]:.0f}" for c in names))
+        w.writerow([k, max(cnt[(k, c)] for c in names)] + [f"{agg[k][c]:.0f}" for c in names])
 
 
 def read_passes(files):
@@ -73,7 +74,11 @@ def read_passes(files):
                 continue
             if row[0] == "kernel":
                 header = row
-            elif header and "k_path_wavefront" in row[0] and len(row) == len(header):
+            elif header and "k_path_wavefront" in row[0]:
+                extra = len(row) - len(header)                     # an unquoted template-argument comma in the name
+                if extra < 0:
+                    continue
+                row = [",".join(row[:extra + 1])] + row[extra + 1:]
                 launches = max(launches, int(row[1]))
                 for k, v in zip(header[2:], row[2:]):
                     c[k] = float(v)
@@ -111,7 +116,7 @@ def cmd_build(d, cfg, prefix=""):
         lim["walk_lanes_per_leaf_phase"] = round(w["lanes_per_leaf_phase"], 1)
         out["walk"] = w
         if cfg == "c4":   # scene data of the 1 M-triangle mesh (96 MB) is not cache-resident: nodes outside the LDS copy + triangle records
-            out["scene_bytes_per_ray"] = 32.0 * w["cold_node_steps_per_ray"] + 48.0 * w["leaf_tests_per_ray"]
+            out["scene_bytes_per_ray"] = 32.0 * w["cold_node_steps_per_ray"] + 48.0 * w.get("triangle_records_per_ray", w["leaf_tests_per_ray"])
     lim["name"] = ("dependent fetch latency of the BVH walk at partially filled waves (VALU instructions execute with "
                    f"{lim.get('valu_lanes_per_instruction', '?')} of 64 lanes; waves wait {100 * lim.get('waiting_share_of_wave_cycles', 0):.0f} % of their cycles)")
     out["limiter"] = lim

@@ -31,7 +31,7 @@ rays = st["closest_rays"] + st["shadow_rays"]
 steps = o[1] + o[8]
 print(f"rays {rays/1e6:.1f} M; outer iterations {o[0]/1e6:.2f} M, active lanes at their start {o[7]/max(1,o[0]):.1f}")
 print(f"box wave-steps {steps/1e6:.2f} M with {(o[2]+o[9])/max(1,steps):.1f} lanes  ({(o[2]+o[9])/rays:.1f} lane-steps per ray, {o[14]/rays:.2f} of them on nodes outside the LDS copy; {steps/max(1,o[0]):.2f} wave-steps per outer iteration)")
-print(f"leaf phases {o[3]/1e6:.2f} M with {o[4]/max(1,o[3]):.1f} lanes  ({o[4]/rays:.2f} leaf tests per ray; in {100*o[3]/max(1,o[0]):.0f} % of outer iterations)")
+print(f"leaf phases {o[3]/1e6:.2f} M with {o[4]/max(1,o[3]):.1f} lanes  ({o[4]/rays:.2f} leaf stops and {o[15]/rays:.2f} shape records per ray; in {100*o[3]/max(1,o[0]):.0f} % of outer iterations)")
 tot = max(1, o[13])
 print(f"wave cycles in the walk: service {100*o[10]/tot:.1f} %, box steps {100*o[11]/tot:.1f} %, leaf tests {100*o[12]/tot:.1f} %; per outer iteration {o[13]/max(1,o[0]):.0f} cycles; per box wave-step {o[11]/max(1,steps):.0f}; per leaf phase {o[12]/max(1,o[3]):.0f}; per refill {o[10]/max(1,o[5]):.0f}")
 print(f"refills {o[5]/1e6:.2f} M with {o[6]/max(1,o[5]):.1f} rays each")
@@ -51,7 +51,7 @@ for b in range(8):
 if js:
     json.dump({"kind": kind, "size": size, "spp": spp, "rays": rays, "paths": st["paths"],
                "box_lane_steps_per_ray": (o[2] + o[9]) / rays, "cold_node_steps_per_ray": o[14] / rays,
-               "leaf_tests_per_ray": o[4] / rays, "lanes_per_box_step": (o[2] + o[9]) / max(1, steps),
+               "leaf_tests_per_ray": o[4] / rays, "triangle_records_per_ray": o[15] / rays, "lanes_per_box_step": (o[2] + o[9]) / max(1, steps),
                "lanes_per_leaf_phase": o[4] / max(1, o[3]), "active_lanes": o[7] / max(1, o[0]),
                "cycle_share": {"service": o[10] / tot, "box": o[11] / tot, "leaf": o[12] / tot},
                "rounds": hist}, open(js, "w"), indent=1)
