@@ -715,13 +715,13 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     // node's first child, the right one the left one's exit) and their triangles go side by side into `pairs`.
     std::vector<uint32_t> pair_of(N, 0xFFFFFFFFu);
     std::vector<float4> pairs;
-    // Worth it on large scenes (1 M triangles: +7 %: a fifth fewer dependent fetch rounds per ray, most of them trips
-    // beyond the L2).  On cache-resident scenes the longer leaf phase (two tests while the rest of the wave waits) costs
-    // more than the rounds save: -7 % on the 6 k-triangle box, -5 % at 60 k triangles, -2 % at 200 k.  So small trees keep
-    // plain leaves and run the kernel instantiation without the pair code.  HJ_PAIR_LEAVES = 0 / 1 forces; default:
-    // trees of >= HJ_PAIR_MIN_NODES records.
+    // Worth it on large scenes (with 8 box steps per round: 1 M triangles +12 %, 200 k +3 %: a fifth fewer dependent
+    // fetch rounds per ray, most of them trips beyond the L2).  On cache-resident scenes the longer leaf phase (two tests
+    // while the rest of the wave waits) costs more than the rounds save: -3 % on the 6 k-triangle box at the best burst.
+    // So small trees keep plain leaves and run the kernel instantiation without the pair code.  HJ_PAIR_LEAVES = 0 / 1
+    // forces; default: trees of >= HJ_PAIR_MIN_NODES records.
     const int pair_env = env_int("HJ_PAIR_LEAVES", -1, -1, 1);
-    if (pair_env == 1 || (pair_env < 0 && N >= (size_t)env_int("HJ_PAIR_MIN_NODES", 1000000, 0, 1 << 30))) {
+    if (pair_env == 1 || (pair_env < 0 && N >= (size_t)env_int("HJ_PAIR_MIN_NODES", 300000, 0, 1 << 30))) {
       const size_t first_tri = s->num_spheres + s->num_quads;
       for (size_t i = 0; i + 2 < N; i++) {
         if (s->bvh[i].shape_index != HJ_BVH_INNER) continue;
