@@ -197,7 +197,9 @@ void hj_default_render_opts(hj_render_opts* opts);
 /* Replaces the staging copy of the packed scene buffer (src/main.rs:1186-1244)
  * and the bind-group plumbing (src/main.rs:808-855).  Validates the same
  * invariants the reference asserts (src/main.rs:562-565) plus index ranges,
- * copies, and re-lays the data out for the kernels. */
+ * copies, and re-lays the data out for the kernels (same boxes, same leaves, same visiting order per ray: DESIGN.md 4).
+ * Limit: the device node array is 32 bytes per record and must fit in 4 GiB (about 134 M records = 67 M shapes);
+ * larger trees return HJ_ERR_UNSUPPORTED. */
 int hj_scene_upload(hj_context* ctx, const hj_scene_desc* scene);
 
 /* -------------------------------------------------------------- framebuffer */

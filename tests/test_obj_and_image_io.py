@@ -259,3 +259,19 @@ def test_cli_renders_like_the_library(tmp_path, obj_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "Built BVH with" in r.stdout and open(out3, "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+
+
+@pytest.mark.gpu
+def test_cli_progress_percentage(tmp_path):
+    """The percentage the reference shows in the window title every --present-interval blocks (src/main.rs:1335-1340) goes
+    to stderr, in the title's format, and ends at 100 %."""
+    exe = os.path.join(ROOT, "hijiki_amd", "bin", "hijiki-hip")
+    out = str(tmp_path / "p.pfm")
+    r = subprocess.run([exe, "--use-bvh", "-w", "512", "-h", "512", "-s", "48", "--present-interval", "64", "-o", out,
+                        "synthetic:cbox"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    marks = [m for m in r.stderr.replace("\r", "\n").split("\n") if "%" in m]
+    total = 16 * 48                                                   # 4 x 4 blocks per pass
+    assert len(marks) >= 2 and marks[-1].strip() == f"100.000% {total}/{total}"
+    done = [int(m.split()[1].split("/")[0]) for m in marks]
+    assert done == sorted(done) and all(m.split()[1].endswith(f"/{total}") for m in marks)
