@@ -71,3 +71,42 @@ def furnace_masks(W, H):
     r = np.sqrt(x * x + y * y)
     r_disc = 0.6 / np.sqrt(2.5 ** 2 - 0.6 ** 2)             # tan of the sphere's angular radius
     return r < 0.8 * r_disc, r > 1.25 * r_disc
+
+
+def random_scene(seed):
+    """Randomised scene through the whole Scene API: random mixes of triangles (a small random soup with random shading
+    normals), spheres and quads, all five material kinds (dielectrics with and without extinction, several lights of
+    different shape kinds), random camera."""
+    rng = np.random.default_rng(1000 + seed)
+    s = host.Scene()
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    q = q * 0.15 + np.array([0, 0, 0, 1.0])          # a mild random rotation around the cbox view
+    q /= np.linalg.norm(q)
+    s.set_camera((float(rng.uniform(-0.2, 0.2)), float(rng.uniform(0.7, 1.0)), float(rng.uniform(3.0, 3.6))),
+                 tuple(float(x) for x in q), float(rng.uniform(25, 45)))
+    mats = [s.add_diffuse(tuple(rng.uniform(0.1, 0.9, 3))) for _ in range(3)]
+    mats.append(s.add_diffuse_cboard(tuple(rng.uniform(0.2, 0.9, 3)), float(rng.uniform(0.05, 0.3)),
+                                     tuple(rng.uniform(0.1, 0.8, 3)), float(rng.uniform(0.05, 0.3))))
+    mats.append(s.add_mirror())
+    mats.append(s.add_dielectric(float(rng.uniform(1.2, 1.8))))
+    mats.append(s.add_dielectric(1.5, extinction=tuple(rng.uniform(0.0, 2.0, 3))))
+    lights = [s.add_emissive(tuple(rng.uniform(5, 25, 3))) for _ in range(2)]
+    # an enclosure of quads so that paths bounce, one of them a light
+    s.add_quad((-1.2, 0, 1.2), (2.4, 0, 0), (0, 0, -2.4), mats[0])
+    s.add_quad((-1.2, 0, -1.2), (2.4, 0, 0), (0, 2.0, 0), mats[1])
+    s.add_quad((-1.2, 0, 1.2), (0, 0, -2.4), (0, 2.0, 0), mats[3])
+    s.add_quad((1.2, 0, -1.2), (0, 0, 2.4), (0, 2.0, 0), mats[2])
+    s.add_quad((-0.4, 1.99, -0.4), (0.8, 0, 0), (0, 0, 0.8), lights[0])
+    for _ in range(int(rng.integers(2, 6))):
+        s.add_sphere(tuple(rng.uniform([-0.8, 0.2, -0.8], [0.8, 1.2, 0.8])), float(rng.uniform(0.1, 0.35)),
+                     int(rng.choice(mats + lights[1:])))
+    nv = int(rng.integers(12, 40))
+    pos = rng.uniform([-0.9, 0.05, -0.9], [0.9, 1.5, 0.9], (nv, 3)).astype(np.float32)
+    nrm = rng.normal(size=(nv, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    base = s.add_vertices(pos, nrm, rng.uniform(0, 1, (nv, 2)).astype(np.float32))
+    for _ in range(int(rng.integers(8, 30))):
+        a, b, c = (int(x) for x in rng.choice(nv, 3, replace=False))
+        s.add_triangle(base + a, base + b, base + c, int(rng.choice(mats + lights[1:])))
+    return s.compile()

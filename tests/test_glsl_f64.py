@@ -159,3 +159,20 @@ def test_white_furnace_cpu(oracle):
     i64 = a64[..., :3] / a64[..., 3:4]
     assert np.abs(i64[wall] - scenes.FURNACE_L).max() < 1e-9
     assert abs(i64[disc].mean() - scenes.FURNACE_RHO * scenes.FURNACE_L) < 0.01 * scenes.FURNACE_L
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_scenes_oracle_vs_float64(oracle, seed):
+    """The six randomised scenes of the GPU suite (tests/scenes.py random_scene: every shape and material kind, random
+    camera), whole frames: the binary32 oracle and the float64 restatement agree pixel for pixel except where a rounding
+    sent a path another way, and agree in the mean."""
+    cs = scenes.random_scene(seed)
+    W, H = 80, 48
+    blocks = host.make_blocks(W, H, 2, seed)
+    a32, _, _ = oracle.render_blocks(cs, blocks, W, H)
+    a64 = G.render_blocks(G.Scene(cs), blocks, W, H)
+    close = (np.abs(a64 - a32) <= 1e-4 * np.maximum(1.0, np.abs(a32))).all(-1)
+    assert close.mean() > 0.95, close.mean()
+    np.testing.assert_allclose(a64[..., 3], a32[..., 3], rtol=3e-4)              # filter weights: first-hit normals only, no random walk
+    s32, s64 = a32[..., :3].sum(), a64[..., :3].sum()
+    assert abs(s64 - s32) < 0.03 * s32
