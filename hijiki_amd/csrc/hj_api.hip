@@ -1176,11 +1176,24 @@ constexpr int kNcclFloat32 = 7, kNcclSum = 0;   // ncclFloat / ncclSum of rccl.h
 // of milliseconds) and reused by every frame's reduce.
 struct hj_comm {
   std::vector<hj_context*> ctxs;
-  std::vector<void*> comms;                  // empty for n == 1
+  std::vector<void*> comms;                  // empty for n == 1 and for a shared-GPU test rig
+  bool shared_gpu = false;                   // HJ_COMM_SHARED_GPU=1: contexts on ONE GPU, summed by a kernel instead of RCCL
 };
+
+namespace hj {
+__global__ void k_add_framebuffer(float4* __restrict__ dst, const float4* __restrict__ src, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float4 a = dst[i], b = src[i]; dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+}
+}  // namespace hj
 
 namespace {
 std::vector<hj_comm*> g_cached_comms;        // communicators made on behalf of hj_reduce_framebuffers
+
+// Test rigs without several GPUs (HJ_COMM_SHARED_GPU=1): the contexts of a communicator may live on one GPU; their
+// framebuffers are then summed by a kernel, in context order, instead of by RCCL.  Everything else of the multi-context
+// path (worker threads, frames in flight on all contexts, the joins inside the reduce) is the real thing.
+bool shared_gpu_allowed() { return env_int("HJ_COMM_SHARED_GPU", 0, 0, 1) != 0; }
 
 int check_reduce_args(hj_context* const* ctxs, int n, int root) {
   if (!ctxs || n < 1 || root < 0 || root >= n || !ctxs[root]) return HJ_ERR_INVALID;
@@ -1188,8 +1201,11 @@ int check_reduce_args(hj_context* const* ctxs, int n, int root) {
   for (int i = 0; i < n; i++) {
     if (!ctxs[i] || !ctxs[i]->accum) return set_error(r, HJ_ERR_STATE, "context %d has no framebuffer", i);
     if (ctxs[i]->width != r->width || ctxs[i]->height != r->height) return set_error(r, HJ_ERR_INVALID, "framebuffer sizes differ");
-    for (int j = 0; j < i; j++)
-      if (ctxs[j]->device == ctxs[i]->device) return set_error(r, HJ_ERR_INVALID, "contexts %d and %d share GPU %d", j, i, ctxs[i]->device);
+    for (int j = 0; j < i; j++) {
+      if (ctxs[j] == ctxs[i]) return set_error(r, HJ_ERR_INVALID, "context %d appears twice", i);
+      if (ctxs[j]->device == ctxs[i]->device && !shared_gpu_allowed())
+        return set_error(r, HJ_ERR_INVALID, "contexts %d and %d share GPU %d", j, i, ctxs[i]->device);
+    }
   }
   return HJ_OK;
 }
@@ -1206,15 +1222,22 @@ int hj_comm_create(hj_context* const* ctxs, int n, hj_comm** out) {
   *out = nullptr;
   if (!ctxs || n < 1 || !ctxs[0]) return HJ_ERR_INVALID;
   hj_context* r = ctxs[0];
+  bool shared = false;
   for (int i = 0; i < n; i++) {
     if (!ctxs[i]) return set_error(r, HJ_ERR_INVALID, "null context %d", i);
-    for (int j = 0; j < i; j++)
-      if (ctxs[j]->device == ctxs[i]->device) return set_error(r, HJ_ERR_INVALID, "contexts %d and %d share GPU %d", j, i, ctxs[i]->device);
+    for (int j = 0; j < i; j++) {
+      if (ctxs[j] == ctxs[i]) return set_error(r, HJ_ERR_INVALID, "context %d appears twice", i);
+      if (ctxs[j]->device == ctxs[i]->device) {
+        if (!shared_gpu_allowed()) return set_error(r, HJ_ERR_INVALID, "contexts %d and %d share GPU %d", j, i, ctxs[i]->device);
+        shared = true;
+      }
+    }
   }
   hj_comm* c = new (std::nothrow) hj_comm();
   if (!c) return set_error(r, HJ_ERR_NOMEM, "out of host memory");
   c->ctxs.assign(ctxs, ctxs + n);
-  if (n > 1) {
+  c->shared_gpu = shared;
+  if (n > 1 && !shared) {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (!g_rccl.load()) {
       delete c;
@@ -1254,6 +1277,17 @@ int hj_comm_reduce_framebuffers(hj_comm* c, int root) {
       return set_error(r, HJ_ERR_DEVICE, "context %d: stream synchronisation failed: %s", i, x->error.c_str());
   }
   if (n == 1) return HJ_OK;
+  if (c->shared_gpu) {
+    const size_t px = (size_t)r->width * r->height;
+    HJ_HIP(r, hipSetDevice(r->device));
+    for (int i = 0; i < n; i++)
+      if (i != root)
+        hipLaunchKernelGGL(hj::k_add_framebuffer, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, r->stream, r->accum,
+                           c->ctxs[(size_t)i]->accum, px);
+    HJ_HIP(r, hipStreamSynchronize(r->stream));
+    HJ_HIP(r, hipGetLastError());
+    return HJ_OK;
+  }
   const size_t count = (size_t)r->width * r->height * 4;
   int nrc = g_rccl.GroupStart();
   for (int i = 0; i < n && nrc == 0; i++) {

@@ -91,3 +91,21 @@ def test_headers_are_plain_c99_and_layouts_hold(tmp_path):
            "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_argument_checks_need_no_gpu():
+    """Entry points added in round 2 reject bad arguments before they touch a device (status codes, no crash)."""
+    import ctypes as C
+    L = device.lib()
+    assert L.hj_device_count() >= 0
+    assert L.hj_sync(None, None) == abi.HJ_ERR_INVALID
+    assert L.hj_render_frame_async(None, 1, 1, 0, 1, 0, 1, None) == abi.HJ_ERR_INVALID
+    out = C.c_void_p()
+    assert L.hj_comm_create(None, 1, C.byref(out)) == abi.HJ_ERR_INVALID and not out.value
+    arr = (C.c_void_p * 1)(None)
+    assert L.hj_comm_create(arr, 1, C.byref(out)) == abi.HJ_ERR_INVALID
+    assert L.hj_comm_create(arr, 0, C.byref(out)) == abi.HJ_ERR_INVALID
+    assert L.hj_comm_reduce_framebuffers(None, 0) == abi.HJ_ERR_INVALID
+    L.hj_comm_destroy(None)                                   # no-ops on NULL
+    L.hj_set_progress_callback(None, device.PROGRESS_FN(), None, 1)
+    assert (L.hj_version() >> 8) & 0xFF >= 2                  # ABI 0.2: statistics grew, async / comm / progress entry points

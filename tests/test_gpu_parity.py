@@ -728,3 +728,41 @@ def test_pair_nodes_forced_on_small_scenes(gpu_renderer, oracle, cbox, cbox_sphe
         else:
             os.environ["HJ_PAIR_LEAVES"] = old
         gpu_renderer.upload_scene(cbox)
+
+
+def test_four_contexts_in_flight_on_one_gpu(cbox, monkeypatch):
+    """The in-process multi-context path on a one-GPU box: four contexts (HJ_COMM_SHARED_GPU test rig: same GPU, the sum by
+    a kernel instead of RCCL) render their shares of the frame AT THE SAME TIME - four worker threads, twelve batch
+    streams - and the communicator's reduce joins them.  With the static deal the block interiors equal the 1-context
+    frame bit for bit; the rotating deal agrees to the usual tolerance."""
+    monkeypatch.setenv("HJ_COMM_SHARED_GPU", "1")
+    n, W, H, spp = 4, 512, 384, 24
+    rs = [device.Renderer(0) for _ in range(n)]
+    try:
+        for r in rs:
+            r.upload_scene(cbox)
+            r.create_framebuffer(W, H)
+        rs[0].render_frame(spp, 7)
+        full = rs[0].read()
+        comm = device.Comm(rs)
+        static = device.default_opts()
+        static.flags = abi.RENDER_STATIC_DEAL
+        for opts in (None, static):
+            for r in rs:
+                r.clear()
+            for i, r in enumerate(rs):
+                r.render_frame_async(spp, 7, rank=i, world=n, opts=opts)
+            comm.reduce(0)
+            stats = [r.sync() for r in rs]
+            got = rs[0].read()
+            np.testing.assert_allclose(got, full, rtol=5e-5, atol=1e-5)
+            if opts is static:
+                interior = np.ones((H, W), bool)
+                for e in range(128, max(W, H), 128):
+                    interior[max(0, e - 2):e + 2, :] = False
+                    interior[:, max(0, e - 2):e + 2] = False
+                assert (bits(got)[interior] == bits(full)[interior]).all()
+        comm.close()
+    finally:
+        for r in rs:
+            r.close()
