@@ -1587,7 +1587,13 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
   }
   HJ_HIP(ctx, hipMemcpyAsync(const_cast<uint32_t*>(cl.base), cbase.data(), sizeof(uint32_t) * K, hipMemcpyHostToDevice, st));
   HJ_HIP(ctx, hipMemcpyAsync(const_cast<uint32_t*>(cl.exit), cexit.data(), sizeof(uint32_t) * K, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(hj::lbvh::k_emit_clusters, grid_sub, blk, 0, st, t, m, cl, idx_mask, d_out);
+  // inside the clusters: SAH re-split (one thread per cluster) or the Morton topology as it is (HJ_LBVH_SAH=0, or clusters
+  // larger than the kernel's arrays)
+  if (cmax <= hj::lbvh::kClusterMax && env_int("HJ_LBVH_SAH", 1, 0, 1))
+    hipLaunchKernelGGL(hj::lbvh::k_emit_clusters_sah, dim3((K + hj::lbvh::kSahThreads - 1) / hj::lbvh::kSahThreads),
+                       dim3(hj::lbvh::kSahThreads), 0, st, t, K, cl, idx_mask, d_out);
+  else
+    hipLaunchKernelGGL(hj::lbvh::k_emit_clusters, grid_sub, blk, 0, st, t, m, cl, idx_mask, d_out);
   HJ_HIP(ctx, hipGetLastError());
   HJ_HIP(ctx, hipMemcpyAsync(out_nodes, d_out, sizeof(hj_bvh_node) * total, hipMemcpyDeviceToHost, st));
   HJ_HIP(ctx, hipStreamSynchronize(st));

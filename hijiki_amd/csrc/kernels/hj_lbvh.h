@@ -294,6 +294,118 @@ __global__ __launch_bounds__(256) void k_emit_clusters(Tree t, uint32_t n, Clust
   out[pos] = nd;
 }
 
+// The records of ONE cluster per thread, with the cluster's leaves re-split top-down by binned SAH (8 bins x 3 axes; the
+// Morton splits inside a cluster are what is left of the LBVH's quality gap once the host has built the top by SAH).  The
+// subtree is emitted directly in pre-order: a range of m leaves at position p takes records [p, p + 2m - 1), its left part
+// starts at p + 1, its right part where the left one ends, exits as in src/main.rs:214-231.  Clusters hold at most
+// kClusterMax leaves, so everything fits in per-thread arrays.
+constexpr uint32_t kClusterMax = 64;
+constexpr uint32_t kSahThreads = 16;                               // clusters per workgroup: 25 KB of LDS, many small groups
+__global__ __launch_bounds__(kSahThreads) void k_emit_clusters_sah(Tree t, uint32_t K, Clusters c, unsigned long long idx_mask,
+                                                                   hj_bvh_node* out) {
+  // the cluster's leaf boxes, staged once ([.][leaf][thread]: a thread's walk over its leaves stays in its own banks), and
+  // the order of the leaves, permuted in place by the splits
+  __shared__ float s_box[6][kClusterMax][kSahThreads];
+  __shared__ uint8_t s_ids[kClusterMax][kSahThreads];
+  __shared__ float s_bin[8][7][kSahThreads];                       // per bin: box and count (dynamically indexed: not registers)
+  const uint32_t k = blockIdx.x * kSahThreads + threadIdx.x, tid = threadIdx.x;
+  if (k >= K) return;
+  const uint32_t first = __float_as_uint(c.lo[k].w), cnt = __float_as_uint(c.hi[k].w);
+  for (uint32_t i = 0; i < cnt; i++) {
+    const uint32_t id = (uint32_t)(t.keys[first + i] & idx_mask);
+    const float4 a = t.leaf_lo[id], b = t.leaf_hi[id];
+    s_box[0][i][tid] = a.x; s_box[1][i][tid] = a.y; s_box[2][i][tid] = a.z;
+    s_box[3][i][tid] = b.x; s_box[4][i][tid] = b.y; s_box[5][i][tid] = b.z;
+    s_ids[i][tid] = (uint8_t)i;
+  }
+  struct Range { uint32_t lo, hi, pos, exit; };
+  Range stack[kClusterMax];
+  uint32_t sp = 0;
+  stack[sp++] = Range{0u, cnt, c.base[k], c.exit[k]};
+  while (sp != 0) {
+    const Range r = stack[--sp];
+    const uint32_t m = r.hi - r.lo;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = r.lo; i < r.hi; i++) {
+      const uint32_t li = s_ids[i][tid];
+      for (int ax = 0; ax < 3; ax++) {
+        const float al = s_box[ax][li][tid], bh = s_box[3 + ax][li][tid], cc = al + bh;
+        lo[ax] = f_min(lo[ax], al); hi[ax] = f_max(hi[ax], bh);
+        clo[ax] = f_min(clo[ax], cc); chi[ax] = f_max(chi[ax], cc);
+      }
+    }
+    hj_bvh_node nd;
+    nd.aabb_min[0] = lo[0]; nd.aabb_min[1] = lo[1]; nd.aabb_min[2] = lo[2];
+    nd.aabb_max[0] = hi[0]; nd.aabb_max[1] = hi[1]; nd.aabb_max[2] = hi[2];
+    nd.exit_index = r.exit;
+    if (m == 1) {
+      nd.shape_index = (uint32_t)(t.keys[first + s_ids[r.lo][tid]] & idx_mask);
+      out[r.pos] = nd;
+      continue;
+    }
+    nd.shape_index = HJ_BVH_INNER;
+    out[r.pos] = nd;
+    // binned SAH: cost = area(L) * |L| + area(R) * |R|
+    constexpr int B = 8;
+    float best = INFINITY;
+    int best_axis = -1, best_bin = 0;
+    for (int ax = 0; ax < 3; ax++) {
+      const float ext = chi[ax] - clo[ax];
+      if (!(ext > 0.f)) continue;
+      for (int q = 0; q < B; q++) { s_bin[q][6][tid] = 0.f; for (int d = 0; d < 3; d++) { s_bin[q][d][tid] = INFINITY; s_bin[q][3 + d][tid] = -INFINITY; } }
+      for (uint32_t i = r.lo; i < r.hi; i++) {
+        const uint32_t li = s_ids[i][tid];
+        int q = (int)(((s_box[ax][li][tid] + s_box[3 + ax][li][tid]) - clo[ax]) / ext * (float)B);
+        q = q < 0 ? 0 : q >= B ? B - 1 : q;
+        s_bin[q][6][tid] += 1.f;
+        for (int d = 0; d < 3; d++) {
+          s_bin[q][d][tid] = f_min(s_bin[q][d][tid], s_box[d][li][tid]);
+          s_bin[q][3 + d][tid] = f_max(s_bin[q][3 + d][tid], s_box[3 + d][li][tid]);
+        }
+      }
+      float rarea[B];
+      uint32_t rn[B];
+      {
+        float alo[3] = {INFINITY, INFINITY, INFINITY}, ahi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t an = 0;
+        for (int q = B - 1; q >= 1; q--) {
+          for (int d = 0; d < 3; d++) { alo[d] = f_min(alo[d], s_bin[q][d][tid]); ahi[d] = f_max(ahi[d], s_bin[q][3 + d][tid]); }
+          an += (uint32_t)s_bin[q][6][tid];
+          const float dx = ahi[0] - alo[0], dy = ahi[1] - alo[1], dz = ahi[2] - alo[2];
+          rarea[q] = an ? dx * dy + dy * dz + dz * dx : 0.f;
+          rn[q] = an;
+        }
+      }
+      float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      uint32_t ln = 0;
+      for (int q = 0; q < B - 1; q++) {
+        for (int d = 0; d < 3; d++) { llo[d] = f_min(llo[d], s_bin[q][d][tid]); lhi[d] = f_max(lhi[d], s_bin[q][3 + d][tid]); }
+        ln += (uint32_t)s_bin[q][6][tid];
+        if (ln == 0 || rn[q + 1] == 0) continue;
+        const float dx = lhi[0] - llo[0], dy = lhi[1] - llo[1], dz = lhi[2] - llo[2];
+        const float cost = (dx * dy + dy * dz + dz * dx) * (float)ln + rarea[q + 1] * (float)rn[q + 1];
+        if (cost < best) { best = cost; best_axis = ax; best_bin = q; }
+      }
+    }
+    uint32_t mid = r.lo + m / 2;                                   // all centroids equal: halves in order
+    if (best_axis >= 0) {
+      const float ext = chi[best_axis] - clo[best_axis];
+      uint32_t w = r.lo;                                           // the order inside a side is free
+      for (uint32_t i = r.lo; i < r.hi; i++) {
+        const uint32_t li = s_ids[i][tid];
+        int q = (int)(((s_box[best_axis][li][tid] + s_box[3 + best_axis][li][tid]) - clo[best_axis]) / ext * (float)B);
+        q = q < 0 ? 0 : q >= B ? B - 1 : q;
+        if (q <= best_bin) { s_ids[i][tid] = s_ids[w][tid]; s_ids[w][tid] = (uint8_t)li; w++; }
+      }
+      if (w > r.lo && w < r.hi) mid = w;
+    }
+    const uint32_t left_pos = r.pos + 1, right_pos = left_pos + 2 * (mid - r.lo) - 1;
+    stack[sp++] = Range{mid, r.hi, right_pos, r.exit};             // a right child inherits its parent's exit
+    stack[sp++] = Range{r.lo, mid, left_pos, right_pos};           // exit of a left child = its sibling
+  }
+}
+
 // One record of the reference's flattened array per tree node (internal nodes: threads [0, n-1), leaves: the rest).
 // The tree occupies records [base, base + 2n - 1) of `out`; `end_exit` is the exit of its right spine.
 __global__ __launch_bounds__(256) void k_emit(Tree t, uint32_t n, uint32_t base, uint32_t end_exit, unsigned long long idx_mask,

@@ -288,11 +288,28 @@ def test_device_built_bvh(gpu_renderer, oracle, kind):
     cs.set_bvh(sah_nodes)
 
 
-def test_device_built_bvh_large_and_degenerate(gpu_renderer, oracle):
-    """200 k triangles (deep Morton prefixes, many equal codes) and a scene whose shapes all share one centroid."""
+def _sah_cost(nodes):
+    """Expected box tests per random ray, up to a constant: sum of the records' surface areas over the root's."""
+    n = np.asarray(nodes).view(np.float32).reshape(-1, 8)
+    d = np.maximum(n[:, 3:6].astype(np.float64) - n[:, 0:3], 0.0)
+    area = d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0]
+    return area.sum() / area[0]
+
+
+def test_device_built_bvh_large_and_degenerate(gpu_renderer, oracle, monkeypatch):
+    """200 k triangles (deep Morton prefixes, many equal codes) and a scene whose shapes all share one centroid.  The tree
+    with the clusters re-split by SAH on the device is valid, as cheap to walk as the host's SAH tree (surface-area
+    cost within 10 %) and cheaper than the plain Morton clusters, which stay available (HJ_LBVH_SAH=0)."""
     cs = host.Scene.synthetic(host.SYNTH_CBOX_MESH, mesh_triangles=200000).compile()
+    host_cost = _sah_cost(cs.bvh)
+    monkeypatch.setenv("HJ_LBVH_SAH", "0")
+    morton = gpu_renderer.build_bvh(cs)
+    _check_skip_link_tree(morton, _shape_boxes(cs))
+    monkeypatch.delenv("HJ_LBVH_SAH")
     nodes = gpu_renderer.build_bvh(cs)
     _check_skip_link_tree(nodes, _shape_boxes(cs))
+    assert _sah_cost(nodes) < 1.10 * host_cost, (_sah_cost(nodes), host_cost)
+    assert _sah_cost(nodes) < 0.95 * _sah_cost(morton), (_sah_cost(nodes), _sah_cost(morton))
     cs.set_bvh(nodes)
     W = H = 128
     blocks = host.make_blocks(W, H, 1, 3)
