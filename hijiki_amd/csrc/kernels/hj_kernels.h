@@ -56,24 +56,29 @@ HJ_DEV uint32_t lds_fetch_chunk(uint32_t* lds_head) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
 }
 
-// Path-state accessors.  HJ_NT_STATE marks them non-temporal (streaming) so that they do not displace scene data
-// (nodes, triangles) from the 32 KB vector L1.
+// Path-state accessors.  NT marks them non-temporal (streaming) so that the record and sample streams do not displace
+// scene data (nodes, triangles) from the caches: measured +4.4 % on the 1 M-triangle scene and -0.5 % / -3 % on the two
+// cbox scenes, whose trees stay cache-resident either way - so the fused kernel sets it together with PAIRS (large trees).
+#ifndef HJ_NT_LARGE
+#define HJ_NT_LARGE 1
+#endif
 typedef float f4s __attribute__((ext_vector_type(4)));
+template <bool NT>
 HJ_DEV float4 ldp(const float4* p, uint32_t i) {
-#if defined(HJ_NT_STATE) || defined(HJ_NT_LOADS)
-  const f4s v = __builtin_nontemporal_load(reinterpret_cast<const f4s*>(p + i));
-  return make_float4(v.x, v.y, v.z, v.w);
-#else
+  if (NT) {
+    const f4s v = __builtin_nontemporal_load(reinterpret_cast<const f4s*>(p + i));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
   return p[i];
-#endif
 }
+template <bool NT>
 HJ_DEV void stp(float4* p, uint32_t i, float4 v) {
-#if defined(HJ_NT_STATE) || defined(HJ_NT_STORES)
-  f4s w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
-  __builtin_nontemporal_store(w, reinterpret_cast<f4s*>(p + i));
-#else
-  p[i] = v;
-#endif
+  if (NT) {
+    f4s w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    __builtin_nontemporal_store(w, reinterpret_cast<f4s*>(p + i));
+  } else {
+    p[i] = v;
+  }
 }
 struct Ray { v3 o, d; float tmin, tmax; };
 struct RawHit { float t, u, v; int id; };
@@ -537,6 +542,7 @@ HJ_DEV uint32_t wg_group(const BatchState& st, uint32_t g, uint32_t k) {
 // reference shader/render.glsl:26-36,149-162: camera paths for groups [k0, k0 + ngen) of this workgroup's sample
 // sequence, appended to the path arrays of `parity` behind the n0 continuing paths (positions n0 + sh.n_gen...; the
 // caller guarantees n0 + 64 * ngen <= pool).
+template <bool NT>
 HJ_DEV void stage_gen_camera(const BatchState& st, const DeviceScene& sc, uint32_t g, WgShared& sh, uint32_t parity,
                              uint32_t n0, uint32_t k0, uint32_t ngen, uint32_t waves) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -578,12 +584,12 @@ HJ_DEV void stage_gen_camera(const BatchState& st, const DeviceScene& sc, uint32
       const v3 rot = V((c2.x + txyz.x * qw) + cq.x * tw, (c2.y + txyz.y * qw) + cq.y * tw, (c2.z + txyz.z * qw) + cq.z * tw);
       const v3 d = normalize3(rot);
       // the sample index rides in origin.w, the RNG state in direction.w
-      stp(st.ray_o[parity], pos, make_float4(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2], __uint_as_float(smp | kCameraFlag)));
-      stp(st.ray_d[parity], pos, make_float4(d.x, d.y, d.z, __uint_as_float(rng)));
-      stp(st.thr[parity], pos, make_float4(1.f, 1.f, 1.f, __uint_as_float(1u)));   // wasDiscrete = true, bounce 0
-      if (sc.has_extinction) stp(st.ext[parity], pos, make_float4(0.f, 0.f, 0.f, 0.f));
-      stp(st.smp_rgb, smp, make_float4(0.f, 0.f, 0.f, 1.f));
-      stp(st.smp_nd, smp, make_float4(0.f, 0.f, 0.f, 0.f));
+      stp<NT>(st.ray_o[parity], pos, make_float4(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2], __uint_as_float(smp | kCameraFlag)));
+      stp<NT>(st.ray_d[parity], pos, make_float4(d.x, d.y, d.z, __uint_as_float(rng)));
+      stp<NT>(st.thr[parity], pos, make_float4(1.f, 1.f, 1.f, __uint_as_float(1u)));   // wasDiscrete = true, bounce 0
+      if (sc.has_extinction) stp<NT>(st.ext[parity], pos, make_float4(0.f, 0.f, 0.f, 0.f));
+      stp<NT>(st.smp_rgb, smp, make_float4(0.f, 0.f, 0.f, 1.f));
+      stp<NT>(st.smp_nd, smp, make_float4(0.f, 0.f, 0.f, 0.f));
     }
   }
 }
@@ -610,7 +616,7 @@ HJ_DEV void linear_scan(const DeviceScene& sc, Ray r, RawHit& h, bool any) {
 // bounce k-1 is added during this phase, emission of bounce k in the shade that follows the barrier.  A closest-hit
 // ray only records its hit (objectID -1 = miss); an unoccluded shadow ray adds its NEE radiance (render.glsl:122-124).
 // Needs sh.head == 0 and the hot nodes loaded (synced).
-template <bool USE_BVH, bool PAIRS>
+template <bool USE_BVH, bool PAIRS, bool NT>
 HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t n,
                                uint32_t ns, WgShared& sh) {
   const uint32_t seg = g * st.pool;
@@ -621,21 +627,21 @@ HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint
     any = i >= n;
     slot = any ? i - n : i;                                         // position in the path / shadow arrays
     float4 o, d;
-    if (any) { o = ldp(st.sh_o + seg, slot); d = ldp(st.sh_d + seg, slot); }
-    else { o = ldp(ro, slot); d = ldp(rd, slot); }
+    if (any) { o = ldp<NT>(st.sh_o + seg, slot); d = ldp<NT>(st.sh_d + seg, slot); }
+    else { o = ldp<NT>(ro, slot); d = ldp<NT>(rd, slot); }
     r.o = xyz(o); r.d = xyz(d);
     r.tmin = (!any && (__float_as_uint(o.w) & kCameraFlag) != 0u) ? kEps : 2.0f * kEps;   // render.glsl:33,132; scene.glsl:85
     r.tmax = any ? d.w : kInf;
   };
   auto finish = [&](bool done, uint32_t slot, const RawHit& h, bool any) {   // wave-convergent
-    if (done && !any) stp(st.hit + seg, slot, make_float4(h.t, __int_as_float(h.id), h.u, h.v));
+    if (done && !any) stp<NT>(st.hit + seg, slot, make_float4(h.t, __int_as_float(h.id), h.u, h.v));
     const bool add = done && any && h.id < 0;       // unoccluded shadow ray: render.glsl:123
     if (add) {
-      const float4 cc = ldp(st.sh_c + seg, slot);
+      const float4 cc = ldp<NT>(st.sh_c + seg, slot);
       const uint32_t smp = __float_as_uint(cc.w);
-      float4 s = ldp(st.smp_rgb, smp);
+      float4 s = ldp<NT>(st.smp_rgb, smp);
       s.x += cc.x; s.y += cc.y; s.z += cc.z;
-      stp(st.smp_rgb, smp, s);
+      stp<NT>(st.smp_rgb, smp, s);
     }
     unocc += (uint32_t)__popcll(__ballot(add));
   };
@@ -668,6 +674,7 @@ HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint
 // stay close together in memory.  Paths whose ray missed are over (render.glsl:94-96): nothing refers to them again.
 // Starts with a barrier (all hit records written); needs sh.cnt_hit[] == 0; leaves the tag counts there.
 // `waves` = waves of the workgroup that take part.
+template <bool NT>
 HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t n, WgShared& sh,
                                 uint32_t waves) {
   const uint32_t G = st.num_wg;
@@ -679,7 +686,7 @@ HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uin
   const uint32_t r0 = wave * rpw < rows ? wave * rpw : rows, r1 = r0 + rpw < rows ? r0 + rpw : rows;
   auto tag_of = [&](uint32_t i) -> uint32_t {
     if (i >= n) return 0xFFu;
-    const int id = __float_as_int(ldp(hit, i).y);
+    const int id = __float_as_int(ldp<NT>(hit, i).y);
     return id >= 0 ? sc.materials[id] >> HJ_MATERIAL_TAG_SHIFT : 0xFFu;
   };
   uint32_t cnt[kNumTags];
@@ -722,6 +729,7 @@ HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uin
 // Shades the hits counted in sh.cnt_hit[] (paths of `parity`); the record of a continuing path is written at the
 // next free position of the arrays of parity ^ 1 (sh.n_ray[parity ^ 1]), NEE shadow rays become shadow records
 // (sh.n_shadow).
+template <bool NT>
 HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t max_bounces,
                         uint32_t rr_start, WgShared& sh, uint32_t waves) {
   const uint32_t G = st.num_wg;
@@ -742,9 +750,9 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
     uint32_t rng = 0, smp = 0, flags_out = 0;
     if (valid) {
       const uint32_t slot = seg + q[i];
-      const float4 hr = ldp(st.hit, slot);
-      const float4 ro4 = ldp(st.ray_o[parity], slot), rd4 = ldp(st.ray_d[parity], slot);
-      const float4 th4 = ldp(st.thr[parity], slot);
+      const float4 hr = ldp<NT>(st.hit, slot);
+      const float4 ro4 = ldp<NT>(st.ray_o[parity], slot), rd4 = ldp<NT>(st.ray_d[parity], slot);
+      const float4 th4 = ldp<NT>(st.thr[parity], slot);
       const v3 ro = xyz(ro4), rd = xyz(rd4);
       T = xyz(th4);
       const uint32_t flags = __float_as_uint(th4.w);
@@ -757,11 +765,11 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
       if (id < sc.ns) populate_sphere(sc.spheres[id], its);
       else if (id < sc.ns + sc.nq) populate_quad(sc, id - sc.ns, hr.z, hr.w, its);
       else populate_triangle(sc, id - sc.ns - sc.nq, hr.z, hr.w, its);
-      if (bounce == 0) stp(st.smp_nd, smp, make_float4(its.n.x, its.n.y, its.n.z, hr.x));   // render.glsl:102-105
+      if (bounce == 0) stp<NT>(st.smp_nd, smp, make_float4(its.n.x, its.n.y, its.n.z, hr.x));   // render.glsl:102-105
       const uint32_t mat = sc.materials[id];
       const uint32_t midx = mat & HJ_MATERIAL_INDEX_MASK;
       if (sc.has_extinction) {                                                             // render.glsl:111-112
-        ext = xyz(ldp(st.ext[parity], slot));
+        ext = xyz(ldp<NT>(st.ext[parity], slot));
         const float dist = len3(ro - its.p);
         T = T * V(hj_exp(-ext.x * dist), hj_exp(-ext.y * dist), hj_exp(-ext.z * dist));
       }
@@ -770,9 +778,9 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
         case HJ_MAT_EMISSIVE: {
           if (was_discrete) {                                                              // render.glsl:114-116
             const v3 e = T * xyz(sc.emissive[midx]);
-            float4 s = ldp(st.smp_rgb, smp);
+            float4 s = ldp<NT>(st.smp_rgb, smp);
             s.x += e.x; s.y += e.y; s.z += e.z;
-            stp(st.smp_rgb, smp, s);
+            stp<NT>(st.smp_rgb, smp, s);
           }
           alive = false;   // sampleBSDF weight 0, wo unwritten (material.glsl:88-89)
           break;
@@ -841,17 +849,17 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
     const uint32_t qn = lds_push(&sh.n_ray[np], alive);
     if (alive) {
       const uint32_t pos = seg + qn;
-      stp(st.ray_o[np], pos, make_float4(its.p.x, its.p.y, its.p.z, __uint_as_float(smp)));
-      stp(st.ray_d[np], pos, make_float4(wo.x, wo.y, wo.z, __uint_as_float(rng)));
-      stp(st.thr[np], pos, make_float4(T.x, T.y, T.z, __uint_as_float(flags_out)));
-      if (sc.has_extinction) stp(st.ext[np], pos, make_float4(ext.x, ext.y, ext.z, 0.f));
+      stp<NT>(st.ray_o[np], pos, make_float4(its.p.x, its.p.y, its.p.z, __uint_as_float(smp)));
+      stp<NT>(st.ray_d[np], pos, make_float4(wo.x, wo.y, wo.z, __uint_as_float(rng)));
+      stp<NT>(st.thr[np], pos, make_float4(T.x, T.y, T.z, __uint_as_float(flags_out)));
+      if (sc.has_extinction) stp<NT>(st.ext[np], pos, make_float4(ext.x, ext.y, ext.z, 0.f));
     }
     const uint32_t qs = lds_push(&sh.n_shadow, want_shadow);
     if (want_shadow) {
       const uint32_t pos = seg + qs;
-      stp(st.sh_o, pos, make_float4(its.p.x, its.p.y, its.p.z, 0.f));
-      stp(st.sh_d, pos, make_float4(sdir.x, sdir.y, sdir.z, stmax));
-      stp(st.sh_c, pos, make_float4(scol.x, scol.y, scol.z, __uint_as_float(smp)));
+      stp<NT>(st.sh_o, pos, make_float4(its.p.x, its.p.y, its.p.z, 0.f));
+      stp<NT>(st.sh_d, pos, make_float4(sdir.x, sdir.y, sdir.z, stmax));
+      stp<NT>(st.sh_c, pos, make_float4(scol.x, scol.y, scol.z, __uint_as_float(smp)));
     }
     }
   }
@@ -879,6 +887,7 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
 template <bool USE_BVH, bool PAIRS>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(HJ_PATH_WAVES, 8))) void k_path_wavefront(BatchState st, DeviceScene sc, uint32_t max_bounces,
                                                                   uint32_t rr_start) {
+  constexpr bool NT = PAIRS && HJ_NT_LARGE != 0;   // large trees: stream the path state past the caches (ldp / stp)
   __shared__ WgShared sh;
   const uint32_t g = blockIdx.x;
   uint32_t groups_left = wg_num_groups(st, g);
@@ -894,7 +903,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
       const uint32_t n0 = uni(sh.n_ray[parity]);
       const uint32_t ngen = min(groups_left, (st.pool - n0) >> 6);
       if (ngen != 0) {
-        stage_gen_camera(st, sc, g, sh, parity, n0, k_next, ngen, waves);
+        stage_gen_camera<NT>(st, sc, g, sh, parity, n0, k_next, ngen, waves);
         k_next += ngen;
         groups_left -= ngen;
         wg_sync(waves);
@@ -918,10 +927,10 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
       if (threadIdx.x == 0) { sh.head = 0; sh.n_ray[parity ^ 1u] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; }
       if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
       wg_sync(waves);
-      stage_trace_merged<USE_BVH, PAIRS>(st, sc, g, parity, n, ns, sh);
-      compact_hits_by_tag(st, sc, g, n, sh, waves);
+      stage_trace_merged<USE_BVH, PAIRS, NT>(st, sc, g, parity, n, ns, sh);
+      compact_hits_by_tag<NT>(st, sc, g, n, sh, waves);
       wg_sync(waves);
-      if (n != 0) stage_shade(st, sc, g, parity, max_bounces, rr_start, sh, waves);
+      if (n != 0) stage_shade<NT>(st, sc, g, parity, max_bounces, rr_start, sh, waves);
       total_closest += n;
       total_shadow += ns;
       for (uint32_t k = 0; k < kNumTags; k++) total_hits += uni(sh.cnt_hit[k]);
@@ -955,7 +964,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_gen_camera(BatchState st, Dev
   const uint32_t g = blockIdx.x;
   if (threadIdx.x == 0) sh.n_gen = 0;
   __syncthreads();
-  stage_gen_camera(st, sc, g, sh, 0, 0, 0, wg_num_groups(st, g), blockDim.x >> 6);
+  stage_gen_camera<false>(st, sc, g, sh, 0, 0, 0, wg_num_groups(st, g), blockDim.x >> 6);
   __syncthreads();
   if (threadIdx.x == 0) {
     st.cnt_ray[0][g] = sh.n_gen;
@@ -976,8 +985,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_trace_closest(BatchState st, 
   if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
   if (USE_BVH && n != 0) load_hot_nodes(sc, sh);
   __syncthreads();
-  stage_trace_merged<USE_BVH, true>(st, sc, g, parity, n, 0, sh);
-  compact_hits_by_tag(st, sc, g, n, sh, blockDim.x >> 6);
+  stage_trace_merged<USE_BVH, true, false>(st, sc, g, parity, n, 0, sh);
+  compact_hits_by_tag<false>(st, sc, g, n, sh, blockDim.x >> 6);
   __syncthreads();
   if (threadIdx.x < kNumTags) st.cnt_hit[g * kNumTags + threadIdx.x] = sh.cnt_hit[threadIdx.x];
   if (threadIdx.x == 0) {
@@ -996,7 +1005,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_trace_shadow(BatchState st, D
   if (threadIdx.x == 0) { sh.head = 0; sh.n_unocc = 0; }
   if (USE_BVH && ns != 0) load_hot_nodes(sc, sh);
   __syncthreads();
-  stage_trace_merged<USE_BVH, true>(st, sc, g, 0, 0, ns, sh);
+  stage_trace_merged<USE_BVH, true, false>(st, sc, g, 0, 0, ns, sh);
   __syncthreads();
   if (threadIdx.x == 0) st.acc_unoccluded[g] += sh.n_unocc;
 }
@@ -1008,7 +1017,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(BatchState st, DeviceSc
   if (threadIdx.x == 0) { sh.n_ray[parity ^ 1u] = 0; sh.n_shadow = 0; }
   if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = st.cnt_hit[g * kNumTags + threadIdx.x];
   __syncthreads();
-  stage_shade(st, sc, g, parity, max_bounces, rr_start, sh, blockDim.x >> 6);
+  stage_shade<false>(st, sc, g, parity, max_bounces, rr_start, sh, blockDim.x >> 6);
   __syncthreads();
   if (threadIdx.x == 0) {
     st.cnt_ray[parity ^ 1u][g] = sh.n_ray[parity ^ 1u];
