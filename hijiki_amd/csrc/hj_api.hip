@@ -1669,10 +1669,10 @@ int hj_debug_samples(hj_context* ctx, const hj_image_block* block, const hj_rend
 }
 
 #ifdef HJ_WALK_STATS
-extern "C" __attribute__((visibility("default"))) int hj_debug_round_stats(unsigned long long out[24], int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hj::g_round_stats), 24 * sizeof(unsigned long long)) != hipSuccess) return HJ_ERR_DEVICE;
+extern "C" __attribute__((visibility("default"))) int hj_debug_round_stats(unsigned long long out[32], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hj::g_round_stats), 32 * sizeof(unsigned long long)) != hipSuccess) return HJ_ERR_DEVICE;
   if (reset) {
-    unsigned long long z[24] = {};
+    unsigned long long z[32] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(hj::g_round_stats), z, sizeof z) != hipSuccess) return HJ_ERR_DEVICE;
   }
   return HJ_OK;

@@ -264,7 +264,7 @@ constexpr uint32_t kRefillMin = 32;   // sweep on the fused kernel: 16 -> 1.39, 
 __device__ unsigned long long g_walk_stats[16];   // [10..12] wave cycles by phase, [13] total, [14] lane-steps on nodes outside the LDS copy
 // rounds of the fused kernel by size bucket b (rays of the round in [64 * 4^b / 4, 64 * 4^b), b = 0..7):
 // [b] rounds, [8 + b] rays, [16 + b] wave-cycles (wall clock of the round x waves of the workgroup still alive)
-__device__ unsigned long long g_round_stats[24];
+__device__ unsigned long long g_round_stats[32];   // [0..23] rounds by size; [24..28] wall cycles x waves of top-up, walk, hit compaction, shade, the rest of a round
 #define HJ_STAT(i, v) do { const long long v_ = (long long)(v); if (__lane_id() == 0) ws[i] += (unsigned long long)v_; } while (0)
 #else
 #define HJ_STAT(i, v) do { } while (0)
@@ -674,7 +674,7 @@ HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint
 // stay close together in memory.  Paths whose ray missed are over (render.glsl:94-96): nothing refers to them again.
 // Starts with a barrier (all hit records written); needs sh.cnt_hit[] == 0; leaves the tag counts there.
 // `waves` = waves of the workgroup that take part.
-template <bool NT>
+template <bool NT, uint32_t R>
 HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t n, WgShared& sh,
                                 uint32_t waves) {
   const uint32_t G = st.num_wg;
@@ -684,18 +684,31 @@ HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uin
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t rows = (n + 63u) >> 6, rpw = (rows + waves - 1u) / waves;
   const uint32_t r0 = wave * rpw < rows ? wave * rpw : rows, r1 = r0 + rpw < rows ? r0 + rpw : rows;
-  auto tag_of = [&](uint32_t i) -> uint32_t {
-    if (i >= n) return 0xFFu;
-    const int id = __float_as_int(ldp<NT>(hit, i).y);
-    return id >= 0 ? sc.materials[id] >> HJ_MATERIAL_TAG_SHIFT : 0xFFu;
+  // Both passes take R rows per memory trip (hit record, then its material word: two dependent fetches per row, and
+  // the ballots keep the compiler from overlapping rows by itself).  R = 4: +1 % (cbox), +1.6 % (spheres).  The
+  // pair-node instantiation of the fused kernel keeps R = 1: with more, its register allocation puts two scratch reloads
+  // into the walk's leaf phase (-3 % at 1 M triangles; tools/spill_scan.py shows them).
+  auto tags4 = [&](uint32_t row, uint32_t tag[R]) {
+    int id[R];
+#pragma unroll
+    for (uint32_t j = 0; j < R; j++) {
+      const uint32_t i = (row + j) * 64u + lane;
+      id[j] = (row + j < r1 && i < n) ? __float_as_int(ldp<NT>(hit, i).y) : -1;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < R; j++) tag[j] = id[j] >= 0 ? sc.materials[id[j]] >> HJ_MATERIAL_TAG_SHIFT : 0xFFu;
   };
   uint32_t cnt[kNumTags];
 #pragma unroll
   for (uint32_t k = 0; k < kNumTags; k++) cnt[k] = 0;
-  for (uint32_t row = r0; row < r1; row++) {
-    const uint32_t tag = tag_of(row * 64u + lane);
+#pragma unroll 1
+  for (uint32_t row = r0; row < r1; row += R) {
+    uint32_t tag[R];
+    tags4(row, tag);
 #pragma unroll
-    for (uint32_t k = 0; k < kNumTags; k++) cnt[k] += (uint32_t)__popcll(__ballot(tag == k));
+    for (uint32_t j = 0; j < R; j++)
+#pragma unroll
+      for (uint32_t k = 0; k < kNumTags; k++) cnt[k] += (uint32_t)__popcll(__ballot(tag[j] == k));
   }
   if (lane == 0) {
 #pragma unroll
@@ -708,14 +721,19 @@ HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uin
     base[k] = 0;
     for (uint32_t w = 0; w < wave; w++) base[k] += uni(sh.wcnt[w][k]);
   }
-  for (uint32_t row = r0; row < r1; row++) {
-    const uint32_t i = row * 64u + lane;
-    const uint32_t tag = tag_of(i);
+#pragma unroll 1
+  for (uint32_t row = r0; row < r1; row += R) {
+    uint32_t tag[R];
+    tags4(row, tag);
 #pragma unroll
-    for (uint32_t k = 0; k < kNumTags; k++) {
-      const unsigned long long mask = __ballot(tag == k);
-      if (tag == k) st.q_hit[((size_t)k * G + g) * st.pool + base[k] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = i;
-      base[k] += (uint32_t)__popcll(mask);
+    for (uint32_t j = 0; j < R; j++) {
+      const uint32_t i = (row + j) * 64u + lane;
+#pragma unroll
+      for (uint32_t k = 0; k < kNumTags; k++) {
+        const unsigned long long mask = __ballot(tag[j] == k);
+        if (tag[j] == k) st.q_hit[((size_t)k * G + g) * st.pool + base[k] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = i;
+        base[k] += (uint32_t)__popcll(mask);
+      }
     }
   }
   if (threadIdx.x < kNumTags) {
@@ -903,10 +921,16 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
       const uint32_t n0 = uni(sh.n_ray[parity]);
       const uint32_t ngen = min(groups_left, (st.pool - n0) >> 6);
       if (ngen != 0) {
+#ifdef HJ_WALK_STATS
+        const unsigned long long gen_t0 = wall_clock64();
+#endif
         stage_gen_camera<NT>(st, sc, g, sh, parity, n0, k_next, ngen, waves);
         k_next += ngen;
         groups_left -= ngen;
         wg_sync(waves);
+#ifdef HJ_WALK_STATS
+        if (threadIdx.x == 0) atomicAdd(&g_round_stats[24], (wall_clock64() - gen_t0) * waves);
+#endif
       }
       const uint32_t n = n0 + uni(sh.n_gen), ns = uni(sh.n_shadow);
       if (n + ns == 0) {
@@ -927,9 +951,19 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
       if (threadIdx.x == 0) { sh.head = 0; sh.n_ray[parity ^ 1u] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; }
       if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
       wg_sync(waves);
+#ifdef HJ_WALK_STATS
+      const unsigned long long st_t0 = wall_clock64();
+#endif
       stage_trace_merged<USE_BVH, PAIRS, NT>(st, sc, g, parity, n, ns, sh);
-      compact_hits_by_tag<NT>(st, sc, g, n, sh, waves);
+#ifdef HJ_WALK_STATS
+      wg_sync(waves);                        // (diagnostic build only: the walk ends for all waves before the compaction is timed)
+      const unsigned long long st_t1 = wall_clock64();
+#endif
+      compact_hits_by_tag<NT, PAIRS ? 1u : 4u>(st, sc, g, n, sh, waves);
       wg_sync(waves);
+#ifdef HJ_WALK_STATS
+      const unsigned long long st_t2 = wall_clock64();
+#endif
       if (n != 0) stage_shade<NT>(st, sc, g, parity, max_bounces, rr_start, sh, waves);
       total_closest += n;
       total_shadow += ns;
@@ -942,7 +976,12 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
         while (b < 7u && round_rays >= (16u << (2u * b))) b++;      // 16, 64, 256, 1024, 4096, 16384, 65536
         atomicAdd(&g_round_stats[b], 1ull);
         atomicAdd(&g_round_stats[8 + b], (unsigned long long)round_rays);
-        atomicAdd(&g_round_stats[16 + b], (wall_clock64() - round_t0) * waves);
+        const unsigned long long st_t3 = wall_clock64();
+        atomicAdd(&g_round_stats[16 + b], (st_t3 - round_t0) * waves);
+        atomicAdd(&g_round_stats[25], (st_t1 - st_t0) * waves);
+        atomicAdd(&g_round_stats[26], (st_t2 - st_t1) * waves);
+        atomicAdd(&g_round_stats[27], (st_t3 - st_t2) * waves);
+        atomicAdd(&g_round_stats[28], (st_t0 - round_t0) * waves);
       }
 #endif
     }
@@ -986,7 +1025,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_trace_closest(BatchState st, 
   if (USE_BVH && n != 0) load_hot_nodes(sc, sh);
   __syncthreads();
   stage_trace_merged<USE_BVH, true, false>(st, sc, g, parity, n, 0, sh);
-  compact_hits_by_tag<false>(st, sc, g, n, sh, blockDim.x >> 6);
+  compact_hits_by_tag<false, 4u>(st, sc, g, n, sh, blockDim.x >> 6);
   __syncthreads();
   if (threadIdx.x < kNumTags) st.cnt_hit[g * kNumTags + threadIdx.x] = sh.cnt_hit[threadIdx.x];
   if (threadIdx.x == 0) {

@@ -19,7 +19,7 @@ r = device.Renderer(0); r.upload_scene(cs); r.create_framebuffer(size, size)
 L = device.lib()
 out = (C.c_ulonglong * 16)()
 L.hj_debug_walk_stats(out, 1)
-rs = (C.c_ulonglong * 24)()
+rs = (C.c_ulonglong * 32)()
 L.hj_debug_round_stats(rs, 1)
 o = device.default_opts()
 if max_bounces:
@@ -48,10 +48,15 @@ for b in range(8):
         print(f"  [{lo:6d}, {hi if b < 7 else 10**9:>10d}): {rs[b]/1e3:9.1f} k rounds, {100*rs[8+b]/tot_r:5.1f} % of rays, {100*rs[16+b]/tot_c:5.1f} % of wave-time")
         hist.append({"rays_lo": lo, "rays_hi": hi, "rounds": rs[b], "share_of_rays": rs[8+b]/tot_r, "share_of_wave_time": rs[16+b]/tot_c})
     lo = hi
+stage = rs[24:29]
+stage_tot = sum(stage) or 1
+names = ("top-up (camera rays)", "walk", "hit compaction", "shade", "round bookkeeping")
+print("wall time of the workgroups by stage: " + ", ".join(f"{n} {100*v/stage_tot:.1f} %" for n, v in zip(names, stage)))
 if js:
     json.dump({"kind": kind, "size": size, "spp": spp, "rays": rays, "paths": st["paths"],
                "box_lane_steps_per_ray": (o[2] + o[9]) / rays, "cold_node_steps_per_ray": o[14] / rays,
                "leaf_tests_per_ray": o[4] / rays, "triangle_records_per_ray": o[15] / rays, "lanes_per_box_step": (o[2] + o[9]) / max(1, steps),
                "lanes_per_leaf_phase": o[4] / max(1, o[3]), "active_lanes": o[7] / max(1, o[0]),
                "cycle_share": {"service": o[10] / tot, "box": o[11] / tot, "leaf": o[12] / tot},
+               "stage_share": {n: v / stage_tot for n, v in zip(("top_up", "walk", "compaction", "shade", "bookkeeping"), stage)},
                "rounds": hist}, open(js, "w"), indent=1)
