@@ -1237,7 +1237,9 @@ int hj_comm_create(hj_context* const* ctxs, int n, hj_comm** out) {
   if (!c) return set_error(r, HJ_ERR_NOMEM, "out of host memory");
   c->ctxs.assign(ctxs, ctxs + n);
   c->shared_gpu = shared;
-  if (n > 1 && !shared) {
+  // HJ_COMM_FORCE_RCCL=1 (test rigs with one GPU): a single context also gets a communicator and its reduce goes through
+  // ncclReduce (one rank, in place), so that the loader, the entry points and the stream handling run before a second GPU exists.
+  if ((n > 1 || env_int("HJ_COMM_FORCE_RCCL", 0, 0, 1) != 0) && !shared) {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (!g_rccl.load()) {
       delete c;
@@ -1276,7 +1278,7 @@ int hj_comm_reduce_framebuffers(hj_comm* c, int root) {
     if (hipSetDevice(x->device) != hipSuccess || sync_all(x) != HJ_OK)
       return set_error(r, HJ_ERR_DEVICE, "context %d: stream synchronisation failed: %s", i, x->error.c_str());
   }
-  if (n == 1) return HJ_OK;
+  if (n == 1 && c->comms.empty()) return HJ_OK;
   if (c->shared_gpu) {
     const size_t px = (size_t)r->width * r->height;
     HJ_HIP(r, hipSetDevice(r->device));

@@ -5,6 +5,8 @@ equality of the RGBA32F accumulation buffer (tolerance 0 ulp), not BASELINE.json
 """
 import ctypes as C
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -13,6 +15,7 @@ import scenes
 from hijiki_amd import abi, device, host
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -712,6 +715,66 @@ def test_in_process_multi_gpu_frame(cbox):
     finally:
         for r in rs:
             r.close()
+
+
+
+def test_single_context_reduce_through_rccl(cbox_small, monkeypatch):
+    """HJ_COMM_FORCE_RCCL test rig: a communicator over ONE context still loads librccl, creates a communicator with
+    ncclCommInitAll and sends the framebuffer through ncclReduce (one rank, in place) on the context's stream - the calls
+    a multi-GPU box makes, checked here for loading, signatures and stream handling.  A one-rank sum changes no bit."""
+    monkeypatch.setenv("HJ_COMM_FORCE_RCCL", "1")
+    r = device.Renderer(0)
+    try:
+        r.upload_scene(cbox_small)
+        W, H, spp = 256, 256, 8
+        r.create_framebuffer(W, H)
+        r.render_frame(spp, 5)
+        want = r.read()
+        comm = device.Comm([r])
+        for _ in range(2):                                    # the communicator is reused
+            r.clear()
+            r.render_frame_async(spp, 5)
+            comm.reduce(0)
+            assert (bits(r.read()) == bits(want)).all()
+        comm.close()
+    finally:
+        r.close()
+
+
+_TORCH_RCCL_SCRIPT = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from hijiki_amd import host, device, dist as hjdist
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[1],
+                  HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+cs = host.Scene.synthetic(host.SYNTH_CBOX).compile()
+sr = hjdist.ShardedRenderer(cs, 256, 256)
+sr.render_frame(8, 5, reduce=False)
+before = sr.fb.clone()
+dist.all_reduce(sr.fb, op=dist.ReduceOp.SUM)                 # RCCL on the buffer the C ABI rendered into
+dist.reduce(sr.fb, dst=0, op=dist.ReduceOp.SUM)
+torch.cuda.synchronize()
+assert torch.equal(sr.fb.view(torch.int32), before.view(torch.int32))
+plain = device.Renderer(0); plain.upload_scene(cs); plain.create_framebuffer(256, 256); plain.render_frame(8, 5)
+assert (sr.fb.cpu().numpy().view(np.uint32) == plain.read().view(np.uint32)).all()
+dist.destroy_process_group()
+print("rccl-ok")
+"""
+
+
+def test_torch_rccl_reduce_of_the_external_framebuffer(tmp_path):
+    """The path `bench.py --gpus N` takes, with N = 1 forced through RCCL: torch.distributed's nccl backend (= RCCL)
+    all-reduces and reduces the torch tensor that the C ABI uses as its external framebuffer.  In a child process: the
+    process group must not leak into the suite."""
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(_TORCH_RCCL_SCRIPT)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    p = subprocess.run([sys.executable, str(script), "29533"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "rccl-ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
 def test_pair_nodes_forced_on_small_scenes(gpu_renderer, oracle, cbox, cbox_spheres):
