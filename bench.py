@@ -47,6 +47,10 @@ CONFIGS = {
                name="cbox-synth + mirror sphere + dielectric sphere {W}x{H} {spp}spp, 6332 triangles + 2 spheres"),
     "c4": dict(kind="mesh", short="1M-triangle mesh", tris=1_000_000, size=2048, spp=256,
                name="synthetic 1M-triangle mesh in the box {W}x{H} {spp}spp"),
+    # BASELINE.json configs[4], the 8-GPU config (68.7 G paths: about 28 s per step on ONE GPU, 3.5 s per rank on eight;
+    # `--gpus 8 --config c5 --steps 1 --warmup 0` is the intended use)
+    "c5": dict(kind="cbox", short="cbox", tris=0, size=4096, spp=4096,
+               name="cbox-synth {W}x{H} {spp}spp diffuse+emissive, 6332 triangles"),
 }
 
 

@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -1362,6 +1363,17 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
     for (int k = 0; k < 3; k++)
       if (s->triangles[i].v[k] >= s->num_vertices) return set_error(ctx, HJ_ERR_INVALID, "triangle %zu refers to unknown vertex", i);
   HJ_HIP(ctx, hipSetDevice(ctx->device));
+  // HJ_LBVH_TIMING=1: wall time of the build's stages on stderr (the stream is drained at every mark)
+  const bool timing = env_int("HJ_LBVH_TIMING", 0, 0, 1) != 0;
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (!timing) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "hj_build_bvh_device: %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
+  mark("argument checks");
   std::vector<DevBuf> bufs;
   struct Release { std::vector<DevBuf>& b; ~Release() { for (auto& x : b) x.release(); } } release{bufs};
   bufs.reserve(32);
@@ -1408,6 +1420,7 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
   const dim3 blk(256), grid_n((N + 255u) / 256u);
   uint32_t* d_nbig = nullptr;
   HJ_DEVBUF(d_nbig, uint32_t, 1);
+  mark("allocations + shape upload");
   hipLaunchKernelGGL(hj::lbvh::k_init_bounds, dim3(1), dim3(64), 0, st, t.bounds);
   hipLaunchKernelGGL(hj::lbvh::k_shape_boxes, grid_n, blk, 0, st, sh, t, N);
   uint32_t idx_bits = 1;
@@ -1433,6 +1446,7 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
     if (nbig == 0 || (nbig <= 256 && n - nbig >= 2)) break;
     big_frac = 0.f;                                          // too many large shapes (or nothing else): one Morton tree
   }
+  mark("boxes, keys, sort");
   // ---- the Morton tree over the m = n - nbig small shapes
   const uint32_t m = N - nbig;
   const size_t sub_total = 2 * (size_t)m - 1;
@@ -1440,10 +1454,13 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
   const uint32_t root_exit = total > HJ_BVH_ROOT_EXIT ? (uint32_t)total : HJ_BVH_ROOT_EXIT;
   const dim3 grid_m((m + 255u) / 256u), grid_sub(((uint32_t)sub_total + 255u) / 256u);
   hipLaunchKernelGGL(hj::lbvh::k_hierarchy, grid_m, blk, 0, st, t, m);
-  hipLaunchKernelGGL(hj::lbvh::k_refit, grid_m, blk, 0, st, t, m, idx_mask);
   // ---- clusters of the Morton tree (HJ_LBVH_CLUSTER leaves at most; 0 = the whole tree is one cluster)
   const uint32_t cmax_env = (uint32_t)env_int("HJ_LBVH_CLUSTER", 64, 0, 1 << 20);
   const uint32_t cmax = cmax_env == 0 ? m : cmax_env;
+  // inside the clusters: SAH re-split (one thread per cluster, which needs no boxes of the Morton tree's internal nodes) or the
+  // Morton topology as it is (HJ_LBVH_SAH=0, or clusters larger than the kernel's arrays: bottom-up refit first)
+  const bool sah_clusters = cmax <= hj::lbvh::kClusterMax && env_int("HJ_LBVH_SAH", 1, 0, 1) != 0;
+  if (!sah_clusters) hipLaunchKernelGGL(hj::lbvh::k_refit, grid_m, blk, 0, st, t, m, idx_mask);
   hj::lbvh::Clusters cl{};
   {
     uint32_t* base_w = nullptr; uint32_t* exit_w = nullptr;
@@ -1456,13 +1473,14 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
     HJ_DEVBUF(exit_w, uint32_t, m);
     cl.base = base_w; cl.exit = exit_w;
     HJ_HIP(ctx, hipMemsetAsync(cl.count, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(hj::lbvh::k_mark_clusters, grid_sub, blk, 0, st, t, m, cmax, idx_mask, cl);
+    hipLaunchKernelGGL(hj::lbvh::k_mark_clusters, grid_sub, blk, 0, st, t, m, cmax, idx_mask, cl, sah_clusters);
   }
   uint32_t K = 0;
   HJ_HIP(ctx, hipMemcpyAsync(&K, cl.count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HJ_HIP(ctx, hipStreamSynchronize(st));
+  mark("hierarchy, refit, clusters");
   // ---- the top of the tree on the host: binned SAH over the K clusters and the nbig large shapes
-  struct Item { float lo[3], hi[3]; uint32_t shape; uint32_t cluster; uint32_t records; float weight; };
+  struct Item { float lo[3], hi[3]; uint32_t shape; uint32_t cluster; uint32_t records; float weight; uint32_t first; };
   std::vector<Item> items(K + nbig);
   {
     std::vector<float4> clo(K), chi(K);
@@ -1474,7 +1492,11 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
       it.hi[0] = chi[k].x; it.hi[1] = chi[k].y; it.hi[2] = chi[k].z;
       const uint32_t cnt = __builtin_bit_cast(uint32_t, chi[k].w);
       it.shape = HJ_BVH_INNER; it.cluster = k; it.records = 2 * cnt - 1; it.weight = (float)cnt;
+      it.first = __builtin_bit_cast(uint32_t, clo[k].w);
     }
+    // the cluster numbers come from an atomic counter: put the list into the order of the sorted leaves, so that the few
+    // order-dependent decisions below (equal centroids) do not depend on the run
+    std::sort(items.begin(), items.begin() + K, [](const Item& x, const Item& y) { return x.first < y.first; });
     if (nbig != 0) {   // boxes of the large shapes: the ones k_shape_boxes computed (src/shape.rs:13-20,46-54, src/main.rs:74-79)
       std::vector<unsigned long long> big_keys(nbig);
       HJ_HIP(ctx, hipMemcpy(big_keys.data(), t.keys + m, sizeof(unsigned long long) * nbig, hipMemcpyDeviceToHost));
@@ -1485,25 +1507,28 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
         HJ_HIP(ctx, hipMemcpy(&hi, t.leaf_hi + shp, sizeof(float4), hipMemcpyDeviceToHost));
         Item& it = items[K + k];
         it.lo[0] = lo.x; it.lo[1] = lo.y; it.lo[2] = lo.z; it.hi[0] = hi.x; it.hi[1] = hi.y; it.hi[2] = hi.z;
-        it.shape = shp; it.cluster = 0; it.records = 1; it.weight = 1.0f;
+        it.shape = shp; it.cluster = 0; it.records = 1; it.weight = 1.0f; it.first = 0;
       }
     }
   }
   std::vector<std::pair<uint32_t, hj_bvh_node>> top_records; // (position, record) of the host-built part
   std::vector<uint32_t> cbase(K, 0), cexit(K, 0);
   {
+    using Records = std::vector<std::pair<uint32_t, hj_bvh_node>>;
+    struct Task { size_t a, b; uint32_t pos, exit; int depth; };
     struct Builder {
       std::vector<Item>& items;
-      std::vector<std::pair<uint32_t, hj_bvh_node>>& out;
       std::vector<uint32_t>& cbase;
       std::vector<uint32_t>& cexit;
       std::vector<uint32_t> ids;
+      size_t task_items = 0;                  // subtrees of at most this many items are set aside as tasks (0: never)
+      std::vector<Task> tasks;
       static float area(const float* lo, const float* hi) {
         const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
         return (dx >= 0 && dy >= 0 && dz >= 0) ? dx * dy + dy * dz + dz * dx : 0.f;
       }
-      static void grow(float* lo, float* hi, const Item& it) {
-        for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], it.lo[k]); hi[k] = std::fmax(hi[k], it.hi[k]); }
+      static void grow(float* lo, float* hi, const float* alo, const float* ahi) {
+        for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], alo[k]); hi[k] = std::fmax(hi[k], ahi[k]); }
       }
       // records of the subtree over ids[a, b): the items' own records + one inner record per split
       uint32_t records(size_t a, size_t b) const {
@@ -1511,7 +1536,8 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
         for (size_t i = a; i < b; i++) r += items[ids[i]].records;
         return r;
       }
-      void emit(size_t a, size_t b, uint32_t pos, uint32_t exit, int depth = 0) {       // pre-order (src/main.rs:203-231)
+      // pre-order (src/main.rs:203-231); `defer`: subtrees small enough become tasks for the worker threads instead
+      void emit(Records& out, size_t a, size_t b, uint32_t pos, uint32_t exit, int depth, bool defer) {
         if (b - a == 1) {
           const Item& it = items[ids[a]];
           if (it.shape == HJ_BVH_INNER) { cbase[it.cluster] = pos; cexit[it.cluster] = exit; return; }
@@ -1521,42 +1547,50 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
           out.emplace_back(pos, nd);
           return;
         }
+        if (defer && b - a <= task_items) { tasks.push_back(Task{a, b, pos, exit, depth}); return; }
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (size_t i = a; i < b; i++) {
           const Item& it = items[ids[i]];
-          grow(lo, hi, it);
+          grow(lo, hi, it.lo, it.hi);
           for (int k = 0; k < 3; k++) { const float c = it.lo[k] + it.hi[k]; clo[k] = std::fmin(clo[k], c); chi[k] = std::fmax(chi[k], c); }
         }
-        // binned SAH, 16 bins per axis: cost = area(L) * weight(L) + area(R) * weight(R)
+        // binned SAH, 16 bins per axis, the three axes in one pass over the items: cost = area(L) * weight(L) + area(R) * weight(R)
         constexpr int B = 16;
+        float scale[3];
+        for (int ax = 0; ax < 3; ax++) { const float ext = chi[ax] - clo[ax]; scale[ax] = ext > 0.f ? (float)B / ext : 0.f; }
+        auto bin_of = [&](const Item& it, int ax) {
+          const int q = (int)(((it.lo[ax] + it.hi[ax]) - clo[ax]) * scale[ax]);
+          return q < 0 ? 0 : q >= B ? B - 1 : q;
+        };
+        float blo[3][B][3], bhi[3][B][3], bw[3][B];
+        for (int ax = 0; ax < 3; ax++)
+          for (int q = 0; q < B; q++) { bw[ax][q] = 0.f; for (int k = 0; k < 3; k++) { blo[ax][q][k] = INFINITY; bhi[ax][q][k] = -INFINITY; } }
+        for (size_t i = a; i < b; i++) {
+          const Item& it = items[ids[i]];
+          for (int ax = 0; ax < 3; ax++) {
+            if (scale[ax] == 0.f) continue;
+            const int q = bin_of(it, ax);
+            grow(blo[ax][q], bhi[ax][q], it.lo, it.hi);
+            bw[ax][q] += it.weight;
+          }
+        }
         float best = INFINITY; int best_axis = -1, best_bin = 0;
         for (int ax = 0; ax < 3; ax++) {
-          const float ext = chi[ax] - clo[ax];
-          if (!(ext > 0.f)) continue;
-          float blo[B][3], bhi[B][3], bw[B];
-          for (int q = 0; q < B; q++) { bw[q] = 0.f; for (int k = 0; k < 3; k++) { blo[q][k] = INFINITY; bhi[q][k] = -INFINITY; } }
-          for (size_t i = a; i < b; i++) {
-            const Item& it = items[ids[i]];
-            int q = (int)(((it.lo[ax] + it.hi[ax]) - clo[ax]) / ext * (float)B);
-            q = q < 0 ? 0 : q >= B ? B - 1 : q;
-            grow(blo[q], bhi[q], it);
-            bw[q] += it.weight;
-          }
-          float rlo[B][3], rhi[B][3], rw[B];
+          if (scale[ax] == 0.f) continue;
+          float rarea[B], rw[B];
           float alo[3] = {INFINITY, INFINITY, INFINITY}, ahi[3] = {-INFINITY, -INFINITY, -INFINITY}, aw = 0.f;
           for (int q = B - 1; q >= 1; q--) {
-            for (int k = 0; k < 3; k++) { alo[k] = std::fmin(alo[k], blo[q][k]); ahi[k] = std::fmax(ahi[k], bhi[q][k]); }
-            aw += bw[q];
-            for (int k = 0; k < 3; k++) { rlo[q][k] = alo[k]; rhi[q][k] = ahi[k]; }
-            rw[q] = aw;
+            grow(alo, ahi, blo[ax][q], bhi[ax][q]);
+            aw += bw[ax][q];
+            rarea[q] = area(alo, ahi); rw[q] = aw;
           }
           float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY}, lw = 0.f;
           for (int q = 0; q < B - 1; q++) {
-            for (int k = 0; k < 3; k++) { llo[k] = std::fmin(llo[k], blo[q][k]); lhi[k] = std::fmax(lhi[k], bhi[q][k]); }
-            lw += bw[q];
+            grow(llo, lhi, blo[ax][q], bhi[ax][q]);
+            lw += bw[ax][q];
             if (lw == 0.f || rw[q + 1] == 0.f) continue;
-            const float cost = area(llo, lhi) * lw + area(rlo[q + 1], rhi[q + 1]) * rw[q + 1];
+            const float cost = area(llo, lhi) * lw + rarea[q + 1] * rw[q + 1];
             if (cost < best) { best = cost; best_axis = ax; best_bin = q; }
           }
         }
@@ -1564,13 +1598,7 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
         if (best_axis < 0 || depth > 256) {
           mid = a + (b - a) / 2;                                         // all centroids equal (or a degenerate chain): halves in list order
         } else {
-          const float ext = chi[best_axis] - clo[best_axis];
-          auto left_of = [&](uint32_t id) {
-            const Item& it = items[id];
-            int q = (int)(((it.lo[best_axis] + it.hi[best_axis]) - clo[best_axis]) / ext * (float)B);
-            q = q < 0 ? 0 : q >= B ? B - 1 : q;
-            return q <= best_bin;
-          };
+          auto left_of = [&](uint32_t id) { return bin_of(items[id], best_axis) <= best_bin; };
           mid = (size_t)(std::stable_partition(ids.begin() + (std::ptrdiff_t)a, ids.begin() + (std::ptrdiff_t)b, left_of) - ids.begin());
           if (mid == a || mid == b) mid = a + (b - a) / 2;
         }
@@ -1579,27 +1607,50 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
         nd.shape_index = HJ_BVH_INNER; nd.exit_index = exit;
         out.emplace_back(pos, nd);
         const uint32_t right_pos = pos + 1 + records(a, mid);
-        emit(a, mid, pos + 1, right_pos, depth + 1);                   // exit of a left child = its sibling
-        emit(mid, b, right_pos, exit, depth + 1);                      // a right child inherits its parent's exit
+        emit(out, a, mid, pos + 1, right_pos, depth + 1, defer);        // exit of a left child = its sibling
+        emit(out, mid, b, right_pos, exit, depth + 1, defer);           // a right child inherits its parent's exit
       }
-    } builder{items, top_records, cbase, cexit, {}};
+    } builder{items, cbase, cexit, {}, 0, {}};
     builder.ids.resize(items.size());
     for (size_t k = 0; k < items.size(); k++) builder.ids[k] = (uint32_t)k;
-    builder.emit(0, items.size(), 0, root_exit);
+    // The top levels here, the subtrees below them on worker threads (disjoint ranges of ids[], disjoint records, disjoint
+    // clusters: nothing is shared but read-only data).  Every level costs one pass over all items, so this leaves about
+    // five sequential passes of the ~17 a 25 000-cluster tree takes.
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    builder.task_items = hw > 1 && items.size() >= 4096 ? items.size() / (4 * hw) : 0;
+    builder.emit(top_records, 0, items.size(), 0, root_exit, 0, builder.task_items != 0);
+    if (!builder.tasks.empty()) {
+      std::vector<Records> parts(builder.tasks.size());
+      std::atomic<size_t> next{0};
+      auto work = [&]() {
+        for (size_t i; (i = next.fetch_add(1)) < builder.tasks.size();) {
+          const Task& tk = builder.tasks[i];
+          builder.emit(parts[i], tk.a, tk.b, tk.pos, tk.exit, tk.depth, false);
+        }
+      };
+      std::vector<std::thread> pool;
+      try {
+        for (unsigned w = 1; w < hw; w++) pool.emplace_back(work);
+      } catch (const std::exception&) {}                               // fewer threads than asked for: the rest is done here
+      work();
+      for (auto& th : pool) th.join();
+      for (const Records& part : parts) top_records.insert(top_records.end(), part.begin(), part.end());
+    }
   }
+  mark("host SAH over the clusters");
   HJ_HIP(ctx, hipMemcpyAsync(const_cast<uint32_t*>(cl.base), cbase.data(), sizeof(uint32_t) * K, hipMemcpyHostToDevice, st));
   HJ_HIP(ctx, hipMemcpyAsync(const_cast<uint32_t*>(cl.exit), cexit.data(), sizeof(uint32_t) * K, hipMemcpyHostToDevice, st));
-  // inside the clusters: SAH re-split (one thread per cluster) or the Morton topology as it is (HJ_LBVH_SAH=0, or clusters
-  // larger than the kernel's arrays)
-  if (cmax <= hj::lbvh::kClusterMax && env_int("HJ_LBVH_SAH", 1, 0, 1))
+  if (sah_clusters)
     hipLaunchKernelGGL(hj::lbvh::k_emit_clusters_sah, dim3((K + hj::lbvh::kSahThreads - 1) / hj::lbvh::kSahThreads),
                        dim3(hj::lbvh::kSahThreads), 0, st, t, K, cl, idx_mask, d_out);
   else
     hipLaunchKernelGGL(hj::lbvh::k_emit_clusters, grid_sub, blk, 0, st, t, m, cl, idx_mask, d_out);
   HJ_HIP(ctx, hipGetLastError());
+  mark("cluster subtrees");
   HJ_HIP(ctx, hipMemcpyAsync(out_nodes, d_out, sizeof(hj_bvh_node) * total, hipMemcpyDeviceToHost, st));
   HJ_HIP(ctx, hipStreamSynchronize(st));
   for (const auto& pr : top_records) out_nodes[pr.first] = pr.second;
+  mark("records to the host");
 #undef HJ_DEVBUF
   if (out_num_nodes) *out_num_nodes = total;
   return HJ_OK;

@@ -234,7 +234,10 @@ struct Clusters {
   const uint32_t* exit;   // [K] exit of the cluster's right spine
 };
 
-__global__ __launch_bounds__(256) void k_mark_clusters(Tree t, uint32_t n, uint32_t cmax, unsigned long long idx_mask, Clusters c) {
+// `scan_boxes`: the internal nodes have no boxes (k_refit was skipped: k_emit_clusters_sah computes its own), so a cluster
+// root unites the boxes of its (at most cmax) leaves itself.
+__global__ __launch_bounds__(256) void k_mark_clusters(Tree t, uint32_t n, uint32_t cmax, unsigned long long idx_mask, Clusters c,
+                                                       bool scan_boxes) {
   const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= 2 * n - 1) return;
   const bool leaf = id >= n - 1;
@@ -250,6 +253,15 @@ __global__ __launch_bounds__(256) void k_mark_clusters(Tree t, uint32_t n, uint3
     if (leaf) {
       const uint32_t shape = (uint32_t)(t.keys[id - (n - 1)] & idx_mask);
       lo = t.leaf_lo[shape]; hi = t.leaf_hi[shape]; first = id - (n - 1);
+    } else if (scan_boxes) {
+      first = t.first[id];
+      lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f); hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+      for (uint32_t i = 0; i < cnt; i++) {
+        const uint32_t shape = (uint32_t)(t.keys[first + i] & idx_mask);
+        const float4 a = t.leaf_lo[shape], b = t.leaf_hi[shape];
+        lo.x = f_min(lo.x, a.x); lo.y = f_min(lo.y, a.y); lo.z = f_min(lo.z, a.z);
+        hi.x = f_max(hi.x, b.x); hi.y = f_max(hi.y, b.y); hi.z = f_max(hi.z, b.z);
+      }
     } else {
       lo = t.node_lo[id]; hi = t.node_hi[id]; first = t.first[id];
     }
