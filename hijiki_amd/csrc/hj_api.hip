@@ -950,12 +950,14 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
   run.tm = Timer{ctx, (run.o.flags & HJ_RENDER_TIME_KERNELS) != 0};
   run.split = (run.o.flags & HJ_RENDER_SPLIT_KERNELS) != 0;
   // Default batch: large batches amortise the latency-bound tail of a batch (measured: cbox+mirror+glass 700 ->
-  // 960 Mpaths/s from 512 to 2048 blocks, +2-3 % more at 4096), but at least ~8 batches should exist so that the slots
-  // can overlap.  Path state does not grow with the batch (pool), only the sample buffers do (0.5 GB per 1024 blocks).
+  // 960 Mpaths/s from 512 to 2048 blocks, +2-3 % more at 4096), but at least four batches should exist so that the three
+  // slots can overlap (tools/batch_probe.py, rank 0's share of the cbox frame at 8 / 4 / 2 / 1 ranks: a quarter of the blocks
+  // per batch beats an eighth by 3.4 / 1.6 / 0.8 / 0.8 %, a half loses 3-5 %).  Path state does not grow with the batch
+  // (pool), only the sample buffers do (0.5 GB per 1024 blocks).
   const size_t n = total_blocks;
   static const size_t batch_cap = (size_t)env_int("HJ_BATCH_CAP", 8192, 64, 8192);
   run.batch = run.o.batch_blocks ? run.o.batch_blocks
-                                 : (uint32_t)std::min<size_t>(batch_cap, std::max<size_t>(256, ((n + 7) / 8 + 63) / 64 * 64));
+                                 : (uint32_t)std::min<size_t>(batch_cap, std::max<size_t>(256, ((n + 3) / 4 + 63) / 64 * 64));
   run.batch = std::min<uint32_t>(run.batch, run.split ? 2048u : 8192u);   // the split path keeps every sample of a batch in flight
   rc = sync_all(ctx);
   if (rc != HJ_OK) return rc;
