@@ -250,7 +250,7 @@ def main():
             "config": {"workload": f"{args.config}: {label}, BVH, block 128, seed {args.seed}",
                        "partition": f"ImageBlock (bx, by) of pass p -> rank (bx + by + p) mod {world}, RCCL sum-reduce of the {W}x{H} RGBA32F framebuffer"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # the CPU baseline is a one-GPU-run item (rank 0, N = 1 only)
             out["cpu_baseline"] = cpu_baseline(cs, W, H, spp, args.seed, cfg["short"])
 
         # ---- roofline of the dominant kernel, from THIS run's device counters and HIP events (rank 0's launches)
