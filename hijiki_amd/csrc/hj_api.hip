@@ -146,7 +146,8 @@ template <class T>
 int upload(hj_context* ctx, const T* src, size_t count, const T** out) {
   ctx->scene_bufs.emplace_back();
   DevBuf& b = ctx->scene_bufs.back();
-  int rc = dev_alloc(ctx, b, std::max<size_t>(count * sizeof(T), 16));
+  // 64 bytes of slack: the walk's merged step reads two 16-byte parts of every shape record, a sphere has one
+  int rc = dev_alloc(ctx, b, count * sizeof(T) + 64);
   if (rc != HJ_OK) return rc;
   if (count) HJ_HIP(ctx, hipMemcpy(b.p, src, count * sizeof(T), hipMemcpyHostToDevice));
   *out = static_cast<const T*>(b.p);

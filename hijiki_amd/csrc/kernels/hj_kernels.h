@@ -883,6 +883,49 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
   }
 }
 
+// The shade stage as a CALLED function (HJ_SHADE_CALL): shade needs about twice the registers of the walk, and inlined into
+// the fused kernel it makes the register allocator of that kernel spill - where, is decided globally, and a single reload
+// inside the walk loop costs a memory trip per round of the loop.  As a function of its own it is allocated on its own
+// (same register budget: the waves-per-SIMD attribute of the calling kernel is propagated to it), and its spills stay
+// inside it.  The batch and scene descriptions are read from the calling kernel's argument segment (every kernel that
+// calls this starts with (BatchState, DeviceScene)): scalar loads, as in the kernel itself.
+#ifndef HJ_SHADE_CALL
+#define HJ_SHADE_CALL 2      // 0: every stage inlined into the fused kernel, 1: shade called, 2: top-up, hit compaction and shade called
+#endif
+typedef __attribute__((address_space(3))) WgShared* WgSharedLds;
+constexpr size_t kSceneArgOffset = (sizeof(BatchState) + alignof(DeviceScene) - 1) / alignof(DeviceScene) * alignof(DeviceScene);
+template <bool NT>
+__device__ __attribute__((noinline)) void stage_shade_call(uint32_t ka_lo, uint32_t ka_hi, uint32_t g, uint32_t parity, uint32_t max_bounces,
+                                                            uint32_t rr_start, uint32_t sh_lds, uint32_t waves) {
+  // (the argument-segment pointer comes from the kernel: the intrinsic is null in a called function)
+  typedef const __attribute__((address_space(4))) char* KArg;
+  KArg ka = (KArg)(((uint64_t)uni(ka_hi) << 32) | (uint64_t)uni(ka_lo));
+  const BatchState& st = *(const BatchState*)ka;
+  const DeviceScene& sc = *(const DeviceScene*)(ka + kSceneArgOffset);
+  WgShared& sh = *(WgShared*)(WgSharedLds)(uintptr_t)uni(sh_lds);
+  stage_shade<NT>(st, sc, uni(g), uni(parity), uni(max_bounces), uni(rr_start), sh, uni(waves));
+}
+
+template <bool NT>
+__device__ __attribute__((noinline)) void stage_gen_camera_call(uint32_t ka_lo, uint32_t ka_hi, uint32_t g, uint32_t sh_lds, uint32_t parity,
+                                                                 uint32_t n0, uint32_t k0, uint32_t ngen, uint32_t waves) {
+  typedef const __attribute__((address_space(4))) char* KArg;
+  KArg ka = (KArg)(((uint64_t)uni(ka_hi) << 32) | (uint64_t)uni(ka_lo));
+  const BatchState& st = *(const BatchState*)ka;
+  const DeviceScene& sc = *(const DeviceScene*)(ka + kSceneArgOffset);
+  WgShared& sh = *(WgShared*)(WgSharedLds)(uintptr_t)uni(sh_lds);
+  stage_gen_camera<NT>(st, sc, uni(g), sh, uni(parity), uni(n0), uni(k0), uni(ngen), uni(waves));
+}
+template <bool NT, uint32_t R>
+__device__ __attribute__((noinline)) void compact_hits_call(uint32_t ka_lo, uint32_t ka_hi, uint32_t g, uint32_t n, uint32_t sh_lds, uint32_t waves) {
+  typedef const __attribute__((address_space(4))) char* KArg;
+  KArg ka = (KArg)(((uint64_t)uni(ka_hi) << 32) | (uint64_t)uni(ka_lo));
+  const BatchState& st = *(const BatchState*)ka;
+  const DeviceScene& sc = *(const DeviceScene*)(ka + kSceneArgOffset);
+  WgShared& sh = *(WgShared*)(WgSharedLds)(uintptr_t)uni(sh_lds);
+  compact_hits_by_tag<NT, R>(st, sc, uni(g), uni(n), sh, uni(waves));
+}
+
 // ------------------------------------------------------------------ kernels
 
 // The whole life of a batch in ONE launch.  Every workgroup walks through ITS samples (64-sample groups g, g + G, ...):
@@ -908,6 +951,10 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
   constexpr bool NT = PAIRS && HJ_NT_LARGE != 0;   // large trees: stream the path state past the caches (ldp / stp)
   __shared__ WgShared sh;
   const uint32_t g = blockIdx.x;
+#if HJ_SHADE_CALL
+  const uint64_t ka_ = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const uint32_t ka_lo = (uint32_t)ka_, ka_hi = (uint32_t)(ka_ >> 32), sh_lds = (uint32_t)(uintptr_t)(WgSharedLds)&sh;
+#endif
   uint32_t groups_left = wg_num_groups(st, g);
   uint32_t total_closest = 0, total_shadow = 0, total_hits = 0, total_unocc = 0;   // (thread 0's copies are published)
   if (groups_left != 0) {
@@ -924,7 +971,11 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
 #ifdef HJ_WALK_STATS
         const unsigned long long gen_t0 = wall_clock64();
 #endif
+#if HJ_SHADE_CALL >= 2
+        stage_gen_camera_call<NT>(ka_lo, ka_hi, g, sh_lds, parity, n0, k_next, ngen, waves);
+#else
         stage_gen_camera<NT>(st, sc, g, sh, parity, n0, k_next, ngen, waves);
+#endif
         k_next += ngen;
         groups_left -= ngen;
         wg_sync(waves);
@@ -959,12 +1010,20 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
       wg_sync(waves);                        // (diagnostic build only: the walk ends for all waves before the compaction is timed)
       const unsigned long long st_t1 = wall_clock64();
 #endif
+#if HJ_SHADE_CALL >= 2
+      compact_hits_call<NT, PAIRS ? 1u : 4u>(ka_lo, ka_hi, g, n, sh_lds, waves);
+#else
       compact_hits_by_tag<NT, PAIRS ? 1u : 4u>(st, sc, g, n, sh, waves);
+#endif
       wg_sync(waves);
 #ifdef HJ_WALK_STATS
       const unsigned long long st_t2 = wall_clock64();
 #endif
+#if HJ_SHADE_CALL
+      if (n != 0) stage_shade_call<NT>(ka_lo, ka_hi, g, parity, max_bounces, rr_start, sh_lds, waves);
+#else
       if (n != 0) stage_shade<NT>(st, sc, g, parity, max_bounces, rr_start, sh, waves);
+#endif
       total_closest += n;
       total_shadow += ns;
       for (uint32_t k = 0; k < kNumTags; k++) total_hits += uni(sh.cnt_hit[k]);
