@@ -150,6 +150,21 @@ HJ_DEV bool triangle_test(const Ray& r, float4 A, float4 B, float4 C, RawHit& h)
   return false;
 }
 
+// quad.glsl:7-25 on record values (origin, edge1, edge2)
+HJ_DEV bool quad_test(const Ray& r, float4 O, float4 E1, float4 E2, RawHit& h) {
+  const v3 e1 = xyz(E1), e2 = xyz(E2);
+  const v3 n = cross3(e1, e2);
+  const v3 ro = r.o - xyz(O);
+  const v3 q = cross3(ro, r.d);
+  const float d = 1.0f / dot3(r.d, n);
+  const float u = d * (-dot3(q, e2));
+  const float v = d * dot3(q, e1);
+  if (u < 0.0f || u > 1.0f || v < 0.0f || v > 1.0f) return false;
+  const float t = d * (-dot3(n, ro));
+  if (r.tmin <= t && t <= r.tmax) { h.t = t; h.u = u; h.v = v; return true; }
+  return false;
+}
+
 // What the walk does when it stands on a leaf: `a` is the first word of the node the lane stopped at.
 //   leaf record:  a = shape index                      -> one shape test (scene.glsl:105-119)
 //   PAIR record:  a = kInnerFlag | kPairFlag | pair    -> an inner node whose two children are triangle leaves, entered:
@@ -273,9 +288,19 @@ __device__ unsigned long long g_round_stats[32];   // [0..23] rounds by size; [2
 // MODE 0: closest-hit rays, 1: any-hit (shadow) rays, 2: both kinds in one queue (fetch says which per ray).
 // PAIRS: the scene has pair nodes (leaf_test); without them the code for them is not even compiled in (it costs 4 % on
 // a scene that has none).
+#ifndef HJ_MERGE_LEAF
+#define HJ_MERGE_LEAF 2      // 0: separate leaf phase everywhere, 1: merged first step on trees without pair nodes only, 2: everywhere
+#endif
+#ifndef HJ_SHADOW_CARRY
+#define HJ_SHADOW_CARRY 1
+#endif
+#ifndef HJ_FETCH_SELECT
+#define HJ_FETCH_SELECT 1
+#endif
 template <int MODE, bool PAIRS, class Fetch, class Finish>
 HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head, const float4* s_nodes,
                              Fetch fetch, Finish finish) {
+  constexpr bool MERGE = HJ_MERGE_LEAF == 2 || (HJ_MERGE_LEAF == 1 && !PAIRS);
   const uint32_t lane = __lane_id();
   const uint32_t nn = sc.num_nodes, nhot = sc.num_hot;
   bool active = false, pending = false, exhausted = false, any = (MODE == 1);
@@ -292,10 +317,72 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     asm volatile("v_mov_b32 %0, %1" : "=v"(nb_lhi) : "s"((uint32_t)(lb >> 32)));
   }
   RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
+  uint32_t shape = 0, ex = 0;
+  bool at_leaf = false;                  // (MERGE: a leaf reached in one round is tested in the first step of the next)
 #ifdef HJ_WALK_STATS
   unsigned long long ws[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_begin = clock64();
 #endif
+  // Merged first step of a round (MERGE): a lane that reached a leaf in the previous round fetches its SHAPE record in the
+  // same memory trip in which the other lanes fetch their next node (one address select, the same load instructions), then
+  // each kind computes its own test.  The leaf tests of a round so cost no memory round trip of their own, and the lane goes
+  // on with the box steps of this round.  Per ray the sequence of box tests, shape tests and tMax updates is unchanged
+  // (scene.glsl:102-133).  step0_issue only issues the loads, step0_compute consumes them.
+  bool go = false, more = false, pair = false;      // the record has a third 16-byte part; a pair record: six
+  float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0, x2 = x0, x3 = x0, x4 = x0, x5 = x0;
+  auto step0_issue = [&]() {
+    go = active && (at_leaf || cur < nn);
+    more = false; pair = false;
+    x0 = x1 = x2 = x3 = x4 = x5 = make_float4(0.f, 0.f, 0.f, 0.f);   // (nothing is carried from one round to the next)
+    if (go) {
+      uint32_t a_lo, a_hi;
+      if (at_leaf) {
+        uint64_t pa;
+        if (PAIRS && (shape & kInnerFlag) != 0u) {
+          pa = reinterpret_cast<uint64_t>(sc.tri_pair) + 96ull * (uint64_t)(shape & kIndexMask);
+          more = true; pair = true;
+        } else if (shape < sc.ns) {
+          pa = reinterpret_cast<uint64_t>(sc.spheres) + 16ull * (uint64_t)shape;
+        } else if (shape < sc.ns + sc.nq) {
+          pa = reinterpret_cast<uint64_t>(sc.quads) + 48ull * (uint64_t)(shape - sc.ns);
+          more = true;
+        } else {
+          pa = reinterpret_cast<uint64_t>(sc.tri_isect) + 48ull * (uint64_t)(shape - sc.ns - sc.nq);
+          more = true;
+        }
+        a_lo = (uint32_t)pa; a_hi = (uint32_t)(pa >> 32);
+      } else {
+        const bool hot = cur < nhot;
+        a_lo = (hot ? nb_llo : nb_glo) + (cur << 5); a_hi = hot ? nb_lhi : nb_ghi;
+      }
+      const float4* __restrict__ p = reinterpret_cast<const float4*>(((uint64_t)a_hi << 32) | (uint64_t)a_lo);
+      x0 = p[0]; x1 = p[1];
+      if (more) x2 = p[2];
+      if (PAIRS && pair) { x3 = p[3]; x4 = p[4]; x5 = p[5]; }
+    }
+  };
+  auto step0_compute = [&]() {
+    if (go) {
+      if (at_leaf) {
+        const bool anyhit = MODE == 1 || (MODE == 2 && any);
+        bool done = false;
+        if (PAIRS && pair) {
+          if (triangle_test(r, x0, x1, x2, h)) { h.id = (int)__float_as_uint(x0.w); if (anyhit) done = true; else r.tmax = h.t - kEps; }
+          if (!done && triangle_test(r, x3, x4, x5, h)) { h.id = (int)__float_as_uint(x3.w); if (anyhit) done = true; else r.tmax = h.t - kEps; }
+        } else {
+          bool hit;
+          if (shape < sc.ns) hit = intersect_sphere(r, x0, h);
+          else if (shape < sc.ns + sc.nq) hit = quad_test(r, x0, x1, x2, h);
+          else hit = triangle_test(r, x0, x1, x2, h);
+          if (hit) { h.id = (int)shape; if (anyhit) done = true; else r.tmax = h.t - kEps; }
+        }
+        if (done) { active = false; pending = true; }   // occluded shadow ray (h.id >= 0 tells finish)
+        cur = ex; at_leaf = false;
+      } else {
+        at_leaf = node_step<PAIRS>(x0, x1, inv, off, r, cur, shape, ex);
+      }
+    }
+  };
   for (;;) {
 #ifdef HJ_WALK_STATS
     const unsigned long long t_a = clock64();   // [10] service, [11] box steps, [12] leaf tests: wave cycles by phase
@@ -306,43 +393,48 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     // a full write acknowledgement.
     const unsigned long long idle = __ballot(!active);
     const uint32_t nidle = (uint32_t)__popcll(idle);
-    if (nidle >= sc.refill_min || nidle == 64u) {
-      // The loads of the NEW rays are issued first, the results of the finished ones are written (and, for an unoccluded
-      // shadow ray, its sample read, added to and written) after them: both memory round trips are then in flight
-      // together, and the wait for the new rays does not include the stores (vmcnt retires in order: only what was
-      // issued BEFORE a load has to complete with it).
-      bool got = false, any2 = any;
-      uint32_t slot2 = 0;
-      Ray r2; r2.o = V(0, 0, 0); r2.d = V(0, 0, 0); r2.tmin = 0.f; r2.tmax = 0.f;
-      if (!exhausted) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(s_head, nidle);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (!active) {
-          const uint32_t my = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-          if (my < n) { fetch(my, slot2, r2, any2); got = true; }
-        }
-        exhausted = base + nidle >= n;
+    const bool service = nidle >= sc.refill_min || nidle == 64u;
+    // The loads of the NEW rays are issued first, the results of the finished ones are written (and, for an unoccluded
+    // shadow ray, its sample read, added to and written) after them: both memory round trips are then in flight
+    // together, and the wait for the new rays does not include the stores (vmcnt retires in order: only what was
+    // issued BEFORE a load has to complete with it).
+    bool got = false, any2 = any;
+    uint32_t slot2 = 0;
+    Ray r2; r2.o = V(0, 0, 0); r2.d = V(0, 0, 0); r2.tmin = 0.f; r2.tmax = 0.f;
+    RawHit h2; h2.t = 0.f; h2.u = 0.f; h2.v = 0.f; h2.id = -1;   // (a shadow ray carries its pending contribution in t, u, v)
+    if (service && !exhausted) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(s_head, nidle);
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (!active) {
+        const uint32_t my = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+        if (my < n) { fetch(my, slot2, r2, any2, h2); got = true; }
       }
+      exhausted = base + nidle >= n;
+    }
+    if (service) {
       if (__ballot(pending) != 0) finish(pending, slot, h, any);
       pending = false;
-      if (got) {
-        slot = slot2; any = any2; r = r2;
-        inv = V(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-        off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
-        cur = sc.root; h.id = -1; active = true;
-      }
       HJ_STAT(5, 1); HJ_STAT(6, __popcll(__ballot(got)));
     }
-    if (__ballot(active) == 0) break;
+    if (got) {
+      slot = slot2; any = any2; r = r2; h = h2;
+      inv = V(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+      off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
+      cur = sc.root; active = true;
+    }
+    if (__ballot(active || pending) == 0) break;   // (a lane can finish in the merged first step: its result is written by the next service phase)
     HJ_STAT(0, 1); HJ_STAT(7, __popcll(__ballot(active)));
 #ifdef HJ_WALK_STATS
     const unsigned long long t_b = clock64();
     HJ_STAT(10, t_b - t_a);
 #endif
-    uint32_t shape = 0, ex = 0;
-    bool at_leaf = false;
+    if (!MERGE) at_leaf = false;
     uint32_t burst = sc.inner_burst;       // lanes standing on a leaf wait at most this many box steps of the others
+    if (MERGE) {
+      step0_issue(); step0_compute();
+      burst--;
+    }
     while (active && cur < nn && !at_leaf && burst != 0) {
       // hot node: LDS copy, same 32-byte record layout as in HBM, so that ONE address select feeds both 16-byte
       // loads (FLAT loads of base + 32*cur and +16; a per-array `if` compiled to two exec-masked address blocks).
@@ -368,7 +460,7 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     { const unsigned long long m = __ballot(at_leaf), mp = __ballot(at_leaf && (shape & kInnerFlag) != 0u);   // [15] shape records fetched (a pair: two)
       if (m && lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[3] += 1; ws[4] += __popcll(m); ws[15] += __popcll(m) + __popcll(mp); } }
 #endif
-    if (at_leaf) {
+    if (!MERGE && at_leaf) {
       if (leaf_test<PAIRS>(sc, r, shape, h, MODE == 1 || (MODE == 2 && any))) { active = false; pending = true; }   // occluded shadow ray (h.id >= 0 tells finish)
       cur = ex;
     }
@@ -623,12 +715,33 @@ HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint
   const float4* __restrict__ ro = st.ray_o[parity] + seg;
   const float4* __restrict__ rd = st.ray_d[parity] + seg;
   uint32_t unocc = 0;                                               // wave-uniform count (statistics)
-  auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r, bool& any) {
+  // HJ_SHADOW_CARRY: a shadow ray brings its pending NEE contribution along in the registers a closest-hit ray uses for
+  // (t, u, v) - an accepted hit ends a shadow ray, so nothing overwrites them while they matter - and its SAMPLE index in
+  // `slot`: the finish of an unoccluded shadow ray is then one read-modify-write of the sample instead of two dependent trips.
+  // HJ_FETCH_SELECT: loads from selected addresses instead of loads in the two arms of a branch.
+  auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r, bool& any, RawHit& h) {
     any = i >= n;
-    slot = any ? i - n : i;                                         // position in the path / shadow arrays
+    const uint32_t pos = any ? i - n : i;                           // position in the path / shadow arrays
+    slot = pos;
     float4 o, d;
-    if (any) { o = ldp<NT>(st.sh_o + seg, slot); d = ldp<NT>(st.sh_d + seg, slot); }
-    else { o = ldp<NT>(ro, slot); d = ldp<NT>(rd, slot); }
+#if HJ_FETCH_SELECT
+    o = ldp<NT>(any ? st.sh_o + seg : ro, pos); d = ldp<NT>(any ? st.sh_d + seg : rd, pos);
+#if HJ_SHADOW_CARRY
+    const float4 cc = ldp<NT>(st.sh_c + seg, any ? pos : 0u);       // (a closest-hit ray's third load is a dummy)
+    h.t = any ? cc.x : 0.f; h.u = any ? cc.y : 0.f; h.v = any ? cc.z : 0.f;
+    slot = any ? __float_as_uint(cc.w) : pos;
+#endif
+#else
+    if (any) {
+      o = ldp<NT>(st.sh_o + seg, pos); d = ldp<NT>(st.sh_d + seg, pos);
+#if HJ_SHADOW_CARRY
+      const float4 cc = ldp<NT>(st.sh_c + seg, pos);
+      h.t = cc.x; h.u = cc.y; h.v = cc.z;
+      slot = __float_as_uint(cc.w);
+#endif
+    } else { o = ldp<NT>(ro, pos); d = ldp<NT>(rd, pos); }
+#endif
+    h.id = -1;
     r.o = xyz(o); r.d = xyz(d);
     r.tmin = (!any && (__float_as_uint(o.w) & kCameraFlag) != 0u) ? kEps : 2.0f * kEps;   // render.glsl:33,132; scene.glsl:85
     r.tmax = any ? d.w : kInf;
@@ -637,11 +750,17 @@ HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint
     if (done && !any) stp<NT>(st.hit + seg, slot, make_float4(h.t, __int_as_float(h.id), h.u, h.v));
     const bool add = done && any && h.id < 0;       // unoccluded shadow ray: render.glsl:123
     if (add) {
+#if HJ_SHADOW_CARRY
+      float4 s = ldp<NT>(st.smp_rgb, slot);
+      s.x += h.t; s.y += h.u; s.z += h.v;
+      stp<NT>(st.smp_rgb, slot, s);
+#else
       const float4 cc = ldp<NT>(st.sh_c + seg, slot);
       const uint32_t smp = __float_as_uint(cc.w);
       float4 s = ldp<NT>(st.smp_rgb, smp);
       s.x += cc.x; s.y += cc.y; s.z += cc.z;
       stp<NT>(st.smp_rgb, smp, s);
+#endif
     }
     unocc += (uint32_t)__popcll(__ballot(add));
   };
@@ -659,7 +778,7 @@ HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint
       RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
       if (valid) {
         Ray r;
-        fetch(i, slot, r, any);
+        fetch(i, slot, r, any, h);
         linear_scan(sc, r, h, any);
       }
       finish(valid, slot, h, any);

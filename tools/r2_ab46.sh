@@ -1,0 +1,12 @@
+#!/bin/bash
+# merged-first-step variants on top of the called-stages kernel: m0 none, a merge, b + carry, c + carry + select, e service merge, f + carry, g + carry + select
+export GPU_MAX_HW_QUEUES=8
+out=gpurun_out/r2_ab46; mkdir -p $out
+for v in a g; do
+HIJIKI_HIP_LIB=hijiki_amd/lib/var_$v.so timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "golden or config1 or divergent or tinted or quads or random or linear or ragged or traversal or pair_nodes or edge_inputs or split_kernel" > $out/pytest_$v.log 2>&1; rc=$?; tail -2 $out/pytest_$v.log
+[ $rc -ne 0 ] && exit 1
+done
+V="base m0 a b c e f g"
+echo "== C2"; PROBE_ARGS="" tools/ab_variants.sh $V 2>&1 | tee $out/c2.txt
+echo "== C3"; PROBE_ARGS="--kind 1 --spp 256" tools/ab_variants.sh $V 2>&1 | tee $out/c3.txt
+echo "== C4"; PROBE_ARGS="--kind 2 --tris 1000000 --size 2048 --spp 64" tools/ab_variants.sh $V 2>&1 | tee $out/c4.txt
