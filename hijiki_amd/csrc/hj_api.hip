@@ -441,9 +441,12 @@ int enqueue_batch_fused(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::
   // HJ_LDS_PAD_KB (diagnostic): unused dynamic LDS that lowers the number of resident workgroups per CU without
   // touching the code, to measure how the frame rate scales with occupancy.
   static const size_t lds_pad = (size_t)env_int("HJ_LDS_PAD_KB", 0, 0, 64) * 1024;
-  if (!o.use_bvh) hipLaunchKernelGGL((hj::k_path_wavefront<false, false>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
-  else if (ctx->scene.has_pairs) hipLaunchKernelGGL((hj::k_path_wavefront<true, true>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
-  else hipLaunchKernelGGL((hj::k_path_wavefront<true, false>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  const bool pairs = ctx->scene.has_pairs != 0, nt = ctx->scene.stream_state != 0;
+  if (!o.use_bvh) hipLaunchKernelGGL((hj::k_path_wavefront<false, false, false>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  else if (pairs && nt) hipLaunchKernelGGL((hj::k_path_wavefront<true, true, true>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  else if (pairs) hipLaunchKernelGGL((hj::k_path_wavefront<true, true, false>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  else if (nt) hipLaunchKernelGGL((hj::k_path_wavefront<true, false, true>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  else hipLaunchKernelGGL((hj::k_path_wavefront<true, false, false>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
   tm.end(ev, sl.stream);
   if (reconstruct) {
     rc = enqueue_reconstruct(ctx, sl, other, st, nb, o, tm);
@@ -717,13 +720,13 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     // node's first child, the right one the left one's exit) and their triangles go side by side into `pairs`.
     std::vector<uint32_t> pair_of(N, 0xFFFFFFFFu);
     std::vector<float4> pairs;
-    // Worth it on large scenes (with 8 box steps per round: 1 M triangles +12 %, 200 k +3 %: a fifth fewer dependent
-    // fetch rounds per ray, most of them trips beyond the L2).  On cache-resident scenes the longer leaf phase (two tests
-    // while the rest of the wave waits) costs more than the rounds save: -3 % on the 6 k-triangle box at the best burst.
-    // So small trees keep plain leaves and run the kernel instantiation without the pair code.  HJ_PAIR_LEAVES = 0 / 1
-    // forces; default: trees of >= HJ_PAIR_MIN_NODES records.
+    // A fifth fewer dependent fetch rounds per ray.  Before the walk's merged first step (hj_kernels.h) the longer leaf phase
+    // - two tests while the rest of the wave waits - cost more than the rounds saved on cache-resident scenes (-3 % on the
+    // 6 k-triangle box against +12 % at 1 M triangles); with the shape fetch riding along with the other lanes' node fetch
+    // they pay everywhere: 6 k triangles +3 %, with the spheres +5 %, 60 k +7 %, 200 k +8 %.  HJ_PAIR_LEAVES = 0 / 1 forces;
+    // default: trees of >= HJ_PAIR_MIN_NODES records (0: all).
     const int pair_env = env_int("HJ_PAIR_LEAVES", -1, -1, 1);
-    if (pair_env == 1 || (pair_env < 0 && N >= (size_t)env_int("HJ_PAIR_MIN_NODES", 300000, 0, 1 << 30))) {
+    if (pair_env == 1 || (pair_env < 0 && N >= (size_t)env_int("HJ_PAIR_MIN_NODES", 0, 0, 1 << 30))) {
       const size_t first_tri = s->num_spheres + s->num_quads;
       for (size_t i = 0; i + 2 < N; i++) {
         if (s->bvh[i].shape_index != HJ_BVH_INNER) continue;
@@ -804,12 +807,19 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     }
     HJ_UP(upload(ctx, pairs.data(), pairs.size(), &d.tri_pair));
     d.has_pairs = pairs.empty() ? 0u : 1u;
+    // Large trees (their nodes and triangles do not fit the caches): the path-state streams bypass the caches so that they
+    // do not evict scene data (1 M triangles +4.4 %; cache-resident scenes lose 0.5 ... 3 % with it).  HJ_STREAM_STATE = 0 / 1 forces.
+    {
+      const int nt_env = env_int("HJ_STREAM_STATE", -1, -1, 1);
+      d.stream_state = (nt_env == 1 || (nt_env < 0 && N >= (size_t)env_int("HJ_STREAM_MIN_NODES", 300000, 0, 1 << 30))) ? 1u : 0u;
+    }
     d.num_nodes = (uint32_t)M_all;
     d.root = N ? map[0] : 0u;
     d.num_hot = hot;
-    // box steps per round of the walk loop before the leaf tests run: 4 on plain trees (6: -0.4 %, 8: -4 % on cbox), 8 with
-    // pair nodes, whose leaf phases are twice as long (1 M triangles: 6 .. 12 all +4.5 % over 4)
-    d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", pairs.empty() ? 4 : 8, 1, 1 << 20);   // >= 1, or the walk would never advance
+    // steps per round of the walk loop (the first one is the merged step that also runs the leaf tests): without pair nodes 4
+    // (6: -0.4 %, 8: -4 % on cbox); with them 5 on small trees (6 k triangles: 6 -1 %, 7 -3 %) and 8 on larger ones (60 k
+    // triangles +1 % over 6; 1 M: 6 .. 8 the same, 10 -1 %)
+    d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", pairs.empty() ? 4 : (M < 50000 ? 5 : 8), 1, 1 << 20);   // >= 1, or the walk would never advance
     d.refill_min = (uint32_t)env_int("HJ_REFILL_MIN", (int)hj::kRefillMin, 1, 64);
     // The walk adds 32 * index to the low word of the array's address without a carry (kernels/hj_kernels.h): the
     // array must not cross a 4 GiB boundary.  Allocate twice the size and start at the boundary if it would.

@@ -60,6 +60,7 @@ struct DeviceScene {
   uint32_t ns, nq, nt, num_emitters;
   uint32_t has_extinction;      // any dielectric with non-zero extinction
   uint32_t has_pairs;           // the node array holds pair nodes (tri_pair)
+  uint32_t stream_state;        // large tree: path records and samples bypass the caches (non-temporal accesses)
   hj_camera camera;
   float tan_half_fov;           // (float)tan(radians(fov/2)) evaluated in double on the host
 };

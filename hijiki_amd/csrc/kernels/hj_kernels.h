@@ -58,10 +58,7 @@ HJ_DEV uint32_t lds_fetch_chunk(uint32_t* lds_head) {
 
 // Path-state accessors.  NT marks them non-temporal (streaming) so that the record and sample streams do not displace
 // scene data (nodes, triangles) from the caches: measured +4.4 % on the 1 M-triangle scene and -0.5 % / -3 % on the two
-// cbox scenes, whose trees stay cache-resident either way - so the fused kernel sets it together with PAIRS (large trees).
-#ifndef HJ_NT_LARGE
-#define HJ_NT_LARGE 1
-#endif
+// cbox scenes, whose trees stay cache-resident either way - so hj_scene_upload sets it for large trees (DeviceScene::stream_state).
 typedef float f4s __attribute__((ext_vector_type(4)));
 template <bool NT>
 HJ_DEV float4 ldp(const float4* p, uint32_t i) {
@@ -432,8 +429,20 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     if (!MERGE) at_leaf = false;
     uint32_t burst = sc.inner_burst;       // lanes standing on a leaf wait at most this many box steps of the others
     if (MERGE) {
+#ifdef HJ_WALK_STATS
+      // the merged step: its node lanes count as a box step, its leaf lanes as a leaf phase; its wave cycles go to [12]
+      { const unsigned long long mn = __ballot(active && !at_leaf && cur < nn), mc = __ballot(active && !at_leaf && cur < nn && cur >= nhot);
+        const unsigned long long ml = __ballot(active && at_leaf), mp = __ballot(active && at_leaf && (shape & kInnerFlag) != 0u);
+        if (lane == 0) {
+          if (mn) { ws[1] += 1; ws[2] += __popcll(mn); ws[14] += __popcll(mc); }
+          if (ml) { ws[3] += 1; ws[4] += __popcll(ml); ws[15] += __popcll(ml) + __popcll(mp); }
+        } }
+#endif
       step0_issue(); step0_compute();
       burst--;
+#ifdef HJ_WALK_STATS
+      HJ_STAT(12, clock64() - t_b);
+#endif
     }
     while (active && cur < nn && !at_leaf && burst != 0) {
       // hot node: LDS copy, same 32-byte record layout as in HBM, so that ONE address select feeds both 16-byte
@@ -456,15 +465,15 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     if (active && !at_leaf && cur >= nn) { active = false; pending = true; }   // walked off the end of the tree
 #ifdef HJ_WALK_STATS
     const unsigned long long t_c = clock64();
-    HJ_STAT(11, t_c - t_b);
-    { const unsigned long long m = __ballot(at_leaf), mp = __ballot(at_leaf && (shape & kInnerFlag) != 0u);   // [15] shape records fetched (a pair: two)
+    HJ_STAT(11, t_c - t_b);      // (MERGE: includes the merged step, also counted in [12])
+    if (!MERGE) { const unsigned long long m = __ballot(at_leaf), mp = __ballot(at_leaf && (shape & kInnerFlag) != 0u);   // [15] shape records fetched (a pair: two)
       if (m && lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[3] += 1; ws[4] += __popcll(m); ws[15] += __popcll(m) + __popcll(mp); } }
 #endif
     if (!MERGE && at_leaf) {
       if (leaf_test<PAIRS>(sc, r, shape, h, MODE == 1 || (MODE == 2 && any))) { active = false; pending = true; }   // occluded shadow ray (h.id >= 0 tells finish)
       cur = ex;
     }
-    HJ_STAT(12, clock64() - t_c);
+    if (!MERGE) HJ_STAT(12, clock64() - t_c);
   }
 #ifdef HJ_WALK_STATS
   HJ_STAT(13, clock64() - t_begin);
@@ -1064,10 +1073,10 @@ __device__ __attribute__((noinline)) void compact_hits_call(uint32_t ka_lo, uint
 #ifndef HJ_PATH_WAVES
 #define HJ_PATH_WAVES 7   // 72 VGPRs; measured on the compacted-record kernel: 6 waves (80 VGPRs) -6 %, 8 waves (64 VGPRs) -2 %, 5 waves -5 %
 #endif
-template <bool USE_BVH, bool PAIRS>
+template <bool USE_BVH, bool PAIRS, bool NT>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(HJ_PATH_WAVES, 8))) void k_path_wavefront(BatchState st, DeviceScene sc, uint32_t max_bounces,
                                                                   uint32_t rr_start) {
-  constexpr bool NT = PAIRS && HJ_NT_LARGE != 0;   // large trees: stream the path state past the caches (ldp / stp)
+  // NT (large trees): the path state is streamed past the caches (ldp / stp)
   __shared__ WgShared sh;
   const uint32_t g = blockIdx.x;
 #if HJ_SHADE_CALL
@@ -1130,9 +1139,9 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
       const unsigned long long st_t1 = wall_clock64();
 #endif
 #if HJ_SHADE_CALL >= 2
-      compact_hits_call<NT, PAIRS ? 1u : 4u>(ka_lo, ka_hi, g, n, sh_lds, waves);
+      compact_hits_call<NT, 4u>(ka_lo, ka_hi, g, n, sh_lds, waves);
 #else
-      compact_hits_by_tag<NT, PAIRS ? 1u : 4u>(st, sc, g, n, sh, waves);
+      compact_hits_by_tag<NT, 4u>(st, sc, g, n, sh, waves);
 #endif
       wg_sync(waves);
 #ifdef HJ_WALK_STATS

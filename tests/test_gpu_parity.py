@@ -777,11 +777,13 @@ def test_torch_rccl_reduce_of_the_external_framebuffer(tmp_path):
     assert p.returncode == 0 and "rccl-ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-def test_pair_nodes_forced_on_small_scenes(gpu_renderer, oracle, cbox, cbox_spheres):
-    """Pair nodes (an inner node over two triangle leaves tested in one stop of the walk) are switched on by tree size;
-    forced on here for the small scenes: frames, raw hits and any-hit results stay bit-identical to the oracle's."""
+@pytest.mark.parametrize("pairs", ["1", "0"])
+def test_pair_nodes_forced_on_and_off(gpu_renderer, oracle, cbox, cbox_spheres, pairs):
+    """Pair nodes (an inner node over two triangle leaves tested in one stop of the walk) are the default; forced on and
+    forced off (plain leaves: the other instantiation of the walk) here: frames, raw hits and any-hit results stay
+    bit-identical to the oracle's either way."""
     old = os.environ.get("HJ_PAIR_LEAVES")
-    os.environ["HJ_PAIR_LEAVES"] = "1"
+    os.environ["HJ_PAIR_LEAVES"] = pairs
     try:
         for cs, name in ((cbox, "cbox"), (cbox_spheres, "spheres")):
             W, H = 192, 128
