@@ -71,8 +71,8 @@ def implemented_bytes(st):
     b += Hh * (4 * 16)             # shade: hit, ray_o, ray_d, thr
     b += A * (3 * 16)              # shade: record of the continuing path (ray_o, ray_d, thr)
     b += S * (3 * 16)              # shade: shadow record (origin, direction + tMax, contribution + sample)
-    b += S * (2 * 16)              # walk: fetch shadow origin, direction
-    b += U * (16 + 2 * 16)         # unoccluded: contribution + read-modify-write of the sample
+    b += S * (3 * 16)              # walk: fetch shadow origin, direction, contribution + sample index (carried in registers)
+    b += U * (2 * 16)              # unoccluded: read-modify-write of the sample
     b += first_hits * 16           # first-hit normal + depth
     b += P * (2 * 16 * (20 * 20) / (16 * 16))   # reconstruction: both sample layers, 20x20 staged per 16x16 tile
     return b
@@ -83,7 +83,7 @@ def coalesced_read_bytes(st):
     rocprofv3's FETCH_SIZE counts these at half their size on gfx950 (MI355X_MICROARCH.md, section HBM), while it counts
     the 64-byte sectors of 16/32/48-byte gathers exactly (profiles/r02_fetch_size_calibration.txt)."""
     P, C, S, Hh = st["paths"], st["closest_rays"], st["shadow_rays"], st["hits"]
-    return C * (2 * 16) + C * (2 * 16) + Hh * (4 * 16) + S * (2 * 16) + P * (2 * 16 * (20 * 20) / (16 * 16))
+    return C * (2 * 16) + C * (2 * 16) + Hh * (4 * 16) + S * (3 * 16) + P * (2 * 16 * (20 * 20) / (16 * 16))
 
 
 def roofline_inputs(config):
