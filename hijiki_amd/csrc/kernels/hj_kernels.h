@@ -314,6 +314,9 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     asm volatile("v_mov_b32 %0, %1" : "=v"(nb_lhi) : "s"((uint32_t)(lb >> 32)));
   }
   RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
+#if defined(HJ_VALU_PROBE) || defined(HJ_LOAD_PROBE)
+  float valu_probe = 1.0f;
+#endif
   uint32_t shape = 0, ex = 0;
   bool at_leaf = false;                  // (MERGE: a leaf reached in one round is tested in the first step of the next)
 #ifdef HJ_WALK_STATS
@@ -459,8 +462,21 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
       const uint32_t a_lo = (hot ? nb_llo : nb_glo) + (cur << 5), a_hi = hot ? nb_lhi : nb_ghi;
       const float4* __restrict__ nd = reinterpret_cast<const float4*>(((uint64_t)a_hi << 32) | (uint64_t)a_lo);
       const float4 n0 = nd[0], n1 = nd[1];
+#ifdef HJ_LOAD_PROBE   // diagnostic: one more 16-byte load per box step; 1: every lane the same address, 2: the lane's own node again, 3: a global (never LDS) address per lane
+      {
+        const float4* pp = HJ_LOAD_PROBE == 1 ? sc.nodes : HJ_LOAD_PROBE == 2 ? nd : sc.nodes + 2 * cur;
+        float4 pv;
+        asm volatile("flat_load_dwordx4 %0, %1" : "=v"(pv) : "v"(pp) : "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        valu_probe += pv.x * 0.0f;
+      }
+#endif
       at_leaf = node_step<PAIRS>(n0, n1, inv, off, r, cur, shape, ex);
       burst--;
+#ifdef HJ_VALU_PROBE   // diagnostic: HJ_VALU_PROBE extra VALU instructions per box step (is the walk VALU-bound?)
+#pragma unroll
+      for (int k_ = 0; k_ < HJ_VALU_PROBE; k_++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(valu_probe));
+#endif
     }
     if (active && !at_leaf && cur >= nn) { active = false; pending = true; }   // walked off the end of the tree
 #ifdef HJ_WALK_STATS
@@ -1022,6 +1038,8 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
 #endif
 typedef __attribute__((address_space(3))) WgShared* WgSharedLds;
 constexpr size_t kSceneArgOffset = (sizeof(BatchState) + alignof(DeviceScene) - 1) / alignof(DeviceScene) * alignof(DeviceScene);
+struct KernelArgsHead { BatchState st; DeviceScene sc; };      // how the argument segment of those kernels starts
+static_assert(offsetof(KernelArgsHead, sc) == kSceneArgOffset, "DeviceScene's place in the kernel argument segment");
 template <bool NT>
 __device__ __attribute__((noinline)) void stage_shade_call(uint32_t ka_lo, uint32_t ka_hi, uint32_t g, uint32_t parity, uint32_t max_bounces,
                                                             uint32_t rr_start, uint32_t sh_lds, uint32_t waves) {

@@ -109,3 +109,19 @@ def test_argument_checks_need_no_gpu():
     L.hj_comm_destroy(None)                                   # no-ops on NULL
     L.hj_set_progress_callback(None, device.PROGRESS_FN(), None, 1)
     assert (L.hj_version() >> 8) & 0xFF >= 2                  # ABI 0.2: statistics grew, async / comm / progress entry points
+
+
+def test_walk_of_the_fused_kernel_is_spill_free():
+    """The fused kernel's own code is the BVH walk (top-up, hit compaction and shade are called functions with their own
+    register allocation): no scratch (spill) instruction may sit between the barriers around the walk - one reload there
+    is a dependent memory trip per round of the walk loop.  tools/spill_scan.py compiles the device
+    code to gfx950 assembly and counts them."""
+    import re
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "spill_scan.py")], capture_output=True, text=True,
+                       env=dict(os.environ, TMPDIR="/tmp"), timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    walks = re.findall(r"scratch instructions inside the walk \(lines \d+ \.\. \d+, between the barriers around it\): (\d+)", r.stdout)
+    assert len(walks) == 4, r.stdout           # the four BVH instantiations (pair nodes x streamed path state)
+    assert all(int(n) == 0 for n in walks), r.stdout

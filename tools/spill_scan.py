@@ -23,8 +23,11 @@ for i0, line in enumerate(s):
     scratch = [(k, l.strip().split(";")[0].strip()) for k, l in enumerate(body) if "scratch_" in l]
     print(f"k_path_wavefront<USE_BVH={m.group(2)}, PAIRS={m.group(3)}, NT={m.group(4)}>: {len(body)} lines, {len(scratch)} scratch instructions")
     if fetch:
-        lo, hi = min(fetch) - 150, max(fetch) + 700
+        # the walk = everything between the workgroup barrier before the first node fetch and the one after the last
+        bars = [k for k, l in enumerate(body) if "s_barrier" in l]
+        lo = max([k for k in bars if k < min(fetch)], default=0)
+        hi = min([k for k in bars if k > max(fetch)], default=len(body))
         near = [x for x in scratch if lo <= x[0] <= hi]
-        print(f"  node fetch at line {fetch[0]}; scratch instructions in [{lo}, {hi}] (service phase, box steps, leaf phase): {len(near)}")
+        print(f"  node fetch at line {fetch[0]}; scratch instructions inside the walk (lines {lo} .. {hi}, between the barriers around it): {len(near)}")
         for k, l in near:
             print(f"    {k:6d}  {l}")
