@@ -117,9 +117,20 @@ def cpu_baseline(cs, width, height, total_spp, seed, label, budget_s=12.0):
     _, _, secs = hj_oracle.render_blocks(cs, host.make_blocks(width, height, 1, seed), width, height, nthreads=cores)
     rate1 = width * height / max(secs, 1e-9)
     spp = int(max(1, min(64, total_spp, budget_s * rate1 / (width * height))))
-    _, _, secs = hj_oracle.render_blocks(cs, host.make_blocks(width, height, spp, seed), width, height, nthreads=cores)
+    _, ctr, secs = hj_oracle.render_blocks(cs, host.make_blocks(width, height, spp, seed), width, height, nthreads=cores)
     return {"value": round(width * height * spp / secs / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{spp} of the {total_spp} passes of {label} {width}x{height} (oracle/hj_oracle.c, {cores} threads, {secs:.2f} s)"}
+            "sample": f"{spp} of the {total_spp} passes of {label} {width}x{height} (oracle/hj_oracle.c, {cores} threads, {secs:.2f} s)"}, ctr
+
+
+def reference_bytes_per_path(c):
+    """SURVEY.md 8(d)'s B_path: the bytes the REFERENCE algorithm touches per camera path (32 B per node visit, 108 B per
+    triangle test - indices + three vertices -, 16 / 48 B per sphere / quad test, closest-hit shadow walks, 128 B per hit
+    for populate + material, 144 B per next-event evaluation, 128 B of sample traffic), from the oracle's counters on the
+    same scene.  Informational: on cbox all of it is cache-resident, and the kernels here move other bytes."""
+    P = max(1, c["paths"])
+    walk = 32 * (c["nodes"] + c["shadow_nodes"]) + 108 * (c["tri_tests"] + c["shadow_tri_tests"]) \
+        + 16 * (c["sphere_tests"] + c["shadow_sphere_tests"]) + 48 * (c["quad_tests"] + c["shadow_quad_tests"])
+    return round((walk + 128 * c["hits"] + 144 * c["nee_evals"]) / P + 128, 1)
 
 
 def main_inproc(args, cfg):
@@ -250,8 +261,9 @@ def main():
             "config": {"workload": f"{args.config}: {label}, BVH, block 128, seed {args.seed}",
                        "partition": f"ImageBlock (bx, by) of pass p -> rank (bx + by + p) mod {world}, RCCL sum-reduce of the {W}x{H} RGBA32F framebuffer"},
         }
+        oracle_counters = None
         if not args.no_cpu_baseline and world == 1:        # the CPU baseline is a one-GPU-run item (rank 0, N = 1 only)
-            out["cpu_baseline"] = cpu_baseline(cs, W, H, spp, args.seed, cfg["short"])
+            out["cpu_baseline"], oracle_counters = cpu_baseline(cs, W, H, spp, args.seed, cfg["short"])
 
         # ---- roofline of the dominant kernel, from THIS run's device counters and HIP events (rank 0's launches)
         inputs, src = roofline_inputs(args.config) if standard and world == 1 else (None, None)
@@ -286,7 +298,7 @@ def main():
             "exclusive_ms_per_launch": round(excl_ms, 4),
             "overlapped_ms_per_launch": round(agg["path_ms"] / launches, 4),
             "achieved_wall": round(alg * world / elapsed / 1e9, 1),
-            "reference_algorithm_bytes_per_path": None if not inputs else inputs.get("reference_bytes_per_path"),
+            "reference_algorithm_bytes_per_path": None if oracle_counters is None else reference_bytes_per_path(oracle_counters),
             "limiter": None if not inputs else inputs.get("limiter"),
             "note": "bytes of the implemented algorithm (path/hit/shadow records and samples; scene data only where it "
                     "is not LDS/cache-resident) over the kernel's exclusive time; `limiter` names what the counters "
