@@ -14,8 +14,10 @@
 //                                                            roulette -> next ray queue + shadow queue
 //   k_recon_weights / k_reconstruct   reconstruction.glsl:22-66
 //
-// k_path_wavefront runs all stages of a batch in ONE persistent launch (workgroup barriers only);
-// k_gen_camera / k_trace_closest / k_shade / k_trace_shadow launch them one by one (diagnostic path).
+// k_path_wavefront runs all stages of a batch in ONE persistent launch (workgroup barriers only): the kernel's own code
+// is the walk (trace_persistent: in-wave ray replacement, merged first step, bounded burst), the other three stages are
+// CALLED device functions (stage_*_call: register-allocated on their own, so the walk stays free of spills);
+// k_gen_camera / k_trace_closest / k_shade / k_trace_shadow launch the stages one by one (diagnostic path).
 // No stage uses a global atomic: appends are wave ballot + one LDS atomic.
 //
 // Every path owns its RNG state, so queue order never changes results; the per-path order of radiance
