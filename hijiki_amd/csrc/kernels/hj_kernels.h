@@ -316,7 +316,7 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     asm volatile("v_mov_b32 %0, %1" : "=v"(nb_lhi) : "s"((uint32_t)(lb >> 32)));
   }
   RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
-#if defined(HJ_VALU_PROBE) || defined(HJ_LOAD_PROBE)
+#if defined(HJ_VALU_PROBE) || defined(HJ_LOAD_PROBE) || defined(HJ_LEAF_VALU_PROBE)
   float valu_probe = 1.0f;
 #endif
   uint32_t shape = 0, ex = 0;
@@ -378,6 +378,10 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
           else hit = triangle_test(r, x0, x1, x2, h);
           if (hit) { h.id = (int)shape; if (anyhit) done = true; else r.tmax = h.t - kEps; }
         }
+#ifdef HJ_LEAF_VALU_PROBE   // diagnostic: extra VALU instructions in the leaf branch of the merged step (a pair test has ~130)
+#pragma unroll
+        for (int k_ = 0; k_ < HJ_LEAF_VALU_PROBE; k_++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(valu_probe));
+#endif
         if (done) { active = false; pending = true; }   // occluded shadow ray (h.id >= 0 tells finish)
         cur = ex; at_leaf = false;
       } else {
