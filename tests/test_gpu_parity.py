@@ -848,3 +848,32 @@ def test_four_contexts_in_flight_on_one_gpu(cbox, monkeypatch):
     finally:
         for r in rs:
             r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [
+    {"HJ_INNER_BURST": "1"},                                        # a round of the walk loop = the merged step alone
+    {"HJ_INNER_BURST": "16", "HJ_REFILL_MIN": "1"},                 # long bursts, refill as soon as one lane is free
+    {"HJ_REFILL_MIN": "64", "HJ_POOL": "1024"},                     # refill only when the whole wave is idle, small pool
+    {"HJ_STREAM_STATE": "1", "HJ_NODE_ORDER": "0"},                 # streamed path state on a small tree, pre-order nodes
+    {"HJ_PAIR_LEAVES": "0", "HJ_STREAM_STATE": "1"},                # the plain-leaf instantiation with streamed state
+    {"HJ_COLLAPSE_PCT": "0", "HJ_NODE_ORDER": "1"},                 # no collapse, sibling groups
+    {"HJ_SLOTS": "1", "HJ_WG_PER_CU": "1", "batch_blocks": "1"},    # one batch slot, 256 workgroups, one ImageBlock per batch
+], ids=lambda e: ",".join(f"{k.replace('HJ_', '')}={v}" for k, v in e.items()))
+def test_tuning_switches_never_change_a_bit(oracle, cbox_spheres, monkeypatch, env):
+    """DESIGN.md section 4's tuning switches (read by the library at context creation / scene upload) steer scheduling
+    and layout only: at their extremes, too, the frame is the oracle's bit for bit (every walk instantiation: pair / plain
+    leaves x streamed / cached path state)."""
+    opts = device.default_opts()
+    for k, v in env.items():
+        if k == "batch_blocks":
+            opts.batch_blocks = int(v)             # (hj_render_opts, not an environment switch)
+        else:
+            monkeypatch.setenv(k, v)
+    W, H = 160, 96
+    blocks = host.make_blocks(W, H, 3, 31)
+    want, ctr, _ = oracle.render_blocks(cbox_spheres, blocks, W, H)
+    with device.Renderer(0) as r:                  # a context of its own: some switches are read when it is created
+        got, st = render(r, cbox_spheres, W, H, blocks, opts)
+    assert_same(got, want, f"switches {env}")
+    assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"]
