@@ -1159,8 +1159,10 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
 #endif
       stage_trace_merged<USE_BVH, PAIRS, NT>(st, sc, g, parity, n, ns, sh);
 #ifdef HJ_WALK_STATS
+      const unsigned long long st_tw = wall_clock64();       // this wave has no ray left
       wg_sync(waves);                        // (diagnostic build only: the walk ends for all waves before the compaction is timed)
       const unsigned long long st_t1 = wall_clock64();
+      if ((threadIdx.x & 63u) == 0) atomicAdd(&g_round_stats[29], st_t1 - st_tw);   // [29] wave time spent waiting for the workgroup's slowest wave
 #endif
 #if HJ_SHADE_CALL >= 2
       compact_hits_call<NT, 4u>(ka_lo, ka_hi, g, n, sh_lds, waves);

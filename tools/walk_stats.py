@@ -51,6 +51,7 @@ for b in range(8):
 stage = rs[24:29]
 stage_tot = sum(stage) or 1
 names = ("top-up (camera rays)", "walk", "hit compaction", "shade", "round bookkeeping")
+print(f"waves waiting at the barrier that ends the walk: {100*rs[29]/max(1,rs[25]):.1f} % of the walk's wave time")
 print("wall time of the workgroups by stage: " + ", ".join(f"{n} {100*v/stage_tot:.1f} %" for n, v in zip(names, stage)))
 if js:
     json.dump({"kind": kind, "size": size, "spp": spp, "rays": rays, "paths": st["paths"],
