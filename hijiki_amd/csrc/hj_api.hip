@@ -1566,6 +1566,7 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
       std::vector<uint32_t>& cexit;
       std::vector<uint32_t> ids;
       size_t task_items = 0;                  // subtrees of at most this many items are set aside as tasks (0: never)
+      int child_order = 3;                    // HJ_BVH_CHILD_ORDER (0: as split)
       std::vector<Task> tasks;
       static float area(const float* lo, const float* hi) {
         const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
@@ -1646,6 +1647,16 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
           mid = (size_t)(std::stable_partition(ids.begin() + (std::ptrdiff_t)a, ids.begin() + (std::ptrdiff_t)b, left_of) - ids.begin());
           if (mid == a || mid == b) mid = a + (b - a) / 2;
         }
+        {
+          // the side with fewer shapes first (host/scene.cpp order_children: what the first child's walk finds culls the second)
+          float wl = 0.f, wr = 0.f;
+          for (size_t i = a; i < mid; i++) wl += items[ids[i]].weight;
+          for (size_t i = mid; i < b; i++) wr += items[ids[i]].weight;
+          if (wr < wl && child_order != 0) {
+            std::rotate(ids.begin() + (std::ptrdiff_t)a, ids.begin() + (std::ptrdiff_t)mid, ids.begin() + (std::ptrdiff_t)b);
+            mid = a + (b - mid);
+          }
+        }
         hj_bvh_node nd;
         for (int k = 0; k < 3; k++) { nd.aabb_min[k] = lo[k]; nd.aabb_max[k] = hi[k]; }
         nd.shape_index = HJ_BVH_INNER; nd.exit_index = exit;
@@ -1654,7 +1665,7 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
         emit(out, a, mid, pos + 1, right_pos, depth + 1, defer);        // exit of a left child = its sibling
         emit(out, mid, b, right_pos, exit, depth + 1, defer);           // a right child inherits its parent's exit
       }
-    } builder{items, cbase, cexit, {}, 0, {}};
+    } builder{items, cbase, cexit, {}, 0, env_int("HJ_BVH_CHILD_ORDER", 3, 0, 9), {}};
     builder.ids.resize(items.size());
     for (size_t k = 0; k < items.size(); k++) builder.ids[k] = (uint32_t)k;
     // The top levels here, the subtrees below them on worker threads (disjoint ranges of ids[], disjoint records, disjoint
@@ -1686,7 +1697,7 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
   HJ_HIP(ctx, hipMemcpyAsync(const_cast<uint32_t*>(cl.exit), cexit.data(), sizeof(uint32_t) * K, hipMemcpyHostToDevice, st));
   if (sah_clusters)
     hipLaunchKernelGGL(hj::lbvh::k_emit_clusters_sah, dim3((K + hj::lbvh::kSahThreads - 1) / hj::lbvh::kSahThreads),
-                       dim3(hj::lbvh::kSahThreads), 0, st, t, K, cl, idx_mask, d_out);
+                       dim3(hj::lbvh::kSahThreads), 0, st, t, K, cl, idx_mask, d_out, env_int("HJ_BVH_CHILD_ORDER", 3, 0, 9));
   else
     hipLaunchKernelGGL(hj::lbvh::k_emit_clusters, grid_sub, blk, 0, st, t, m, cl, idx_mask, d_out);
   HJ_HIP(ctx, hipGetLastError());

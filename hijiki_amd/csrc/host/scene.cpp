@@ -208,10 +208,32 @@ struct Builder {
 
 }  // namespace
 
+namespace {
+// Which child comes first matters to a fixed-order (skip-link) walk: a hit found in the first child shrinks tMax and
+// culls the second one's box (t0 < tMax), never the other way round.  The SAH split does not depend on the order, so
+// this is a pass over the finished tree that swaps children: the child with FEWER SHAPES first (equal counts: the smaller
+// box) - it is the cheaper one to walk and about as likely to hold the nearest hit, and what it finds spares the walk
+// the expensive one; a leaf (always tested once its parent is entered) so comes before a subtree.  Closest-hit node
+// visits per ray with the reference walk (oracle counters): cbox 21.8 -> 21.1, with the two spheres 23.5 -> 21.6,
+// 100 k-triangle mesh 54.9 -> 50.5.  Shadow rays do not care (any-hit; unoccluded ones visit the same boxes in any order).
+// HJ_BVH_CHILD_ORDER: 0 as split (lower coordinates first), 1 larger box first, 2 smaller box first, 3 (default) fewer shapes first.
+size_t order_children(std::vector<BuildNode>& nodes, int32_t nd, int mode) {
+  BuildNode& b = nodes[nd];
+  if (b.shape >= 0) return 1;
+  const size_t nl = order_children(nodes, b.left, mode), nr = order_children(nodes, b.right, mode);
+  const float al = b.left_box.half_area(), ar = b.right_box.half_area();
+  const bool swap = mode == 1 ? ar > al : mode == 2 ? ar < al : (nr < nl || (nr == nl && ar < al));
+  if (swap) { std::swap(b.left, b.right); std::swap(b.left_box, b.right_box); }
+  return nl + nr;
+}
+}  // namespace
+
 std::vector<BuildNode> build_bvh(const std::vector<Aabb>& boxes) {
   if (boxes.empty()) return {};
   Builder b(boxes);
   b.build(0, boxes.size());
+  static const int child_order = [] { const char* e = std::getenv("HJ_BVH_CHILD_ORDER"); return e ? std::atoi(e) : 3; }();
+  if (child_order != 0) order_children(b.nodes, 0, child_order);
   return std::move(b.nodes);
 }
 

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_emit_clusters(Tree t, uint32_t n, Clust
 constexpr uint32_t kClusterMax = 64;
 constexpr uint32_t kSahThreads = 16;                               // clusters per workgroup: 25 KB of LDS, many small groups
 __global__ __launch_bounds__(kSahThreads) void k_emit_clusters_sah(Tree t, uint32_t K, Clusters c, unsigned long long idx_mask,
-                                                                   hj_bvh_node* out) {
+                                                                   hj_bvh_node* out, int child_order) {
   // the cluster's leaf boxes, staged once ([.][leaf][thread]: a thread's walk over its leaves stays in its own banks), and
   // the order of the leaves, permuted in place by the splits
   __shared__ float s_box[6][kClusterMax][kSahThreads];
@@ -411,6 +411,15 @@ __global__ __launch_bounds__(kSahThreads) void k_emit_clusters_sah(Tree t, uint3
         if (q <= best_bin) { s_ids[i][tid] = s_ids[w][tid]; s_ids[w][tid] = (uint8_t)li; w++; }
       }
       if (w > r.lo && w < r.hi) mid = w;
+    }
+    if (child_order != 0 && r.hi - mid < mid - r.lo) {
+      // the side with fewer leaves first (host/scene.cpp order_children): swap the two blocks of the id list (three reversals)
+      auto reverse = [&](uint32_t a, uint32_t b) {
+        for (; a + 1 < b; a++, b--) { const uint8_t x = s_ids[a][tid]; s_ids[a][tid] = s_ids[b - 1][tid]; s_ids[b - 1][tid] = x; }
+      };
+      reverse(r.lo, r.hi); 
+      mid = r.lo + (r.hi - mid);
+      reverse(r.lo, mid); reverse(mid, r.hi);
     }
     const uint32_t left_pos = r.pos + 1, right_pos = left_pos + 2 * (mid - r.lo) - 1;
     stack[sp++] = Range{mid, r.hi, right_pos, r.exit};             // a right child inherits its parent's exit

@@ -15,9 +15,13 @@ ap.add_argument("--tris", type=int, default=0)
 ap.add_argument("--time-kernels", type=int, default=1)
 ap.add_argument("--split", type=int, default=0)
 ap.add_argument("--batch", type=int, default=0)
+ap.add_argument("--device-bvh", type=int, default=0, help="1: the tree of hj_build_bvh_device instead of the host's SAH tree")
 a = ap.parse_args()
 cs = host.Scene.synthetic(a.kind, mesh_triangles=a.tris).compile()
-r = device.Renderer(0); r.upload_scene(cs); r.create_framebuffer(a.size, a.size)
+r = device.Renderer(0)
+if a.device_bvh:
+    cs.set_bvh(r.build_bvh(cs))
+r.upload_scene(cs); r.create_framebuffer(a.size, a.size)
 o = device.default_opts(); o.batch_blocks = a.batch; o.flags = (abi.RENDER_TIME_KERNELS if a.time_kernels else 0) | (abi.RENDER_SPLIT_KERNELS if a.split else 0)
 for i in range(a.reps):
     r.clear(); t = time.time(); st = r.render_frame(a.spp, 1, opts=o); dt = time.time() - t
