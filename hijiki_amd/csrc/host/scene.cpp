@@ -220,11 +220,12 @@ namespace {
 // HJ_BVH_CHILD_ORDER: 0 as split (lower coordinates first), 1 larger box first, 2 smaller box first, 3 (default) fewer shapes first.
 // Tree rotations (Kensler 2008): the greedy top-down SAH leaves local improvements on the table - for a node with children
 // A and B, handing B down into A in exchange for one of A's children (or the other way round) changes only A's box; the
-// exchange that shrinks it most is applied, bottom-up, for a few passes.  HJ_BVH_ROTATE = passes (default 8, 0: off).
+// exchange that shrinks it most is applied, bottom-up, for a few passes; so is an exchange of two grandchildren across
+// (both children's boxes change).  HJ_BVH_ROTATE = passes (default 8, 0: off).
 // Node visits per ray of the reference walk (oracle counters, closest / shadow): cbox 21.1 / 18.8 -> 19.5 / 16.8, with the
-// spheres 21.6 / 17.5 -> 20.4 / 17.1, 100 k-triangle mesh 50.5 -> 43.6 (closest).  On the GPU the gain is smaller - lanes
+// spheres 21.6 / 17.5 -> 20.4 / 17.2, 100 k-triangle mesh 50.5 / 63.0 -> 42.7 / 56.2.  On the GPU the gain is smaller - lanes
 // per wave-step fall with the steps per ray (cbox 13.9 -> 13.1 lane-steps, 41.7 -> 38.8 lanes: the same wave-steps) -:
-// c3 +5 %, c4 +2 %, 60 k triangles +1 %, c2 the same.
+// c3 +5 %, c4 +2 %, 60 k triangles +2 %, c2 the same.
 struct Rotator {
   std::vector<BuildNode>& nodes;
   double gain = 0;
@@ -246,6 +247,29 @@ struct Rotator {
         const float delta = join(stays, other).half_area() - abox.half_area();
         if (delta < best) { best = delta; bo = o; bg = g; }
       }
+    }
+    // ... and the two exchanges of grandchildren across (left's g-th child with right's h-th child: both boxes change)
+    int xg = -1, xh = -1;
+    if (nodes[n.left].shape < 0 && nodes[n.right].shape < 0) {
+      BuildNode &a = nodes[n.left], &c = nodes[n.right];
+      for (int g = 0; g < 2; g++) {
+        const int h = 0;                                             // (g, 1) is (1 - g, 0) with the children's names swapped
+        const Aabb& a_up = g == 0 ? a.left_box : a.right_box;        // leaves a
+        const Aabb& a_stay = g == 0 ? a.right_box : a.left_box;
+        const Aabb& c_up = h == 0 ? c.left_box : c.right_box;        // leaves c
+        const Aabb& c_stay = h == 0 ? c.right_box : c.left_box;
+        const float delta = join(a_stay, c_up).half_area() + join(c_stay, a_up).half_area() - n.left_box.half_area() - n.right_box.half_area();
+        if (delta < best) { best = delta; bo = -1; xg = g; xh = h; }
+      }
+    }
+    if (xg >= 0) {
+      BuildNode &a = nodes[n.left], &c = nodes[n.right];
+      int32_t& ai = xg == 0 ? a.left : a.right;  Aabb& ab = xg == 0 ? a.left_box : a.right_box;
+      int32_t& ci = xh == 0 ? c.left : c.right;  Aabb& cb = xh == 0 ? c.left_box : c.right_box;
+      std::swap(ai, ci); std::swap(ab, cb);
+      n.left_box = join(a.left_box, a.right_box); n.right_box = join(c.left_box, c.right_box);
+      gain -= best;
+      return;
     }
     if (bo < 0) return;
     const int32_t open = bo == 0 ? n.left : n.right;
