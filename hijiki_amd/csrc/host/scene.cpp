@@ -135,7 +135,7 @@ struct Builder {
     float ext = cmax[0] - cmin[0];
     for (int a = 1; a < 3; a++)
       if (cmax[a] - cmin[a] > ext) ext = cmax[a] - cmin[a], axis = a;
-    if (hi - lo > 2) {
+    if (hi - lo > 2 && depth < 96) {   // (past that depth - adversarial size progressions - median splits bound the recursion)
       float best = INFINITY;
       int best_axis = -1, best_split = -1;
       for (int ax = 0; ax < 3; ax++) {
