@@ -267,14 +267,16 @@ HJ_DEV bool traverse(const DeviceScene& sc, Ray r, RawHit& h) {
 // Measured need: with one ray per lane for the lifetime of a wave, VALU instructions of the bounce-ray
 // traversal ran with 9.6 of 64 lanes active (rocprofv3 SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU).
 // Each ray still performs exactly the reference's pre-order skip-link walk (scene.glsl:97-133).
-//   fetch(i, slot, ray)   loads queue entry i
-//   finish(done, slot, h) wave-convergent: called when some lanes are done; `done` lanes have a final result
+//   fetch(i, slot, ray, any, h)  loads queue entry i (a shadow ray: any = true, its pending contribution in h, its sample in slot)
+//   finish(done, slot, h, any)   wave-convergent: called when some lanes are done; `done` lanes have a final result
+// A round of the loop: service phase (only when enough lanes are free) -> merged first step (leaf lanes fetch their shape
+// record, the others their node, in one trip) -> up to inner_burst - 1 plain box steps for the lanes not standing on a leaf.
 constexpr uint32_t kRefillMin = 32;   // sweep on the fused kernel: 16 -> 1.39, 32..48 -> 1.43 Gpaths/s, 64 -> 1.24
 
 #ifdef HJ_WALK_STATS
 // Diagnostic build only (tools/build_variant.sh stats -DHJ_WALK_STATS): wave-level occupancy of the walk's phases.
 // [0] outer iterations [1] inner wave-steps [2] lanes in them [3] leaf phases [4] lanes in them [5] refills
-// [6] lanes refilled [7] lanes active at the start of an outer iteration
+// [6] lanes refilled [7] lanes active at the start of an outer iteration; [29] of g_round_stats: wave time at the barrier behind the walk
 __device__ unsigned long long g_walk_stats[16];   // [10..12] wave cycles by phase, [13] total, [14] lane-steps on nodes outside the LDS copy
 // rounds of the fused kernel by size bucket b (rays of the round in [64 * 4^b / 4, 64 * 4^b), b = 0..7):
 // [b] rounds, [8 + b] rays, [16 + b] wave-cycles (wall clock of the round x waves of the workgroup still alive)
