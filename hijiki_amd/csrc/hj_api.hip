@@ -816,11 +816,14 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     d.num_nodes = (uint32_t)M_all;
     d.root = N ? map[0] : 0u;
     d.num_hot = hot;
-    // steps per round of the walk loop (the first one is the merged step that also runs the leaf tests): without pair nodes 4
-    // (6: -0.4 %, 8: -4 % on cbox); with them 5 on small trees (6 k triangles: 6 -1 %, 7 -3 %) and 8 on larger ones (60 k
-    // triangles +1 % over 6; 1 M: 6 .. 8 the same, 10 -1 %)
-    d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", pairs.empty() ? 4 : (M < 50000 ? 5 : 8), 1, 1 << 20);   // >= 1, or the walk would never advance
-    d.refill_min = (uint32_t)env_int("HJ_REFILL_MIN", (int)hj::kRefillMin, 1, 64);
+    // steps per round of the walk loop (the first one is the merged step that also runs the leaf tests) and free lanes at
+    // which a wave fetches new rays: without pair nodes 4 / 32 (6: -0.4 %, 8: -4 % on cbox); with them 7 / 24 on small trees
+    // (the rays of the rotated, child-ordered trees are shorter: 5 / 32, the optimum before those passes, is 3 % slower on
+    // cbox now; 6 or 8 steps, 20 or 28 lanes: -1 ... -2 %) and 8 / 32 on larger ones (1 M triangles: 6 .. 10 steps the same,
+    // 24 lanes -1 %)
+    const bool small_tree = M < 50000;
+    d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", pairs.empty() ? 4 : (small_tree ? 7 : 8), 1, 1 << 20);   // >= 1, or the walk would never advance
+    d.refill_min = (uint32_t)env_int("HJ_REFILL_MIN", !pairs.empty() && small_tree ? 24 : (int)hj::kRefillMin, 1, 64);
     // The walk adds 32 * index to the low word of the array's address without a carry (kernels/hj_kernels.h): the
     // array must not cross a 4 GiB boundary.  Allocate twice the size and start at the boundary if it would.
     {
