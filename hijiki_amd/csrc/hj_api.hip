@@ -819,11 +819,11 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     // steps per round of the walk loop (the first one is the merged step that also runs the leaf tests) and free lanes at
     // which a wave fetches new rays: without pair nodes 4 / 32 (6: -0.4 %, 8: -4 % on cbox); with them 7 / 24 on small trees
     // (the rays of the rotated, child-ordered trees are shorter: 5 / 32, the optimum before those passes, is 3 % slower on
-    // cbox now; 6 or 8 steps, 20 or 28 lanes: -1 ... -2 %) and 8 / 32 on larger ones (1 M triangles: 6 .. 10 steps the same,
-    // 24 lanes -1 %)
+    // cbox now; 6 or 8 steps, 20 or 28 lanes: -1 ... -2 %), 8 / 24 up to 600 000 records and 8 / 32 beyond (1 M triangles:
+    // 6 .. 10 steps the same, 24 lanes -1 %)
     const bool small_tree = M < 50000;
     d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", pairs.empty() ? 4 : (small_tree ? 7 : 8), 1, 1 << 20);   // >= 1, or the walk would never advance
-    d.refill_min = (uint32_t)env_int("HJ_REFILL_MIN", !pairs.empty() && small_tree ? 24 : (int)hj::kRefillMin, 1, 64);
+    d.refill_min = (uint32_t)env_int("HJ_REFILL_MIN", !pairs.empty() && M < 600000 ? 24 : (int)hj::kRefillMin, 1, 64);   // (20 k / 60 k / 200 k triangles: 24 lanes +2 / +3 / +1 %)
     // The walk adds 32 * index to the low word of the array's address without a carry (kernels/hj_kernels.h): the
     // array must not cross a 4 GiB boundary.  Allocate twice the size and start at the boundary if it would.
     {
