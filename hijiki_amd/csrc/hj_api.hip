@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -72,10 +73,12 @@ struct hj_context {
   struct BatchSlot {
     hj::BatchState st{};
     std::vector<DevBuf> bufs, sample_bufs;   // path-state arrays + queues; per-sample buffers
-    DevBuf d_blocks, d_wtab, d_tiles;
+    DevBuf d_blocks, d_tiles;
     uint32_t* h_tiles = nullptr;          // pinned staging of the per-tile block lists
     size_t h_tiles_cap = 0;
     hipStream_t stream = nullptr;
+    hipStream_t rstream = nullptr;        // the reconstruction's stream (high priority: see hj_context_create)
+    hipEvent_t ev_path = nullptr;         // this slot's path kernel has finished (the reconstruction stream waits for it)
     hj_image_block* h_blocks = nullptr;   // pinned staging of the block list
     uint32_t h_blocks_cap = 0;
     uint32_t* h_counts = nullptr;         // pinned read-back: 2 (split-path ray counts) + 4 (statistics) arrays of num_wg words
@@ -99,11 +102,21 @@ struct hj_context {
   uint32_t progress_interval = 128;
   uint64_t blocks_total = 0, blocks_done = 0, blocks_reported = 0;
 
-  // hj_render_frame_async: one worker thread per context runs the (blocking) render; hj_sync joins it
+  // hj_render_frame_async: ONE persistent worker thread per context (started by the first asynchronous frame) runs the
+  // blocking render; hj_sync waits for it.  `busy` is what every other entry point checks (HJ_ERR_STATE while a frame is
+  // in flight); the last frame's result stays retrievable (hj_sync) until the next asynchronous frame starts.
   std::thread worker;
-  bool async_pending = false;
+  std::mutex job_mu;
+  std::condition_variable job_cv;
+  struct AsyncJob { uint32_t spp, pass_begin, pass_end, rank, world; uint64_t master_seed; hj_render_opts opts; } job{};
+  bool job_posted = false, worker_exit = false;
+  std::atomic<bool> busy{false};
+  bool async_valid = false;               // async_rc / async_stats hold a finished frame's result
   int async_rc = HJ_OK;
   hj_render_stats async_stats{};
+
+  // hj_last_error: the worker thread writes `error` while the caller's thread may read it
+  std::mutex err_mu;
 };
 
 namespace {
@@ -120,10 +133,27 @@ int set_error(hj_context* ctx, int code, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  if (ctx) ctx->error = buf;
-  else g_create_error = buf;
+  if (ctx) {
+    std::lock_guard<std::mutex> lock(ctx->err_mu);
+    ctx->error = buf;
+  } else {
+    g_create_error = buf;
+  }
   return code;
 }
+
+std::string get_error(hj_context* ctx) {
+  std::lock_guard<std::mutex> lock(ctx->err_mu);
+  return ctx->error;
+}
+
+// Entry points that touch the context's device state refuse to run while an asynchronous frame is in flight on it
+// (the worker thread owns the slots, the streams and the framebuffer until hj_sync).
+#define HJ_NOT_BUSY(ctx)                                                                                          \
+  do {                                                                                                            \
+    if ((ctx)->busy.load(std::memory_order_acquire))                                                              \
+      return set_error(ctx, HJ_ERR_STATE, "%s: an asynchronous frame is in flight on this context: call hj_sync first", __func__); \
+  } while (0)
 
 #define HJ_HIP(ctx, call)                                                                         \
   do {                                                                                            \
@@ -248,7 +278,6 @@ int ensure_batch(hj_context* ctx, hj_context::BatchSlot& sl, uint32_t num_blocks
     HJ_ALLOC(sl.sample_bufs, smp_rgb, float4, (size_t)cap)
     HJ_ALLOC(sl.sample_bufs, smp_nd, float4, (size_t)cap)
     if (rc == HJ_OK) rc = dev_alloc(ctx, sl.d_blocks, sizeof(hj_image_block) * num_blocks);
-    if (rc == HJ_OK) rc = dev_alloc(ctx, sl.d_wtab, sizeof(float) * 25 * num_blocks);
     if (rc == HJ_OK && sl.h_blocks_cap < num_blocks) {
       if (sl.h_blocks) (void)hipHostFree(sl.h_blocks);
       sl.h_blocks = nullptr;
@@ -259,7 +288,7 @@ int ensure_batch(hj_context* ctx, hj_context::BatchSlot& sl, uint32_t num_blocks
     }
     if (rc == HJ_OK) st.capacity = cap;
   }
-  if (rc == HJ_OK && st.pool < pool) {
+  if (rc == HJ_OK && (st.pool < pool || (ctx->scene.has_extinction && !st.ext[0]))) {
     for (auto& b : sl.bufs) b.release();
     sl.bufs.clear();
     st.pool = 0;
@@ -268,7 +297,8 @@ int ensure_batch(hj_context* ctx, hj_context::BatchSlot& sl, uint32_t num_blocks
       HJ_ALLOC(sl.bufs, ray_o[par], float4, n)
       HJ_ALLOC(sl.bufs, ray_d[par], float4, n)
       HJ_ALLOC(sl.bufs, thr[par], float4, n)
-      HJ_ALLOC(sl.bufs, ext[par], float4, n)
+      if (ctx->scene.has_extinction) { HJ_ALLOC(sl.bufs, ext[par], float4, n) }   // (only tinted dielectrics read it)
+      else st.ext[par] = nullptr;
     }
     HJ_ALLOC(sl.bufs, hit, float4, n)
     HJ_ALLOC(sl.bufs, q_hit, uint32_t, n * hj::kNumTags)
@@ -318,7 +348,14 @@ struct Timer {
 // Reconstruction of one slot's batch, ordered after the previous batch's (framebuffer sums are defined by block order).
 int enqueue_reconstruct(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::BatchSlot& other, const hj::BatchState& st,
                         uint32_t nb, const hj_render_opts& o, Timer& tm) {
-  hipStream_t s = sl.stream;
+  // On its own stream of HIGH priority when there is one: behind the path kernel of its batch (ev_path) and behind the
+  // previous batch's reconstruction (ev_recon), but its few hundred short workgroups are dispatched ahead of the waiting
+  // workgroups of the other slots' persistent kernels, which otherwise take every wave slot that frees up.
+  hipStream_t s = sl.rstream ? sl.rstream : sl.stream;
+  if (sl.rstream) {
+    HJ_HIP(ctx, hipEventRecord(sl.ev_path, sl.stream));
+    HJ_HIP(ctx, hipStreamWaitEvent(s, sl.ev_path, 0));
+  }
   // Per 16x16 pixel tile, the blocks of this batch whose extended rectangle touches it, in list order (CSR).
   // Built here on the host, which is idle while the path kernel of this batch runs.
   const uint32_t tw = (ctx->width + 15) / 16, th = (ctx->height + 15) / 16, ntiles = tw * th;
@@ -370,25 +407,24 @@ int enqueue_reconstruct(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::
   HJ_HIP(ctx, hipMemcpyAsync(sl.d_tiles.p, sl.h_tiles, sizeof(uint32_t) * words, hipMemcpyHostToDevice, s));
   if (other.recon_recorded) HJ_HIP(ctx, hipStreamWaitEvent(s, other.ev_recon, 0));
   const int ev = tm.begin(EV_RECON, s);
-  hipLaunchKernelGGL(hj::k_recon_weights, dim3((nb * 25 + 255) / 256), dim3(256), 0, s, st.blocks, nb, o.recon_stddev,
-                     static_cast<float*>(sl.d_wtab.p));
   const uint32_t* d_off = static_cast<const uint32_t*>(sl.d_tiles.p);
-  hipLaunchKernelGGL(hj::k_reconstruct, dim3(tw, th), dim3(256), 0, s, st, static_cast<const float*>(sl.d_wtab.p), d_off,
+  hipLaunchKernelGGL(hj::k_reconstruct, dim3(tw, th), dim3(256), 0, s, st, o.recon_stddev, d_off,
                      d_off + ntiles + 1, ctx->accum, ctx->width, ctx->height);
   tm.end(ev, s);
   HJ_HIP(ctx, hipEventRecord(sl.ev_recon, s));
   sl.recon_recorded = true;
+  if (sl.rstream) HJ_HIP(ctx, hipStreamWaitEvent(sl.stream, sl.ev_recon, 0));   // the slot's batch ends with its reconstruction
   return HJ_OK;
 }
 
 // Wait for a slot's batch and fold its per-workgroup ray counters into the statistics.
-int harvest(hj_context* ctx, hj_context::BatchSlot& sl, hj_render_stats* stats) {
+int harvest(hj_context* ctx, hj_context::BatchSlot& sl, hj_render_stats* stats, bool count_progress = true) {
   if (!sl.pending) return HJ_OK;
   HJ_HIP(ctx, hipEventSynchronize(sl.ev_done));
   sl.pending = false;
-  ctx->blocks_done += sl.nb_in_flight;
+  if (count_progress) ctx->blocks_done += sl.nb_in_flight;   // (hj_debug_samples' batches are not part of a frame)
   sl.nb_in_flight = 0;
-  if (ctx->progress && ctx->blocks_done - ctx->blocks_reported >= ctx->progress_interval) {   // src/main.rs:1335-1340
+  if (count_progress && ctx->progress && ctx->blocks_done - ctx->blocks_reported >= ctx->progress_interval) {   // src/main.rs:1335-1340
     ctx->blocks_reported = ctx->blocks_done;
     ctx->progress(ctx->progress_user, ctx->blocks_done, std::max(ctx->blocks_total, ctx->blocks_done));
   }
@@ -525,6 +561,7 @@ int sync_all(hj_context* ctx) {
   HJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (auto& sl : ctx->slots) {
     HJ_HIP(ctx, hipStreamSynchronize(sl.stream));
+    if (sl.rstream) HJ_HIP(ctx, hipStreamSynchronize(sl.rstream));
     sl.pending = false;
     sl.recon_recorded = false;
   }
@@ -557,7 +594,14 @@ void hj_default_render_opts(hj_render_opts* o) {
   o->batch_blocks = 0;
 }
 
-const char* hj_last_error(const hj_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+// The text is copied into a buffer of the CALLING thread (valid until that thread's next hj_last_error call): the
+// context's own string may be rewritten by its worker thread at any time.
+const char* hj_last_error(const hj_context* ctx) {
+  if (!ctx) return g_create_error.c_str();
+  thread_local std::string copy;
+  copy = get_error(const_cast<hj_context*>(ctx));
+  return copy.c_str();
+}
 
 // Three batch streams + the context stream want their own hardware queues; the HIP runtime's default is 4 queues
 // for the whole process and streams that share one serialise (measured: frames 9 % slower when another HIP user
@@ -595,8 +639,15 @@ int hj_context_create(int device, hj_context** out) {
   for (auto& sl : ctx->slots) {
     if ((e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     if ((e = hipHostMalloc((void**)&sl.h_counts, sizeof(uint32_t) * 6 * ctx->num_wg, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
-    for (hipEvent_t* ev : {&sl.ev_count[0], &sl.ev_count[1], &sl.ev_recon, &sl.ev_done})
+    for (hipEvent_t* ev : {&sl.ev_count[0], &sl.ev_count[1], &sl.ev_recon, &sl.ev_done, &sl.ev_path})
       if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+  }
+  // HJ_RECON_PRIORITY (default 1): the reconstructions run on one stream per slot of the device's highest priority.
+  if (env_int("HJ_RECON_PRIORITY", 1, 0, 1) != 0) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+      for (auto& sl : ctx->slots)
+        if (hipStreamCreateWithPriority(&sl.rstream, hipStreamNonBlocking, greatest) != hipSuccess) sl.rstream = nullptr;
   }
   *out = ctx;
   return HJ_OK;
@@ -604,23 +655,32 @@ int hj_context_create(int device, hj_context** out) {
 
 void hj_context_destroy(hj_context* ctx) {
   if (!ctx) return;
-  if (ctx->worker.joinable()) ctx->worker.join();
+  if (ctx->worker.joinable()) {              // a frame still in flight finishes first (the worker drains its slots)
+    {
+      std::lock_guard<std::mutex> lock(ctx->job_mu);
+      ctx->worker_exit = true;
+    }
+    ctx->job_cv.notify_all();
+    ctx->worker.join();
+  }
   hj_drop_cached_comms(ctx);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  for (auto& sl : ctx->slots)
+  for (auto& sl : ctx->slots) {
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    if (sl.rstream) (void)hipStreamSynchronize(sl.rstream);
+  }
   release_scene(ctx);
   release_batch(ctx);
   for (auto& sl : ctx->slots) {
     sl.d_blocks.release();
-    sl.d_wtab.release();
     sl.d_tiles.release();
     if (sl.h_tiles) (void)hipHostFree(sl.h_tiles);
     if (sl.h_blocks) (void)hipHostFree(sl.h_blocks);
     if (sl.h_counts) (void)hipHostFree(sl.h_counts);
-    for (hipEvent_t ev : {sl.ev_count[0], sl.ev_count[1], sl.ev_recon, sl.ev_done})
+    for (hipEvent_t ev : {sl.ev_count[0], sl.ev_count[1], sl.ev_recon, sl.ev_done, sl.ev_path})
       if (ev) (void)hipEventDestroy(ev);
+    if (sl.rstream) (void)hipStreamDestroy(sl.rstream);
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
   }
   if (ctx->accum && ctx->accum_owned) (void)hipFree(ctx->accum);
@@ -634,6 +694,7 @@ void hj_context_destroy(hj_context* ctx) {
 
 int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
   if (!ctx) return HJ_ERR_INVALID;
+  HJ_NOT_BUSY(ctx);
   if (!s) return set_error(ctx, HJ_ERR_INVALID, "null scene");
   int rc = validate_scene(ctx, s);
   if (rc != HJ_OK) return rc;
@@ -899,6 +960,7 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
 
 int hj_framebuffer_create(hj_context* ctx, uint32_t width, uint32_t height, void* external) {
   if (!ctx) return HJ_ERR_INVALID;
+  HJ_NOT_BUSY(ctx);
   if (width == 0 || height == 0 || width > 65536 || height > 65536) return set_error(ctx, HJ_ERR_INVALID, "bad framebuffer size %ux%u", width, height);
   HJ_HIP(ctx, hipSetDevice(ctx->device));
   {
@@ -925,6 +987,7 @@ int hj_framebuffer_create(hj_context* ctx, uint32_t width, uint32_t height, void
 
 int hj_framebuffer_clear(hj_context* ctx) {
   if (!ctx) return HJ_ERR_INVALID;
+  HJ_NOT_BUSY(ctx);
   if (!ctx->accum) return set_error(ctx, HJ_ERR_STATE, "no framebuffer");
   HJ_HIP(ctx, hipSetDevice(ctx->device));
   HJ_HIP(ctx, hipMemsetAsync(ctx->accum, 0, (size_t)ctx->width * ctx->height * sizeof(float4), ctx->stream));
@@ -936,6 +999,7 @@ void* hj_framebuffer_device_ptr(hj_context* ctx) { return ctx ? ctx->accum : nul
 
 int hj_framebuffer_read(hj_context* ctx, float* host_rgba) {
   if (!ctx) return HJ_ERR_INVALID;
+  HJ_NOT_BUSY(ctx);
   if (!ctx->accum) return set_error(ctx, HJ_ERR_STATE, "no framebuffer");
   if (!host_rgba) return set_error(ctx, HJ_ERR_INVALID, "null destination");
   HJ_HIP(ctx, hipSetDevice(ctx->device));
@@ -1004,6 +1068,29 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
   run.batch = run.o.batch_blocks ? run.o.batch_blocks
                                  : (uint32_t)std::min<size_t>(batch_cap, std::max<size_t>(256, ((n + 3) / 4 + 63) / 64 * 64));
   run.batch = std::min<uint32_t>(run.batch, run.split ? 2048u : 8192u);   // the split path keeps every sample of a batch in flight
+  // Footprint: per batch slot 512 KB of samples per ImageBlock of the batch + num_wg x pool positions of
+  // path state (164 B each, 196 B with tinted dielectrics): 4 + 2.75 GB per slot at the defaults, three slots.  A DEFAULT
+  // batch that does not fit the device's free memory (other contexts on the GPU, the host application) is halved until
+  // it does; an explicit hj_render_opts::batch_blocks is taken as given and fails with HJ_ERR_NOMEM if it does not fit.
+  if (!run.o.batch_blocks && !run.split) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      size_t held = 0;
+      for (auto& sl : ctx->slots) {
+        for (auto& b : sl.bufs) held += b.bytes;
+        for (auto& b : sl.sample_bufs) held += b.bytes;
+      }
+      const size_t slots_needed = std::min<size_t>(ctx->num_slots, (n + run.batch - 1) / std::max<uint32_t>(run.batch, 1u));
+      auto need = [&](uint32_t batch) {
+        const size_t per_wg = ((((size_t)batch * hj::kSlotsPerBlock + 63) / 64 + ctx->num_wg - 1) / ctx->num_wg) * 64;
+        const size_t pool = std::min<size_t>(per_wg, ctx->pool);
+        const size_t state = (size_t)ctx->num_wg * pool * (ctx->scene.has_extinction ? 196u + 20u : 164u + 20u);
+        return std::max<size_t>(1, slots_needed) * (state + (size_t)batch * hj::kSlotsPerBlock * 32u);
+      };
+      const size_t margin = (size_t)512 << 20;
+      while (run.batch > 64 && need(run.batch) > held + (free_b > margin ? free_b - margin : 0)) run.batch = std::max(64u, run.batch / 2 / 64 * 64);
+    }
+  }
   rc = sync_all(ctx);
   if (rc != HJ_OK) return rc;
   ctx->blocks_total = total_blocks;
@@ -1041,7 +1128,7 @@ int run_submit(hj_context* ctx, RenderRun& run, const hj_image_block* blocks, si
 
 // Drains the slots (also after an error, so that nothing of this run is still in flight) and closes the statistics.
 int run_end(hj_context* ctx, RenderRun& run, int rc) {
-  const std::string first_error = ctx->error;
+  const std::string first_error = get_error(ctx);
   for (auto& sl : ctx->slots) {
     const int rc2 = harvest(ctx, sl, run.st);
     if (rc == HJ_OK) rc = rc2;
@@ -1049,7 +1136,7 @@ int run_end(hj_context* ctx, RenderRun& run, int rc) {
   {  // ALWAYS: after an error, too, nothing of this run may still be writing to the (possibly caller-owned) framebuffer
     const int rc2 = sync_all(ctx);
     if (rc == HJ_OK) rc = rc2;
-    else ctx->error = first_error;          // keep the message of the error that ended the run
+    else set_error(ctx, rc, "%s", first_error.c_str());   // keep the message of the error that ended the run
   }
   if (rc == HJ_OK && ctx->progress && ctx->blocks_done != ctx->blocks_reported)
     ctx->progress(ctx->progress_user, ctx->blocks_done, std::max(ctx->blocks_total, ctx->blocks_done));
@@ -1101,6 +1188,7 @@ int run_end(hj_context* ctx, RenderRun& run, int rc) {
 int hj_render_blocks(hj_context* ctx, const hj_image_block* blocks, size_t n, const hj_render_opts* opts,
                      hj_render_stats* stats) {
   if (!ctx) return HJ_ERR_INVALID;
+  HJ_NOT_BUSY(ctx);
   if (n && !blocks) return set_error(ctx, HJ_ERR_INVALID, "null block list");
   RenderRun run;
   int rc = run_begin(ctx, run, opts, stats, n);
@@ -1109,9 +1197,19 @@ int hj_render_blocks(hj_context* ctx, const hj_image_block* blocks, size_t n, co
   return run_end(ctx, run, rc);
 }
 
+namespace {
+int render_frame_impl(hj_context* ctx, uint32_t spp, uint64_t master_seed, uint32_t pass_begin, uint32_t pass_end,
+                      uint32_t rank, uint32_t world, const hj_render_opts* opts, hj_render_stats* stats);
+}
 int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed, uint32_t pass_begin, uint32_t pass_end,
                     uint32_t rank, uint32_t world, const hj_render_opts* opts, hj_render_stats* stats) {
   if (!ctx) return HJ_ERR_INVALID;
+  HJ_NOT_BUSY(ctx);
+  return render_frame_impl(ctx, spp, master_seed, pass_begin, pass_end, rank, world, opts, stats);
+}
+namespace {
+int render_frame_impl(hj_context* ctx, uint32_t spp, uint64_t master_seed, uint32_t pass_begin, uint32_t pass_end,
+                      uint32_t rank, uint32_t world, const hj_render_opts* opts, hj_render_stats* stats) {
   if (!ctx->accum) return set_error(ctx, HJ_ERR_STATE, "render before hj_framebuffer_create");
   if (world == 0 || rank >= world) return set_error(ctx, HJ_ERR_INVALID, "bad rank %u / world %u", rank, world);
   if (pass_end > spp || pass_begin > pass_end) return set_error(ctx, HJ_ERR_INVALID, "bad pass range [%u,%u) of %u", pass_begin, pass_end, spp);
@@ -1142,34 +1240,68 @@ int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed, uint32_
   return run_end(ctx, run, rc);
 }
 
-// ---- asynchronous frame: the blocking hj_render_frame on a worker thread of the context, so that ONE host thread can
-// keep several GPUs (contexts) rendering at the same time and overlap one context's drain with work on the others.
+// The context's worker: sleeps until a frame is posted, renders it (blocking, on this thread), publishes the result.
+void worker_main(hj_context* ctx) {
+  for (;;) {
+    hj_context::AsyncJob j;
+    {
+      std::unique_lock<std::mutex> lock(ctx->job_mu);
+      ctx->job_cv.wait(lock, [&] { return ctx->job_posted || ctx->worker_exit; });
+      if (!ctx->job_posted) return;          // (exit is honoured only between frames)
+      j = ctx->job;
+      ctx->job_posted = false;
+    }
+    hj_render_stats st{};
+    const int rc = render_frame_impl(ctx, j.spp, j.master_seed, j.pass_begin, j.pass_end, j.rank, j.world, &j.opts, &st);
+    {
+      std::lock_guard<std::mutex> lock(ctx->job_mu);
+      ctx->async_rc = rc;
+      ctx->async_stats = st;
+      ctx->async_valid = true;
+      ctx->busy.store(false, std::memory_order_release);
+    }
+    ctx->job_cv.notify_all();
+  }
+}
+}  // namespace
+
+// ---- asynchronous frame: the blocking render on the context's worker thread, so that ONE host thread can keep several
+// GPUs (contexts) rendering at the same time and overlap one context's drain with work on the others.
 
 int hj_render_frame_async(hj_context* ctx, uint32_t spp, uint64_t master_seed, uint32_t pass_begin, uint32_t pass_end,
                           uint32_t rank, uint32_t world, const hj_render_opts* opts) {
   if (!ctx) return HJ_ERR_INVALID;
-  if (ctx->async_pending) return set_error(ctx, HJ_ERR_STATE, "a frame is already in flight on this context: call hj_sync first");
-  hj_render_opts o;
-  if (opts) o = *opts;
-  else hj_default_render_opts(&o);
-  ctx->async_pending = true;
-  ctx->async_rc = HJ_OK;
-  try {
-    ctx->worker = std::thread([=]() {
-      ctx->async_rc = hj_render_frame(ctx, spp, master_seed, pass_begin, pass_end, rank, world, &o, &ctx->async_stats);
-    });
-  } catch (const std::exception& e) {
-    ctx->async_pending = false;
-    return set_error(ctx, HJ_ERR_NOMEM, "could not start the render thread: %s", e.what());
+  HJ_NOT_BUSY(ctx);
+  hj_context::AsyncJob j{};
+  j.spp = spp; j.master_seed = master_seed; j.pass_begin = pass_begin; j.pass_end = pass_end; j.rank = rank; j.world = world;
+  if (opts) j.opts = *opts;
+  else hj_default_render_opts(&j.opts);
+  if (!ctx->worker.joinable()) {
+    try {
+      ctx->worker = std::thread(worker_main, ctx);
+    } catch (const std::exception& e) {
+      return set_error(ctx, HJ_ERR_NOMEM, "could not start the render thread: %s", e.what());
+    }
   }
+  {
+    std::lock_guard<std::mutex> lock(ctx->job_mu);
+    ctx->job = j;
+    ctx->job_posted = true;
+    ctx->async_valid = false;
+    ctx->busy.store(true, std::memory_order_release);
+  }
+  ctx->job_cv.notify_all();
   return HJ_OK;
 }
 
+// Waits for the frame in flight (if any) and returns its status and statistics; the result of the LAST asynchronous
+// frame stays available until the next one starts, so hj_sync after hj_comm_reduce_framebuffers (which joins every
+// frame itself) still yields the statistics.  With no asynchronous frame ever started: HJ_OK, *stats untouched.
 int hj_sync(hj_context* ctx, hj_render_stats* stats) {
   if (!ctx) return HJ_ERR_INVALID;
-  if (!ctx->async_pending) return HJ_OK;
-  if (ctx->worker.joinable()) ctx->worker.join();
-  ctx->async_pending = false;
+  std::unique_lock<std::mutex> lock(ctx->job_mu);
+  ctx->job_cv.wait(lock, [&] { return !ctx->busy.load(std::memory_order_acquire); });
+  if (!ctx->async_valid) return HJ_OK;
   if (stats) *stats = ctx->async_stats;
   return ctx->async_rc;                      // the worker's error text is in hj_last_error(ctx)
 }
@@ -1322,9 +1454,9 @@ int hj_comm_reduce_framebuffers(hj_comm* c, int root) {
   for (int i = 0; i < n; i++) {
     hj_context* x = c->ctxs[(size_t)i];
     const int rs = hj_sync(x, nullptr);
-    if (rs != HJ_OK) return set_error(r, rs, "context %d: render failed: %s", i, x->error.c_str());
+    if (rs != HJ_OK) return set_error(r, rs, "context %d: render failed: %s", i, get_error(x).c_str());
     if (hipSetDevice(x->device) != hipSuccess || sync_all(x) != HJ_OK)
-      return set_error(r, HJ_ERR_DEVICE, "context %d: stream synchronisation failed: %s", i, x->error.c_str());
+      return set_error(r, HJ_ERR_DEVICE, "context %d: stream synchronisation failed: %s", i, get_error(x).c_str());
   }
   if (n == 1 && c->comms.empty()) return HJ_OK;
   if (c->shared_gpu) {
@@ -1371,7 +1503,7 @@ int hj_reduce_framebuffers(hj_context* const* ctxs, int n, int root) {
   if (!c) {
     rc = hj_comm_create(ctxs, n, &c);
     if (rc != HJ_OK) {
-      if (ctxs[root] != ctxs[0]) ctxs[root]->error = ctxs[0]->error;
+      if (ctxs[root] != ctxs[0]) set_error(ctxs[root], rc, "%s", get_error(ctxs[0]).c_str());
       return rc;
     }
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
@@ -1398,6 +1530,7 @@ extern "C" {
 // the tree of Scene::compile (src/main.rs:199-231), built on the device (kernels/hj_lbvh.h).
 int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* out_nodes, size_t capacity, size_t* out_num_nodes) {
   if (!ctx) return HJ_ERR_INVALID;
+  HJ_NOT_BUSY(ctx);
   if (!s || !out_nodes) return set_error(ctx, HJ_ERR_INVALID, "null argument");
   const size_t n = s->num_spheres + s->num_quads + s->num_triangles;
   if (n < 2) return set_error(ctx, HJ_ERR_INVALID, "scene needs at least 2 shapes (reference panics: root would be a leaf, src/main.rs:230)");
@@ -1452,7 +1585,7 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
   hj_bvh_node* d_out = nullptr;
   HJ_DEVBUF(t.leaf_lo, float4, n);
   HJ_DEVBUF(t.leaf_hi, float4, n);
-  HJ_DEVBUF(t.bounds, int, 6);
+  HJ_DEVBUF(t.bounds, int, 12);
   HJ_DEVBUF(keys_in, unsigned long long, n);
   HJ_DEVBUF(t.keys, unsigned long long, n);
   HJ_DEVBUF(t.child, uint32_t, 2 * (n - 1));
@@ -1545,16 +1678,18 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
     // order-dependent decisions below (equal centroids) do not depend on the run
     std::sort(items.begin(), items.begin() + K, [](const Item& x, const Item& y) { return x.first < y.first; });
     if (nbig != 0) {   // boxes of the large shapes: the ones k_shape_boxes computed (src/shape.rs:13-20,46-54, src/main.rs:74-79)
-      std::vector<unsigned long long> big_keys(nbig);
-      HJ_HIP(ctx, hipMemcpy(big_keys.data(), t.keys + m, sizeof(unsigned long long) * nbig, hipMemcpyDeviceToHost));
+      // one gather kernel + one copy for all of them (they sort behind the small shapes: keys [m, n))
+      float4* d_big = nullptr;
+      HJ_DEVBUF(d_big, float4, 2 * (size_t)nbig);
+      hipLaunchKernelGGL(hj::lbvh::k_gather_big, dim3((nbig + 63u) / 64u), dim3(64), 0, st, t, m, nbig, idx_mask, d_big);
+      std::vector<float4> big(2 * (size_t)nbig);
+      HJ_HIP(ctx, hipMemcpyAsync(big.data(), d_big, sizeof(float4) * big.size(), hipMemcpyDeviceToHost, st));
+      HJ_HIP(ctx, hipStreamSynchronize(st));
       for (uint32_t k = 0; k < nbig; k++) {
-        const uint32_t shp = (uint32_t)(big_keys[k] & idx_mask);
-        float4 lo, hi;
-        HJ_HIP(ctx, hipMemcpy(&lo, t.leaf_lo + shp, sizeof(float4), hipMemcpyDeviceToHost));
-        HJ_HIP(ctx, hipMemcpy(&hi, t.leaf_hi + shp, sizeof(float4), hipMemcpyDeviceToHost));
+        const float4 lo = big[2 * (size_t)k], hi = big[2 * (size_t)k + 1];
         Item& it = items[K + k];
         it.lo[0] = lo.x; it.lo[1] = lo.y; it.lo[2] = lo.z; it.hi[0] = hi.x; it.hi[1] = hi.y; it.hi[2] = hi.z;
-        it.shape = shp; it.cluster = 0; it.records = 1; it.weight = 1.0f; it.first = 0;
+        it.shape = __builtin_bit_cast(uint32_t, lo.w); it.cluster = 0; it.records = 1; it.weight = 1.0f; it.first = 0;
       }
     }
   }
@@ -1716,6 +1851,7 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
 
 int hj_debug_trace(hj_context* ctx, const float* rays, size_t n, uint32_t use_bvh, uint32_t any_hit, float* hits) {
   if (!ctx) return HJ_ERR_INVALID;
+  HJ_NOT_BUSY(ctx);
   if (!ctx->have_scene) return set_error(ctx, HJ_ERR_STATE, "trace before hj_scene_upload");
   if (n == 0) return HJ_OK;
   if (!rays || !hits) return set_error(ctx, HJ_ERR_INVALID, "null argument");
@@ -1748,6 +1884,7 @@ int hj_debug_trace(hj_context* ctx, const float* rays, size_t n, uint32_t use_bv
 
 int hj_debug_samples(hj_context* ctx, const hj_image_block* block, const hj_render_opts* opts, float* samples) {
   if (!ctx) return HJ_ERR_INVALID;
+  HJ_NOT_BUSY(ctx);
   if (!ctx->have_scene) return set_error(ctx, HJ_ERR_STATE, "render before hj_scene_upload");
   if (!block || !samples) return set_error(ctx, HJ_ERR_INVALID, "null argument");
   if (block->dimension[0] == 0 || block->dimension[1] == 0 || block->dimension[0] > HJ_BLOCK_SIZE || block->dimension[1] > HJ_BLOCK_SIZE)
@@ -1765,7 +1902,7 @@ int hj_debug_samples(hj_context* ctx, const hj_image_block* block, const hj_rend
   hj_context::BatchSlot& sl = ctx->slots[0];
   rc = (o.flags & HJ_RENDER_SPLIT_KERNELS) ? render_batch_split(ctx, sl, ctx->slots[1], block, 1, o, tm, nullptr, /*reconstruct=*/false)
                                            : enqueue_batch_fused(ctx, sl, ctx->slots[1], block, 1, o, tm, nullptr, /*reconstruct=*/false);
-  if (rc == HJ_OK) rc = harvest(ctx, sl, nullptr);
+  if (rc == HJ_OK) rc = harvest(ctx, sl, nullptr, /*count_progress=*/false);
   if (rc != HJ_OK) return rc;
   std::vector<float4> rgb(hj::kSlotsPerBlock), nd(hj::kSlotsPerBlock);
   HJ_HIP(ctx, hipMemcpy(rgb.data(), sl.st.smp_rgb, sizeof(float4) * hj::kSlotsPerBlock, hipMemcpyDeviceToHost));

@@ -12,7 +12,7 @@
 //     stage_shade          scene.glsl:160-175, render.glsl:102-144, material.glsl
 //                                                            populate, emission, NEE sample, BSDF sample,
 //                                                            roulette -> next ray queue + shadow queue
-//   k_recon_weights / k_reconstruct   reconstruction.glsl:22-66
+//   k_reconstruct                     reconstruction.glsl:22-66
 //
 // k_path_wavefront runs all stages of a batch in ONE persistent launch (workgroup barriers only): the kernel's own code
 // is the walk (trace_persistent: in-wave ray replacement, merged first step, bounded burst), the other three stages are
@@ -1140,7 +1140,11 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
       const uint32_t n = n0 + uni(sh.n_gen), ns = uni(sh.n_shadow);
       if (n + ns == 0) {
         if (groups_left == 0) break;
-        continue;                            // every sample of the new groups lay outside its block: next groups
+        // every sample of the new groups lay outside its block: next groups.  The other parity's path count is the one the
+        // round before last left behind (only a round that reaches the reset below clears it): it must not be found again.
+        if (threadIdx.x == 0) sh.n_ray[parity ^ 1u] = 0;
+        wg_sync(waves);
+        continue;
       }
       // Tail of the workgroup: one wave can hold every ray of a round and the counts never grow again.
       if (waves > 1u && groups_left == 0 && n + ns <= HJ_TAIL1) {
@@ -1295,26 +1299,14 @@ __global__ __launch_bounds__(kBlockThreads) void k_debug_trace(DeviceScene sc, c
 
 // ------------------------------------------------------------ reconstruction
 
-// 25 Gaussian tap weights per block (uniform over the block because the
-// sub-pixel offset is per block): reconstruction.glsl:27-28,43-44.
-__global__ void k_recon_weights(const hj_image_block* blocks, uint32_t num_blocks, float stddev, float* wtab) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= num_blocks * 25u) return;
-  const uint32_t bi = i / 25u, t = i % 25u;
-  const int dx = (int)(t / 5u) - 2, dy = (int)(t % 5u) - 2;
-  const float g = -1.0f / ((2.0f * stddev) * stddev);
-  const float c0 = hj_exp(g * 4.0f);
-  const float sx = ((float)dx + blocks[bi].sample_offset[0]) - 0.5f;
-  const float sy = ((float)dy + blocks[bi].sample_offset[1]) - 0.5f;
-  wtab[i] = hj_exp(g * (sx * sx + sy * sy)) - c0;
-}
-
 // One thread per output pixel; gathers, IN BLOCK ORDER, what every block of
 // the batch splats onto it.  Per-pixel addition order == the reference's
 // serial per-block dispatch order (reconstruction.glsl:22-66, main.rs:1316-1355).
 // tile_off / tile_blk: for every 16x16 pixel tile the batch's blocks (ascending = list order) whose 2-pixel-extended
 // rectangle touches the tile, built on the host while the path kernel runs (CSR layout).
-__global__ __launch_bounds__(256) void k_reconstruct(BatchState st, const float* __restrict__ wtab,
+// The 25 Gaussian tap weights of a block (uniform over the block because the sub-pixel offset is per block:
+// reconstruction.glsl:27-28,43-44) are formed per (tile, block) in LDS by the first 25 threads.
+__global__ __launch_bounds__(256) void k_reconstruct(BatchState st, float stddev,
                                                      const uint32_t* __restrict__ tile_off,
                                                      const uint32_t* __restrict__ tile_blk,
                                                      float4* __restrict__ accum, uint32_t W, uint32_t H) {
@@ -1329,7 +1321,10 @@ __global__ __launch_bounds__(256) void k_reconstruct(BatchState st, const float*
   // the 25 taps of its 256 pixels read them there instead of 50 global fetches per pixel.
   constexpr int TS = 20;
   __shared__ float4 s_rgb[TS * TS], s_nd[TS * TS];
+  __shared__ float s_w[25];
   const int px = (int)(threadIdx.x & 15u), py = (int)(threadIdx.x >> 4);
+  const float gq = -1.0f / ((2.0f * stddev) * stddev);
+  const float c0 = hj_exp(gq * 4.0f);
   for (uint32_t idx = i0; idx < i1; idx++) {
     const uint32_t bi = tile_blk[idx];
     const hj_image_block b = st.blocks[bi];
@@ -1337,6 +1332,12 @@ __global__ __launch_bounds__(256) void k_reconstruct(BatchState st, const float*
     const uint32_t sbase = bi * kSlotsPerBlock;
     const int bx0 = tx0 - 2 - ox, by0 = ty0 - 2 - oy;        // block-local coordinates of LDS entry (0, 0)
     __syncthreads();                                          // previous block's taps are done with the LDS tile
+    if (threadIdx.x < 25u) {
+      const int dx = (int)(threadIdx.x / 5u) - 2, dy = (int)(threadIdx.x % 5u) - 2;
+      const float sx = ((float)dx + b.sample_offset[0]) - 0.5f;
+      const float sy = ((float)dy + b.sample_offset[1]) - 0.5f;
+      s_w[threadIdx.x] = hj_exp(gq * (sx * sx + sy * sy)) - c0;
+    }
     for (int e = (int)threadIdx.x; e < TS * TS; e += 256) {
       const int ex = bx0 + e % TS, ey = by0 + e / TS;
       if (ex >= 0 && ex < Dx && ey >= 0 && ey < Dy) {
@@ -1355,7 +1356,7 @@ __global__ __launch_bounds__(256) void k_reconstruct(BatchState st, const float*
       if (lx + dx < 0 || lx + dx >= Dx) continue;
       for (int dy = -2; dy <= 2; dy++) {
         if (ly + dy < 0 || ly + dy >= Dy) continue;
-        float w = wtab[bi * 25u + (uint32_t)((dx + 2) * 5 + (dy + 2))];
+        float w = s_w[(dx + 2) * 5 + (dy + 2)];
         if (w < 0.0f) continue;
         const int e = (py + 2 + dy) * TS + (px + 2 + dx);
         const float4 nd = s_nd[e];

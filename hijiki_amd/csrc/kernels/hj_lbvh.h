@@ -7,7 +7,7 @@
 // topology: shapes sorted along a Morton curve of their centroids (as many bits per axis as a 64-bit key leaves beside
 // the shape index: 14 for a million shapes), hierarchy by longest common prefix (Karras 2012, "Maximizing parallelism
 // in the construction of BVHs, octrees and k-d trees"), bounds by a bottom-up pass.  LARGE shapes (box area above
-// 1/64 of the scene's, e.g. the walls of the box around a mesh) are kept OUT of the Morton tree: sorted by centroid they
+// HJ_LBVH_BIG_PCT = 2 % of the area of the SCENE's box, e.g. the walls of the box around a mesh) are kept OUT of the Morton tree: sorted by centroid they
 // would sit deep inside it and blow the boxes of all their ancestors up to scene size; they go into a small SAH tree
 // that the host builds over them and over the CLUSTERS of the Morton tree (its subtrees of at most 64 leaves; hj_api.hip),
 // so that only the lowest levels keep the Morton splits.  The image does not depend on the
@@ -39,7 +39,8 @@ struct Shapes {               // the shape arrays of an hj_scene_desc, on the de
 struct Tree {                 // working arrays, n = number of shapes
   float4* leaf_lo;            // [n] bounds of shape i (global shape index), w unused
   float4* leaf_hi;
-  int* bounds;                // [6] scene bounds of the CENTROIDS as order-preserving ints (min xyz, max xyz)
+  int* bounds;                // [12] order-preserving ints: [0..5] bounds of the shapes' CENTROIDS (min xyz, max xyz: the Morton
+                              //      grid), [6..11] bounds of the shapes' BOXES (the scene's box: the large-shape threshold)
   unsigned long long* keys;   // [n] large-shape flag (bit 63) | morton << idx_bits | shape index
   uint32_t* child;            // [2 * (n - 1)] left, right of internal node i
   uint32_t* first;            // [n - 1] first sorted leaf of internal node i
@@ -56,8 +57,7 @@ HJ_DEV int ordered(float f) { const int i = __float_as_int(f); return i >= 0 ? i
 HJ_DEV float unordered(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
 __global__ void k_init_bounds(int* bounds) {
-  if (threadIdx.x < 3) bounds[threadIdx.x] = 0x7FFFFFFF;
-  else if (threadIdx.x < 6) bounds[threadIdx.x] = (int)0x80000000;
+  if (threadIdx.x < 12) bounds[threadIdx.x] = (threadIdx.x % 6u) < 3u ? 0x7FFFFFFF : (int)0x80000000;
 }
 
 // Shape bounds as the host computes them (src/shape.rs:13-20,46-54, src/main.rs:74-79) + bounds of the centroids.
@@ -105,6 +105,18 @@ __global__ __launch_bounds__(256) void k_shape_boxes(Shapes s, Tree t, uint32_t 
       atomicMin(&t.bounds[k], mn);
       atomicMax(&t.bounds[3 + k], mx);
     }
+    // the scene's box (NaN or inverted boxes do not take part)
+    const bool okb = valid && lo[k] <= hi[k];
+    int bmn = okb ? ordered(lo[k]) : 0x7FFFFFFF, bmx = okb ? ordered(hi[k]) : (int)0x80000000;
+    for (int o = 32; o > 0; o >>= 1) {
+      const int a = __shfl_xor(bmn, o), b = __shfl_xor(bmx, o);
+      bmn = a < bmn ? a : bmn;
+      bmx = b > bmx ? b : bmx;
+    }
+    if ((threadIdx.x & 63u) == 0) {
+      atomicMin(&t.bounds[6 + k], bmn);
+      atomicMax(&t.bounds[9 + k], bmx);
+    }
   }
 }
 
@@ -121,7 +133,7 @@ HJ_DEV unsigned long long spread21(unsigned long long v) {   // 21 bits -> every
 constexpr unsigned long long kBigShape = 1ull << 63;
 
 // idx_bits: bits of the shape index; axis_bits: Morton bits per axis (3 * axis_bits + idx_bits <= 63);
-// big_frac: shapes whose box area exceeds big_frac x the area of the centroid bounds are flagged (and counted in *nbig).
+// big_frac: shapes whose box area exceeds big_frac x the area of the scene's box are flagged (and counted in *nbig).
 __global__ __launch_bounds__(256) void k_morton_keys(Tree t, uint32_t n, uint32_t idx_bits, uint32_t axis_bits, float big_frac,
                                                      uint32_t* nbig) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,22 +141,33 @@ __global__ __launch_bounds__(256) void k_morton_keys(Tree t, uint32_t n, uint32_
   const float4 lo = t.leaf_lo[i], hi = t.leaf_hi[i];
   const float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
   unsigned long long q[3];
-  float ext[3];
   const float scale = (float)(1u << axis_bits);
   for (int k = 0; k < 3; k++) {
     const float mn = unordered(t.bounds[k]), mx = unordered(t.bounds[3 + k]);
     const float e = mx - mn;
-    ext[k] = e > 0.f ? e : 0.f;
     float u = e > 0.f ? (c[k] - mn) / e : 0.f;
     u = u == u ? f_min(f_max(u, 0.f), 1.f) : 0.f;
     q[k] = (unsigned long long)f_min(u * scale, scale - 1.0f);
   }
   const unsigned long long code = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
   const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
-  const float area = dx * dy + dy * dz + dz * dx, scene = ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0];
+  float sx[3];
+  for (int k = 0; k < 3; k++) { const float e = unordered(t.bounds[9 + k]) - unordered(t.bounds[6 + k]); sx[k] = e > 0.f ? e : 0.f; }
+  const float area = dx * dy + dy * dz + dz * dx, scene = sx[0] * sx[1] + sx[1] * sx[2] + sx[2] * sx[0];
   const bool big = big_frac > 0.f && scene > 0.f && area > big_frac * scene;
   if (big) atomicAdd(nbig, 1u);
   t.keys[i] = (big ? kBigShape : 0ull) | (code << idx_bits) | i;        // the index makes every key unique
+}
+
+// Boxes (and, in lo.w, shape indices) of the nbig large shapes, which sort behind the m small ones: out[2k], out[2k + 1].
+__global__ void k_gather_big(Tree t, uint32_t m, uint32_t nbig, unsigned long long idx_mask, float4* out) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nbig) return;
+  const uint32_t shape = (uint32_t)(t.keys[m + k] & idx_mask);
+  float4 lo = t.leaf_lo[shape];
+  lo.w = __uint_as_float(shape);
+  out[2 * k] = lo;
+  out[2 * k + 1] = t.leaf_hi[shape];
 }
 
 // Karras 2012, section 4: internal node i of the radix tree over the sorted (unique) keys.

@@ -185,8 +185,9 @@ typedef struct hj_context hj_context;
  * 1167-1314).  One context per GPU; no global state. */
 int hj_context_create(int device_ordinal, hj_context** out_ctx);
 void hj_context_destroy(hj_context* ctx);
-/* Replaces unwrap()/panic! text: message of the last failing call on ctx
- * (owned by ctx; valid until the next call).  ctx may be NULL for create errors. */
+/* Replaces unwrap()/panic! text: message of the last failing call on ctx, copied into a buffer of the CALLING thread
+ * (valid until that thread's next hj_last_error call; the context's worker thread may fail at any time).  ctx may be
+ * NULL for create errors. */
 const char* hj_last_error(const hj_context* ctx);
 /* Library / ABI version: (major<<16)|(minor<<8)|patch. */
 uint32_t hj_version(void);
@@ -256,11 +257,16 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* scene, hj_bvh_node
 
 /* ------------------------------------------------- asynchronous frame, progress */
 
-/* hj_render_frame on a worker thread of the context: returns at once, hj_sync waits for the frame and returns its
- * status and statistics.  One host thread can so keep one context per GPU rendering at the same time, and the drain of
- * one context overlaps whatever the host does next (the reduce waits for all of them).  At most one frame in flight per
- * context; every other call on the context must wait for hj_sync.  (No counterpart in the reference, whose submit loop
- * src/main.rs:1316-1355 is synchronous with respect to the host but never waits for the device.) */
+/* hj_render_frame on the context's worker thread (one persistent thread per context, started by the first call):
+ * returns at once, hj_sync waits for the frame and returns its status and statistics.  One host thread can so keep one
+ * context per GPU rendering at the same time, and the drain of one context overlaps whatever the host does next (the
+ * reduce waits for all of them).  At most one frame in flight per context: until it has finished every other entry
+ * point that touches the context's device state (scene upload, framebuffer create / clear / read / resolve, the render
+ * calls, the probes, hj_build_bvh_device) returns HJ_ERR_STATE.  The result of the last asynchronous frame stays
+ * retrievable - hj_sync after hj_comm_reduce_framebuffers, which joins the frames itself, still returns the statistics -
+ * until the next hj_render_frame_async; hj_sync on a context that never ran one returns HJ_OK and leaves *stats alone.
+ * (No counterpart in the reference, whose submit loop src/main.rs:1316-1355 is synchronous with respect to the host but
+ * never waits for the device.) */
 int hj_render_frame_async(hj_context* ctx, uint32_t spp, uint64_t master_seed,
                           uint32_t pass_begin, uint32_t pass_end, uint32_t rank, uint32_t world,
                           const hj_render_opts* opts);

@@ -113,7 +113,7 @@ def test_argument_checks_need_no_gpu():
 
 def test_walk_of_the_fused_kernel_is_spill_free():
     """The fused kernel's own code is the BVH walk (top-up, hit compaction and shade are called functions with their own
-    register allocation): no scratch (spill) instruction may sit between the barriers around the walk - one reload there
+    register allocation): no scratch (spill) instruction may sit inside the walk's loops - one reload there
     is a dependent memory trip per round of the walk loop.  tools/spill_scan.py compiles the device
     code to gfx950 assembly and counts them."""
     import re
@@ -122,6 +122,6 @@ def test_walk_of_the_fused_kernel_is_spill_free():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "spill_scan.py")], capture_output=True, text=True,
                        env=dict(os.environ, TMPDIR="/tmp"), timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    walks = re.findall(r"scratch instructions inside the walk \(lines \d+ \.\. \d+, between the barriers around it\): (\d+)", r.stdout)
+    walks = re.findall(r"scratch instructions inside the walk \(loops of depth >= 2 of the kernel\): (\d+)", r.stdout)
     assert len(walks) == 4, r.stdout           # the four BVH instantiations (pair nodes x streamed path state)
     assert all(int(n) == 0 for n in walks), r.stdout

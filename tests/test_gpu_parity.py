@@ -878,3 +878,48 @@ def test_tuning_switches_never_change_a_bit(oracle, cbox_spheres, monkeypatch, e
         got, st = render(r, cbox_spheres, W, H, blocks, opts)
     assert_same(got, want, f"switches {env}")
     assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"]
+
+
+@pytest.mark.gpu
+def test_small_pool_with_partial_block_rows(oracle, cbox_spheres, monkeypatch):
+    """A pool of ONE 64-sample group per workgroup on a frame whose bottom block row is 3 pixels high: most top-ups of the
+    workgroups that own that row append nothing (every sample of the group lies outside its block) and the round is skipped
+    without a shade - the path through k_path_wavefront's `continue`, which must not find an older round's path count again
+    (samples would be shaded twice).  Mirror + glass + emitter scene, exact."""
+    monkeypatch.setenv("HJ_POOL", "64")
+    monkeypatch.setenv("HJ_WG_PER_CU", "1")
+    W, H = 200, 131
+    blocks = host.make_blocks(W, H, 3, 17)
+    want, ctr, _ = oracle.render_blocks(cbox_spheres, blocks, W, H)
+    with device.Renderer(0) as r:
+        got, st = render(r, cbox_spheres, W, H, blocks)
+    assert_same(got, want, "pool 64, ragged rows")
+    assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"]
+
+
+@pytest.mark.gpu
+def test_async_frame_state_and_statistics(cbox_small):
+    """hj_render_frame_async: other entry points answer HJ_ERR_STATE while the frame is in flight (never a race with the
+    worker thread); the frame's statistics stay retrievable after a reduce has already joined it; a second frame reuses
+    the same worker thread; the frame equals the synchronous one bit for bit."""
+    W = H = 256
+    with device.Renderer(0) as r:
+        r.upload_scene(cbox_small)
+        r.create_framebuffer(W, H)
+        want_st = r.render_frame(8, 5)
+        want = r.read()
+        for _ in range(2):
+            r.clear()
+            r.render_frame_async(8, 5)
+            L = device.lib()
+            rc = L.hj_framebuffer_clear(r._h)        # in flight (or just finished): HJ_ERR_STATE or HJ_OK, never a crash
+            assert rc in (abi.HJ_OK, abi.HJ_ERR_STATE)
+            if rc == abi.HJ_ERR_STATE:
+                assert b"in flight" in L.hj_last_error(r._h)
+            comm = device.Comm([r])
+            comm.reduce(0)                            # joins the frame (hj_sync(ctx, NULL) inside)
+            comm.close()
+            st = r.sync()                             # ... and the statistics are still there
+            if rc == abi.HJ_ERR_STATE:
+                assert st["paths"] == want_st["paths"] == W * H * 8 and st["closest_rays"] == want_st["closest_rays"]
+                assert (bits(r.read()) == bits(want)).all()

@@ -27,7 +27,7 @@ done
 rm -rf $out/stats
 cd $root
 # walk statistics of the same workload (diagnostic build with counters: tools/build_variant.sh stats -DHJ_WALK_STATS)
-if [ -f hijiki_amd/lib/var_stats.so ]; then
+if [ -f build/variants/var_stats.so ]; then
   case $cfg in
     c2) HJ_STATS_SPP=512 timeout 300 python3 tools/walk_stats.py 0 --json $out/walk_stats.json > $out/walk_stats.txt 2>&1 ;;
     c3) HJ_STATS_SPP=1024 timeout 300 python3 tools/walk_stats.py 1 --json $out/walk_stats.json > $out/walk_stats.txt 2>&1 ;;

@@ -23,11 +23,21 @@ for i0, line in enumerate(s):
     scratch = [(k, l.strip().split(";")[0].strip()) for k, l in enumerate(body) if "scratch_" in l]
     print(f"k_path_wavefront<USE_BVH={m.group(2)}, PAIRS={m.group(3)}, NT={m.group(4)}>: {len(body)} lines, {len(scratch)} scratch instructions")
     if fetch:
-        # the walk = everything between the workgroup barrier before the first node fetch and the one after the last
-        bars = [k for k, l in enumerate(body) if "s_barrier" in l]
-        lo = max([k for k in bars if k < min(fetch)], default=0)
-        hi = min([k for k in bars if k > max(fetch)], default=len(body))
-        near = [x for x in scratch if lo <= x[0] <= hi]
-        print(f"  node fetch at line {fetch[0]}; scratch instructions inside the walk (lines {lo} .. {hi}, between the barriers around it): {len(near)}")
-        for k, l in near:
+        # The walk = the loops nested inside the round loop of the kernel (depth 1): trace_persistent's for(;;) is depth 2, its
+        # box-step loop depth 3; top-up, hit compaction and shade are calls and have no loops here.  The assembly printer
+        # annotates every basic block (".LBBn_m:" or "; %bb.m:") with its innermost loop and depth.
+        depth, in_walk = 0, []
+        for k, l in enumerate(body):
+            if re.match(r"^(\.LBB\d+_\d+:|; %bb\.\d+:)", l):
+                m2 = re.search(r"Depth=(\d+)", l)
+                depth = int(m2.group(1)) if m2 else 0
+            elif l.lstrip().startswith("; =>") or l.lstrip().startswith(";   "):
+                m2 = re.search(r"This (?:Inner )?Loop Header: Depth=(\d+)", l)
+                if m2:
+                    depth = int(m2.group(1))
+            if "scratch_" in l and depth >= 2:
+                in_walk.append((k, l.strip().split(";")[0].strip()))
+        fetch_depth_ok = True
+        print(f"  node fetch at line {fetch[0]}; scratch instructions inside the walk (loops of depth >= 2 of the kernel): {len(in_walk)}")
+        for k, l in in_walk:
             print(f"    {k:6d}  {l}")

@@ -3,7 +3,7 @@
     python tools/walk_stats.py KIND [MAX_BOUNCES] [--json OUT]     env: HJ_STATS_SPP (512 = the batch sizes of the benchmark; small frames give small batches and emptier waves), HJ_STATS_SIZE (1024), HJ_STATS_TRIS
 """
 import sys, os, json, ctypes as C
-os.environ.setdefault("HIJIKI_HIP_LIB", "hijiki_amd/lib/var_stats.so")
+os.environ.setdefault("HIJIKI_HIP_LIB", "build/variants/var_stats.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hijiki_amd import host, device
 argv = [a for a in sys.argv[1:]]
