@@ -888,7 +888,7 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     // The walk adds 32 * index to the low word of the array's address without a carry (kernels/hj_kernels.h): the
     // array must not cross a 4 GiB boundary.  Allocate twice the size and start at the boundary if it would.
     {
-      const size_t bytes = std::max<size_t>(dev.size() * sizeof(float4), 16);
+      const size_t bytes = std::max<size_t>(dev.size() * sizeof(float4), 16) + 128;   // (slack: a whole 128-byte line may be read around the last record)
       if (bytes >= (1ull << 32)) { release_scene(ctx); return set_error(ctx, HJ_ERR_UNSUPPORTED, "BVH of %zu records: the device node array is limited to 4 GiB", M); }
       ctx->scene_bufs.emplace_back();
       DevBuf& b = ctx->scene_bufs.back();

@@ -318,7 +318,7 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     asm volatile("v_mov_b32 %0, %1" : "=v"(nb_lhi) : "s"((uint32_t)(lb >> 32)));
   }
   RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
-#if defined(HJ_VALU_PROBE) || defined(HJ_LOAD_PROBE) || defined(HJ_LEAF_VALU_PROBE)
+#if defined(HJ_VALU_PROBE) || defined(HJ_LOAD_PROBE) || defined(HJ_LEAF_VALU_PROBE) || defined(HJ_WIDE_PROBE)
   float valu_probe = 1.0f;
 #endif
   uint32_t shape = 0, ex = 0;
@@ -477,6 +477,21 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
         asm volatile("flat_load_dwordx4 %0, %1" : "=v"(pv) : "v"(pp) : "memory");
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         valu_probe += pv.x * 0.0f;
+      }
+#endif
+#ifdef HJ_WIDE_PROBE   // diagnostic: what a 128-byte node would cost per step - the six other 16-byte parts of the node's 128-byte line
+      {
+        const uint32_t own = (cur & 3u) * 2u;             // the node's own two parts within its group of four records
+        const float4* gp = reinterpret_cast<const float4*>((((uint64_t)a_hi << 32) | (uint64_t)a_lo) & ~127ull);
+        float4 pv[6];
+#pragma unroll
+        for (int k_ = 0; k_ < 6; k_++) {
+          const float4* pp = gp + ((own + 2u + (uint32_t)k_) & 7u);
+          asm volatile("flat_load_dwordx4 %0, %1" : "=v"(pv[k_]) : "v"(pp) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k_ = 0; k_ < 6; k_++) valu_probe += pv[k_].x * 0.0f;
       }
 #endif
       at_leaf = node_step<PAIRS>(n0, n1, inv, off, r, cur, shape, ex);

@@ -11,7 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("cfg", ["c2", "c3", "c4"])
 def test_roofline_inputs_regenerate_from_committed_csv(cfg):
-    tag = f"r02_{cfg}_"
+    import glob
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{cfg}_roofline_inputs.json")))[-1]     # what bench.py reads
+    tag = os.path.basename(newest)[:-len("roofline_inputs.json")]
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "roofline_inputs.py"), "build",
                                    os.path.join(ROOT, "profiles"), cfg, tag], text=True)
     fresh = json.loads(out)
@@ -19,6 +21,7 @@ def test_roofline_inputs_regenerate_from_committed_csv(cfg):
     assert fresh == stored
     assert stored["counters"]["FETCH_SIZE"] > 0 and stored["counters"]["WRITE_SIZE"] > 0
     assert 0 < stored["limiter"]["valu_lanes_per_instruction"] <= 64
+    assert 0 < stored["limiter"]["valu_issue_frac"] < 1 and 0 < stored["limiter"]["lane_fill"] <= 1
     if cfg == "c4":
         assert stored["scene_bytes_per_ray"] > 500          # nodes beyond the LDS copy + triangle records
 
@@ -33,3 +36,18 @@ def test_bench_byte_model_is_consistent():
     assert 0 < bench.coalesced_read_bytes(st) < b
     st2 = {k: 2 * v for k, v in st.items()}
     assert abs(bench.implemented_bytes(st2) - 2 * b) < 1e-6 * b
+
+
+def test_roofline_block_never_quotes_more_than_the_counters_saw():
+    """on the 1 M-triangle scene the quoted `achieved` (0.66 of peak) exceeded the PMC traffic (0.42).  Scene bytes
+    now count only the share the L2 does not serve, and `achieved` is capped at `traffic`."""
+    sys.path.insert(0, ROOT)
+    import bench
+    P = 2048 * 2048 * 256
+    agg = {"paths": P, "closest_rays": int(2.9 * P), "shadow_rays": int(1.85 * P), "hits": int(2.7 * P),
+           "unoccluded_shadow_rays": int(1.2 * P), "path_launches": 8, "path_busy_ms": 960.0, "path_ms": 2800.0}
+    r = bench.roofline_block("c4", agg, 0.99, 1, 1, True)
+    assert r["bound"] == "hbm" and r["limited_by"] == "latency"
+    assert r["traffic"] is not None and r["achieved"] <= r["traffic"] * 1.001
+    assert 0 < r["valu_issue_frac"] < 1 and 0 < r["lane_fill"] < 1
+    assert r["frac"] == round(r["achieved"] / 8000.0, 4)

@@ -102,6 +102,11 @@ def cmd_build(d, cfg, prefix=""):
     lim = {}
     if c.get("SQ_INSTS_VALU"):
         lim["valu_lanes_per_instruction"] = round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"], 2)
+        lim["lane_fill"] = round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"] / 64.0, 4)
+    if c.get("SQ_INSTS_VALU") and c.get("GRBM_GUI_ACTIVE"):
+        # share of the chip's VALU issue slots the kernel uses: a VALU instruction occupies its SIMD for 4 cycles (64 lanes on a
+        # 16-lane unit); 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        lim["valu_issue_frac"] = round(c["SQ_INSTS_VALU"] * 4.0 / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0), 4)
     if c.get("SQ_WAVE_CYCLES"):
         for k, n in (("SQ_ACTIVE_INST_VALU", "valu_issue_share_of_wave_cycles"), ("SQ_WAIT_ANY", "waiting_share_of_wave_cycles"),
                      ("SQ_WAIT_INST_ANY", "issue_stall_share_of_wave_cycles"), ("SQ_ACTIVE_INST_VMEM", "vmem_issue_share_of_wave_cycles")):
