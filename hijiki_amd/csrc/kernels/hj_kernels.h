@@ -492,6 +492,9 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int k_ = 0; k_ < 6; k_++) valu_probe += pv[k_].x * 0.0f;
+        // the destinations must stay live until the wait: a register the compiler considers dead is handed to the next
+        // address computation while the load that will overwrite it is still in flight (a build without this faulted)
+        asm volatile("" :: "v"(valu_probe));
       }
 #endif
       at_leaf = node_step<PAIRS>(n0, n1, inv, off, r, cur, shape, ex);

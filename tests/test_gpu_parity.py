@@ -742,6 +742,28 @@ def test_single_context_reduce_through_rccl(cbox_small, monkeypatch):
         r.close()
 
 
+def test_rccl_reduce_at_config5_frame_size(cbox_small, monkeypatch):
+    """BASELINE.json configs[4]'s framebuffer through the RCCL calls of the C ABI: 4096 x 4096 RGBA32F = 67 108 864 floats
+    (268 MB) in ONE ncclReduce on the context's stream (one rank, in place - all a one-GPU box allows): count and
+    stream handling at the size the 8-GPU frame reduces.  One pass of the frame is rendered first so that the buffer holds
+    real sums; the reduce must return it bit for bit."""
+    monkeypatch.setenv("HJ_COMM_FORCE_RCCL", "1")
+    W = H = 4096
+    with device.Renderer(0) as r:
+        r.upload_scene(cbox_small)
+        r.create_framebuffer(W, H)
+        st = r.render_frame(1, 9)
+        assert st["paths"] == W * H
+        want = r.read()
+        assert want[..., 3].min() > 0                                    # every pixel was written
+        comm = device.Comm([r])
+        comm.reduce(0)
+        comm.reduce(0)
+        got = r.read()
+        comm.close()
+    assert (bits(got) == bits(want)).all()
+
+
 _TORCH_RCCL_SCRIPT = r"""
 import os, sys
 import numpy as np

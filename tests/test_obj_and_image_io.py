@@ -187,6 +187,59 @@ def test_exr_and_pfm_round_trip(tmp_path):
     assert (back.view(np.uint32) == rgb.view(np.uint32)).all()
 
 
+def test_exr_file_is_the_published_scanline_layout_byte_for_byte(tmp_path):
+    """Independent of read_exr above: the whole file of a 2 x 2 image, assembled here by hand from the OpenEXR file-layout
+    document (magic 20000630, version 2 without flag bits = single-part scan-line file with short names; header =
+    attributes `name\\0 type\\0 int32 size, value`, the eight REQUIRED attributes of the format with their standard types
+    and sizes, terminated by a null byte; line offset table of one uint64 per scan line for NO_COMPRESSION; each line
+    chunk = int32 y, int32 byte count, then the channels in alphabetical order, each w floats).  What the reference
+    writes through the openexr crate (src/main.rs:1402-1419: 3 x FLOAT "R", "G", "B" scan lines) has this layout."""
+    def attr(name, typ, value):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(value)) + value
+    def chan(name):          # name\0, pixel type (2 = FLOAT), pLinear + 3 reserved bytes, xSampling, ySampling
+        return name.encode() + b"\0" + struct.pack("<i", 2) + b"\0\0\0\0" + struct.pack("<ii", 1, 1)
+    w = h = 2
+    rgb = np.arange(12, dtype=np.float32).reshape(h, w, 3) + 0.5
+    box = struct.pack("<4i", 0, 0, w - 1, h - 1)
+    header = (bytes([0x76, 0x2F, 0x31, 0x01]) + struct.pack("<i", 2)
+              + attr("channels", "chlist", chan("B") + chan("G") + chan("R") + b"\0")
+              + attr("compression", "compression", b"\0")
+              + attr("dataWindow", "box2i", box)
+              + attr("displayWindow", "box2i", box)
+              + attr("lineOrder", "lineOrder", b"\0")
+              + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+              + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0.0, 0.0))
+              + attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+              + b"\0")
+    line = 8 + w * 3 * 4
+    table = b"".join(struct.pack("<Q", len(header) + 8 * h + y * line) for y in range(h))
+    chunks = b""
+    for y in range(h):
+        chunks += struct.pack("<ii", y, w * 3 * 4)
+        for c in (2, 1, 0):                                       # B, G, R planes of the line
+            chunks += rgb[y, :, c].astype("<f4").tobytes()
+    host.write_image(tmp_path / "tiny.exr", rgb)
+    got = open(tmp_path / "tiny.exr", "rb").read()
+    assert got == header + table + chunks
+    # the required attributes, by the names and types every OpenEXR reader looks up
+    for name, typ in (("channels", "chlist"), ("compression", "compression"), ("dataWindow", "box2i"), ("displayWindow", "box2i"),
+                      ("lineOrder", "lineOrder"), ("pixelAspectRatio", "float"), ("screenWindowCenter", "v2f"), ("screenWindowWidth", "float")):
+        assert name.encode() + b"\0" + typ.encode() + b"\0" in got[:len(header)]
+
+
+def test_png_is_read_back_by_an_independent_decoder(tmp_path):
+    """Pillow (not part of this repo) decodes the preview PNG to the same 8-bit values the sRGB transfer function gives."""
+    PIL = pytest.importorskip("PIL.Image")
+    rgb = np.random.default_rng(9).random((33, 47, 3)).astype(np.float32)
+    host.write_image(tmp_path / "b.png", rgb)
+    im = PIL.open(tmp_path / "b.png")
+    assert im.size == (47, 33) and im.mode == "RGB"
+    got = np.asarray(im).astype(np.int32)
+    v = rgb.astype(np.float64)
+    want = np.where(v <= 0.0031308, 12.92 * v, 1.055 * v ** (1 / 2.4) - 0.055) * 255
+    assert np.abs(got - want).max() <= 0.51
+
+
 def test_png_preview_image(tmp_path):
     """8-bit sRGB PNG (what the reference's preview window shows): decoded with zlib here, checked against the sRGB
     transfer function, every chunk CRC verified; a frame larger than one stored deflate block."""
