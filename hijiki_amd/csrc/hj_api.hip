@@ -27,7 +27,6 @@
 #include "host/blockgen.hpp"
 #include "kernels/hj_kernels.h"
 #include "kernels/hj_lbvh.h"
-#include "wide_tree.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -480,8 +479,6 @@ int enqueue_batch_fused(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::
   static const size_t lds_pad = (size_t)env_int("HJ_LDS_PAD_KB", 0, 0, 64) * 1024;
   const bool pairs = ctx->scene.has_pairs != 0, nt = ctx->scene.stream_state != 0;
   if (!o.use_bvh) hipLaunchKernelGGL((hj::k_path_wavefront<false, false, false>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
-  else if (ctx->scene.wnodes && nt) hipLaunchKernelGGL((hj::k_path_wavefront<true, true, true, true>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
-  else if (ctx->scene.wnodes) hipLaunchKernelGGL((hj::k_path_wavefront<true, true, false, true>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
   else if (pairs && nt) hipLaunchKernelGGL((hj::k_path_wavefront<true, true, true>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
   else if (pairs) hipLaunchKernelGGL((hj::k_path_wavefront<true, true, false>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
   else if (nt) hipLaunchKernelGGL((hj::k_path_wavefront<true, false, true>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
@@ -868,41 +865,6 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
       float4* rec = &dev[2 * (size_t)map[i]];
       rec[0] = make_float4(nd.aabb_min[0], nd.aabb_min[1], nd.aabb_min[2], __builtin_bit_cast(float, a));
       rec[1] = make_float4(nd.aabb_max[0], nd.aabb_max[1], nd.aabb_max[2], __builtin_bit_cast(float, b));
-    }
-    // Wide nodes (wide_tree.h; HJ_WIDE=1): the same tree, up to kWideK children's boxes per record
-    const size_t shapes_total = s->num_spheres + s->num_quads + s->num_triangles;
-    if (env_int("HJ_WIDE", 0, 0, 1) != 0 && !pairs.empty() && shapes_total < hj::kUnguardedFlag) {
-      hj_wide::Tree wt;
-      if (hj_wide::build(s->bvh, N, pair_of, hj::kWideK, wt)) {
-        // hottest first (the LDS copy): by the area of the box that guards the node's entry; the rest keeps creation order
-        std::vector<uint32_t> ord(wt.num_nodes);
-        for (uint32_t k = 0; k < wt.num_nodes; k++) ord[k] = k;
-        const uint32_t whot = std::min<uint32_t>(hj::kWideHot, wt.num_nodes);
-        std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return wt.entry_area[a] > wt.entry_area[b]; });
-        std::sort(ord.begin() + whot, ord.end());
-        hj_wide::permute(wt, hj::kWideK, ord);
-        const size_t bytes = wt.rec.size() * sizeof(float) + 256;
-        if (bytes < (1ull << 32)) {
-          ctx->scene_bufs.emplace_back();
-          DevBuf& b = ctx->scene_bufs.back();
-          HJ_UP(dev_alloc(ctx, b, bytes));
-          uintptr_t start = reinterpret_cast<uintptr_t>(b.p);
-          if ((start >> 32) != ((start + bytes - 1) >> 32)) {           // (the walk adds offsets to the low address word without a carry)
-            b.release();
-            HJ_UP(dev_alloc(ctx, b, 2 * bytes));
-            start = reinterpret_cast<uintptr_t>(b.p);
-            if ((start >> 32) != ((start + bytes - 1) >> 32)) start = ((start >> 32) + 1) << 32;
-          }
-          if (hipMemcpy(reinterpret_cast<void*>(start), wt.rec.data(), wt.rec.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-            release_scene(ctx);
-            return set_error(ctx, HJ_ERR_DEVICE, "wide node upload failed");
-          }
-          d.wnodes = reinterpret_cast<const float4*>(start);
-          d.num_wnodes = wt.num_nodes;
-          d.num_whot = whot;
-          d.wroot = 0;                                                  // the one-slot top node has the largest entry area
-        }
-      }
     }
     HJ_UP(upload(ctx, pairs.data(), pairs.size(), &d.tri_pair));
     d.has_pairs = pairs.empty() ? 0u : 1u;

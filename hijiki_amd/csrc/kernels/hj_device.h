@@ -20,18 +20,6 @@ constexpr uint32_t kHotNodes = HJ_HOT_NODES;
 constexpr uint32_t kInnerFlag = 0x80000000u;
 constexpr uint32_t kPairFlag = 0x40000000u;    // with kInnerFlag: an inner node whose two children are triangle leaves
 constexpr uint32_t kIndexMask = 0x3FFFFFFFu;
-// Wide nodes (csrc/wide_tree.h): HJ_WIDE_K slots of 32 bytes each, the binary record's format per slot:
-//   (box min.xyz, LINK) (box max.xyz, NEXT)
-//   LINK  bit 31 set: inner slot (bit 30 clear, index of the child's wide node) or pair slot (bit 30 set, pair record)
-//         bit 31 clear: a leaf's shape index; bit 30 set: tested without a box test; 0xFFFFFFFF: unused slot (NaN box)
-//   NEXT  where the walk goes on when slot s is done: node index | slot << 30 (index kIndexMask: the walk is over);
-//         the last slot's NEXT is also what the walk takes when no slot passes
-#ifndef HJ_WIDE_K
-#define HJ_WIDE_K 4
-#endif
-constexpr uint32_t kWideK = HJ_WIDE_K;
-constexpr uint32_t kWideHot = (2u * HJ_HOT_NODES) / (2u * HJ_WIDE_K);   // wide nodes in the LDS copy (the same 12 KB)
-constexpr uint32_t kUnguardedFlag = 0x40000000u;
 
 // Scene data in HBM.  `nodes` are 32-byte records (two float4 per node) derived from the reference's
 // skip-link array (same tree, same boxes, same visiting order) but RE-INDEXED: the kHotNodes nodes with the
@@ -55,8 +43,6 @@ struct DeviceScene {
   uint32_t num_hot;             // nodes [0, num_hot) are the LDS-cached ones (<= kHotNodes)
   uint32_t inner_burst;         // max box steps per round of the persistent walk before leaf tests run
   uint32_t refill_min;          // free lanes that trigger a ray refill
-  const float4* wnodes;         // wide nodes (2 * kWideK float4 each), hottest first; null: binary walk
-  uint32_t num_wnodes, num_whot, wroot;
   const float4* tri_isect;
   const float4* tri_pair;       // 6 x float4 per pair node: (a, b-a, c-a) of the left and of the right triangle, shape indices in [0].w, [3].w
   const float4* tri_shade;

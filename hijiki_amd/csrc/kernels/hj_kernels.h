@@ -261,67 +261,6 @@ HJ_DEV bool traverse(const DeviceScene& sc, Ray r, RawHit& h) {
   return h.id != -1;
 }
 
-// ---- wide nodes (csrc/wide_tree.h, hj_device.h) -----------------------------------------------------------------------
-// One wide node: the K slots' boxes are tested with the CURRENT tMax, slots before the walk's current one (cur >> 30) are
-// done, the FIRST slot that passes is taken (the reference visits children left to right; a later slot is looked at again
-// when the walk returns, with the tMax of that moment - that is when scene.glsl:120-131 tests it).  An inner slot moves
-// `cur` to its child node; a leaf or pair slot stops the lane (returns true) with `shape` = what to test
-// (leaf_test's encoding) and `cur` = where to go on afterwards; no slot: `cur` = the node's return link.
-template <int K>
-HJ_DEV bool wide_step(const float4 (&x)[2 * K], v3 inv, v3 off, const Ray& r, uint32_t& cur, uint32_t& shape) {
-  bool pass[K];
-#pragma unroll
-  for (int s = 0; s < K; s++) {
-    const float4 n0 = x[2 * s], n1 = x[2 * s + 1];
-    const float tnx = fmaf(n0.x, inv.x, off.x), tpx = fmaf(n1.x, inv.x, off.x);
-    const float tny = fmaf(n0.y, inv.y, off.y), tpy = fmaf(n1.y, inv.y, off.y);
-    const float tnz = fmaf(n0.z, inv.z, off.z), tpz = fmaf(n1.z, inv.z, off.z);
-    const float t0 = f_max(f_max(f_min(tnx, tpx), f_min(tny, tpy)), f_min(tnz, tpz));
-    const float t1 = f_min(f_min(f_max(tnx, tpx), f_max(tny, tpy)), f_max(tnz, tpz));
-    const bool enter = (t0 < t1 + kEps && t0 < r.tmax && t1 > r.tmin);
-    pass[s] = enter || (int)__float_as_uint(n0.w) >= (int)kUnguardedFlag;      // (an unused slot: NaN box, link 0xFFFFFFFF)
-  }
-  pass[0] = pass[0] && cur < (1u << 30);
-  if (K > 2) pass[1] = pass[1] && cur < (2u << 30);
-  if (K > 3) pass[2] = pass[2] && cur < (3u << 30);
-  uint32_t L = __float_as_uint(x[2 * (K - 1)].w), nx = __float_as_uint(x[2 * (K - 1) + 1].w);
-  bool anyp = pass[K - 1];
-#pragma unroll
-  for (int s = K - 2; s >= 0; s--) {
-    L = pass[s] ? __float_as_uint(x[2 * s].w) : L;
-    nx = pass[s] ? __float_as_uint(x[2 * s + 1].w) : nx;
-    anyp = anyp || pass[s];
-  }
-  const bool inner = anyp && (L & (kInnerFlag | kPairFlag)) == kInnerFlag;
-  shape = (int)L < 0 ? L : (L & kIndexMask);
-  cur = inner ? (L & kIndexMask) : nx;
-  return anyp && !inner;
-}
-
-// The reference walk (scene.glsl:97-133) over wide nodes, one ray per lane (probe kernel; the persistent form is below).
-template <int K, bool ANYHIT>
-HJ_DEV bool traverse_wide(const DeviceScene& sc, Ray r, RawHit& h) {
-  h.id = -1;
-  const v3 inv = V(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-  const v3 off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
-  const uint32_t nn = sc.num_wnodes;
-  uint32_t cur = sc.wroot;
-  for (;;) {
-    uint32_t shape = 0;
-    bool at_leaf = false;
-    while ((cur & kIndexMask) < nn && !at_leaf) {
-      const float4* __restrict__ nd = sc.wnodes + (size_t)(2 * K) * (cur & kIndexMask);
-      float4 x[2 * K];
-#pragma unroll
-      for (int q = 0; q < 2 * K; q++) x[q] = nd[q];
-      at_leaf = wide_step<K>(x, inv, off, r, cur, shape);
-    }
-    if (!at_leaf) break;
-    if (leaf_test<true>(sc, r, shape, h, ANYHIT)) return true;
-  }
-  return h.id != -1;
-}
-
 // Persistent "while-while" walk with in-wave ray replacement (BVH mode): a lane whose ray has left the tree
 // does not idle until the slowest lane of its wave is done - as soon as kRefillMin lanes are free the wave
 // pulls that many new rays from its workgroup's queue segment (one LDS atomic) and the walk continues.
@@ -588,179 +527,6 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
 #endif
 }
 
-// The persistent walk over WIDE nodes: trace_persistent's scheme (in-wave ray replacement, merged first step, bounded
-// burst) with wide_step in place of node_step.  `cur` = node index | current slot << 30; a lane that stops on a leaf or
-// pair slot already holds its continuation in `cur`.
-template <int MODE, int K, class Fetch, class Finish>
-HJ_DEV void trace_persistent_wide(const DeviceScene& sc, uint32_t n, uint32_t* s_head, const float4* s_nodes,
-                                  Fetch fetch, Finish finish) {
-  constexpr int Q = 2 * K;                         // 16-byte parts of a node
-  constexpr int QX = Q > 6 ? Q : 6;                // ... and of the largest record of the merged step (a pair record: six)
-  const uint32_t lane = __lane_id();
-  const uint32_t nn = sc.num_wnodes, nhot = sc.num_whot;
-  bool active = false, pending = false, exhausted = false, any = (MODE == 1);
-  uint32_t slot = 0, cur = 0;
-  Ray r; r.o = V(0, 0, 0); r.d = V(0, 0, 0); r.tmin = 0.f; r.tmax = 0.f;
-  v3 inv = V(0, 0, 0), off = V(0, 0, 0);
-  uint32_t nb_glo, nb_ghi, nb_llo, nb_lhi;         // base addresses as opaque VGPR values (see trace_persistent)
-  {
-    const uint64_t gb = reinterpret_cast<uint64_t>(sc.wnodes), lb = reinterpret_cast<uint64_t>(s_nodes);
-    asm volatile("v_mov_b32 %0, %1" : "=v"(nb_glo) : "s"((uint32_t)gb));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(nb_ghi) : "s"((uint32_t)(gb >> 32)));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(nb_llo) : "s"((uint32_t)lb));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(nb_lhi) : "s"((uint32_t)(lb >> 32)));
-  }
-  RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
-  uint32_t shape = 0;
-  bool at_leaf = false;
-#ifdef HJ_WALK_STATS
-  unsigned long long ws[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const unsigned long long t_begin = clock64();
-#endif
-  auto node_addr = [&](uint32_t c, uint32_t& a_lo, uint32_t& a_hi) {
-    const uint32_t idx = c & kIndexMask;
-    const bool hot = idx < nhot;
-    a_lo = (hot ? nb_llo : nb_glo) + idx * (uint32_t)(32 * K);   // (neither array crosses a 4 GiB boundary: no carry)
-    a_hi = hot ? nb_lhi : nb_ghi;
-  };
-  for (;;) {
-#ifdef HJ_WALK_STATS
-    const unsigned long long t_a = clock64();
-#endif
-    const unsigned long long idle = __ballot(!active);
-    const uint32_t nidle = (uint32_t)__popcll(idle);
-    const bool service = nidle >= sc.refill_min || nidle == 64u;
-    bool got = false, any2 = any;
-    uint32_t slot2 = 0;
-    Ray r2; r2.o = V(0, 0, 0); r2.d = V(0, 0, 0); r2.tmin = 0.f; r2.tmax = 0.f;
-    RawHit h2; h2.t = 0.f; h2.u = 0.f; h2.v = 0.f; h2.id = -1;
-    if (service && !exhausted) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(s_head, nidle);
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      if (!active) {
-        const uint32_t my = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-        if (my < n) { fetch(my, slot2, r2, any2, h2); got = true; }
-      }
-      exhausted = base + nidle >= n;
-    }
-    if (service) {
-      if (__ballot(pending) != 0) finish(pending, slot, h, any);
-      pending = false;
-      HJ_STAT(5, 1); HJ_STAT(6, __popcll(__ballot(got)));
-    }
-    if (got) {
-      slot = slot2; any = any2; r = r2; h = h2;
-      inv = V(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-      off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
-      cur = sc.wroot; active = true;
-    }
-    if (__ballot(active || pending) == 0) break;
-    HJ_STAT(0, 1); HJ_STAT(7, __popcll(__ballot(active)));
-#ifdef HJ_WALK_STATS
-    const unsigned long long t_b = clock64();
-    HJ_STAT(10, t_b - t_a);
-    { const unsigned long long mn = __ballot(active && !at_leaf && (cur & kIndexMask) < nn), mc = __ballot(active && !at_leaf && (cur & kIndexMask) < nn && (cur & kIndexMask) >= nhot);
-      const unsigned long long ml = __ballot(active && at_leaf), mp = __ballot(active && at_leaf && (shape & kInnerFlag) != 0u);
-      if (lane == 0) {
-        if (mn) { ws[1] += 1; ws[2] += __popcll(mn); ws[14] += __popcll(mc); }
-        if (ml) { ws[3] += 1; ws[4] += __popcll(ml); ws[15] += __popcll(ml) + __popcll(mp); }
-      } }
-#endif
-    uint32_t burst = sc.inner_burst;
-    // ---- merged first step: leaf lanes fetch their shape record, the others their node, in one trip
-    {
-      const bool go = active && (at_leaf || (cur & kIndexMask) < nn);
-      float4 x[QX];
-#pragma unroll
-      for (int q = 0; q < QX; q++) x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      uint32_t parts = 0;
-      bool pair = false;
-      if (go) {
-        uint32_t a_lo, a_hi;
-        if (at_leaf) {
-          uint64_t pa;
-          if ((shape & kInnerFlag) != 0u) {
-            pa = reinterpret_cast<uint64_t>(sc.tri_pair) + 96ull * (uint64_t)(shape & kIndexMask);
-            parts = 6; pair = true;
-          } else if (shape < sc.ns) {
-            pa = reinterpret_cast<uint64_t>(sc.spheres) + 16ull * (uint64_t)shape;
-            parts = 2;
-          } else if (shape < sc.ns + sc.nq) {
-            pa = reinterpret_cast<uint64_t>(sc.quads) + 48ull * (uint64_t)(shape - sc.ns);
-            parts = 3;
-          } else {
-            pa = reinterpret_cast<uint64_t>(sc.tri_isect) + 48ull * (uint64_t)(shape - sc.ns - sc.nq);
-            parts = 3;
-          }
-          a_lo = (uint32_t)pa; a_hi = (uint32_t)(pa >> 32);
-        } else {
-          node_addr(cur, a_lo, a_hi);
-          parts = Q;
-        }
-        const float4* __restrict__ p = reinterpret_cast<const float4*>(((uint64_t)a_hi << 32) | (uint64_t)a_lo);
-        x[0] = p[0]; x[1] = p[1];
-#pragma unroll
-        for (int q = 2; q < QX; q++)
-          if ((uint32_t)q < parts) x[q] = p[q];
-      }
-      if (go) {
-        if (at_leaf) {
-          const bool anyhit = MODE == 1 || (MODE == 2 && any);
-          bool done = false;
-          if (pair) {
-            if (triangle_test(r, x[0], x[1], x[2], h)) { h.id = (int)__float_as_uint(x[0].w); if (anyhit) done = true; else r.tmax = h.t - kEps; }
-            if (!done && triangle_test(r, x[3], x[4], x[5], h)) { h.id = (int)__float_as_uint(x[3].w); if (anyhit) done = true; else r.tmax = h.t - kEps; }
-          } else {
-            bool hit;
-            if (shape < sc.ns) hit = intersect_sphere(r, x[0], h);
-            else if (shape < sc.ns + sc.nq) hit = quad_test(r, x[0], x[1], x[2], h);
-            else hit = triangle_test(r, x[0], x[1], x[2], h);
-            if (hit) { h.id = (int)shape; if (anyhit) done = true; else r.tmax = h.t - kEps; }
-          }
-          if (done) { active = false; pending = true; }
-          at_leaf = false;                       // (cur already names where the walk goes on)
-        } else {
-          float4 y[Q];
-#pragma unroll
-          for (int q = 0; q < Q; q++) y[q] = x[q];
-          at_leaf = wide_step<K>(y, inv, off, r, cur, shape);
-        }
-      }
-      burst--;
-    }
-#ifdef HJ_WALK_STATS
-    HJ_STAT(12, clock64() - t_b);
-#endif
-    while (active && (cur & kIndexMask) < nn && !at_leaf && burst != 0) {
-#ifdef HJ_WALK_STATS
-      { const unsigned long long m = __ballot(true), mc = __ballot((cur & kIndexMask) >= nhot);
-        if (lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[1] += 1; ws[2] += __popcll(m); ws[14] += __popcll(mc); } }
-#endif
-      uint32_t a_lo, a_hi;
-      node_addr(cur, a_lo, a_hi);
-      const float4* __restrict__ nd = reinterpret_cast<const float4*>(((uint64_t)a_hi << 32) | (uint64_t)a_lo);
-      float4 y[Q];
-#pragma unroll
-      for (int q = 0; q < Q; q++) y[q] = nd[q];
-      at_leaf = wide_step<K>(y, inv, off, r, cur, shape);
-      burst--;
-    }
-    if (active && !at_leaf && (cur & kIndexMask) >= nn) { active = false; pending = true; }   // the walk is over
-#ifdef HJ_WALK_STATS
-    HJ_STAT(11, clock64() - t_b);
-#endif
-  }
-#ifdef HJ_WALK_STATS
-  HJ_STAT(13, clock64() - t_begin);
-  for (int i = 0; i < 16; i++) {
-    unsigned long long v = ws[i];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    if (lane == 0 && v) atomicAdd(&g_walk_stats[i], v);
-  }
-#endif
-}
-
 // ------------------------------------------------------------ populate (its)
 
 struct Its { v3 p, n, ft, fb; float u, v; };   // frame = [ft fb n]
@@ -885,13 +651,8 @@ struct WgShared {                 // LDS of a path workgroup (12.4 KB)
   float4 nodes[2 * kHotNodes];    // LDS copy of the hottest BVH nodes (same record layout as DeviceScene::nodes)
 };
 
-template <bool WIDE = false>
 HJ_DEV void load_hot_nodes(const DeviceScene& sc, WgShared& sh) {
-  if (WIDE) {
-    for (uint32_t i = threadIdx.x; i < 2 * kWideK * sc.num_whot; i += blockDim.x) sh.nodes[i] = sc.wnodes[i];
-  } else {
-    for (uint32_t i = threadIdx.x; i < 2 * sc.num_hot; i += blockDim.x) sh.nodes[i] = sc.nodes[i];
-  }
+  for (uint32_t i = threadIdx.x; i < 2 * sc.num_hot; i += blockDim.x) sh.nodes[i] = sc.nodes[i];
 }
 
 // Barrier between two stages of a workgroup.  In the tail of a batch the workgroup is down to ONE wave (the others
@@ -998,7 +759,7 @@ HJ_DEV void linear_scan(const DeviceScene& sc, Ray r, RawHit& h, bool any) {
 // bounce k-1 is added during this phase, emission of bounce k in the shade that follows the barrier.  A closest-hit
 // ray only records its hit (objectID -1 = miss); an unoccluded shadow ray adds its NEE radiance (render.glsl:122-124).
 // Needs sh.head == 0 and the hot nodes loaded (synced).
-template <bool USE_BVH, bool PAIRS, bool NT, bool WIDE = false>
+template <bool USE_BVH, bool PAIRS, bool NT>
 HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t n,
                                uint32_t ns, WgShared& sh) {
   const uint32_t seg = g * st.pool;
@@ -1054,9 +815,7 @@ HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint
     }
     unocc += (uint32_t)__popcll(__ballot(add));
   };
-  if (USE_BVH && WIDE) {
-    trace_persistent_wide<2, (int)kWideK>(sc, n + ns, &sh.head, sh.nodes, fetch, finish);
-  } else if (USE_BVH) {
+  if (USE_BVH) {
     trace_persistent<2, PAIRS>(sc, n + ns, &sh.head, sh.nodes, fetch, finish);
   } else {
     const uint32_t lane = threadIdx.x & 63u;
@@ -1358,7 +1117,7 @@ __device__ __attribute__((noinline)) void compact_hits_call(uint32_t ka_lo, uint
 #ifndef HJ_PATH_WAVES
 #define HJ_PATH_WAVES 7   // 72 VGPRs; measured on the compacted-record kernel: 6 waves (80 VGPRs) -6 %, 8 waves (64 VGPRs) -2 %, 5 waves -5 %
 #endif
-template <bool USE_BVH, bool PAIRS, bool NT, bool WIDE = false>
+template <bool USE_BVH, bool PAIRS, bool NT>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(HJ_PATH_WAVES, 8))) void k_path_wavefront(BatchState st, DeviceScene sc, uint32_t max_bounces,
                                                                   uint32_t rr_start) {
   // NT (large trees): the path state is streamed past the caches (ldp / stp)
@@ -1373,7 +1132,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
   if (groups_left != 0) {
     uint32_t k_next = 0;                     // next group of this workgroup's sample sequence
     if (threadIdx.x == 0) { sh.n_ray[0] = 0; sh.n_ray[1] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; }
-    if (USE_BVH) load_hot_nodes<WIDE>(sc, sh);
+    if (USE_BVH) load_hot_nodes(sc, sh);
     uint32_t waves = blockDim.x >> 6;
     wg_sync(waves);
     for (uint32_t parity = 0;; parity ^= 1u) {
@@ -1422,7 +1181,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
 #ifdef HJ_WALK_STATS
       const unsigned long long st_t0 = wall_clock64();
 #endif
-      stage_trace_merged<USE_BVH, PAIRS, NT, WIDE>(st, sc, g, parity, n, ns, sh);
+      stage_trace_merged<USE_BVH, PAIRS, NT>(st, sc, g, parity, n, ns, sh);
 #ifdef HJ_WALK_STATS
       const unsigned long long st_tw = wall_clock64();       // this wave has no ray left
       wg_sync(waves);                        // (diagnostic build only: the walk ends for all waves before the compaction is timed)
@@ -1552,7 +1311,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_debug_trace(DeviceScene sc, c
   const float* r8 = rays + (size_t)i * 8;
   Ray r; r.o = V(r8[0], r8[1], r8[2]); r.d = V(r8[3], r8[4], r8[5]); r.tmin = r8[6]; r.tmax = r8[7];
   RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f;
-  const bool hit = (USE_BVH && sc.wnodes != nullptr) ? traverse_wide<(int)kWideK, ANYHIT>(sc, r, h) : traverse<USE_BVH, ANYHIT>(sc, r, h);
+  const bool hit = traverse<USE_BVH, ANYHIT>(sc, r, h);
   hits[i] = make_float4(__int_as_float(hit ? h.id : -1), hit ? h.t : 0.f, hit ? h.u : 0.f, hit ? h.v : 0.f);
 }
 

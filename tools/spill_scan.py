@@ -14,14 +14,14 @@ cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ff
 subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 s = open(asm).read().split("\n")
 for i0, line in enumerate(s):
-    m = re.match(r"^(_ZN2hj16k_path_wavefrontILb([01])ELb([01])ELb([01])ELb([01])E\S*): ;", line)
+    m = re.match(r"^(_ZN2hj16k_path_wavefrontILb([01])ELb([01])ELb([01])E\S*): ;", line)
     if not m:
         continue
     end = next(i for i in range(i0, len(s)) if s[i].startswith(".Lfunc_end"))
     body = s[i0:end]
     fetch = [k for k, l in enumerate(body) if "flat_load_dwordx4" in l]
     scratch = [(k, l.strip().split(";")[0].strip()) for k, l in enumerate(body) if "scratch_" in l]
-    print(f"k_path_wavefront<USE_BVH={m.group(2)}, PAIRS={m.group(3)}, NT={m.group(4)}, WIDE={m.group(5)}>: {len(body)} lines, {len(scratch)} scratch instructions")
+    print(f"k_path_wavefront<USE_BVH={m.group(2)}, PAIRS={m.group(3)}, NT={m.group(4)}>: {len(body)} lines, {len(scratch)} scratch instructions")
     if fetch:
         # The walk = the loops nested inside the round loop of the kernel (depth 1): trace_persistent's for(;;) is depth 2, its
         # box-step loop depth 3; top-up, hit compaction and shade are calls and have no loops here.  The assembly printer
