@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -1697,15 +1698,20 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
   std::vector<uint32_t> cbase(K, 0), cexit(K, 0);
   {
     using Records = std::vector<std::pair<uint32_t, hj_bvh_node>>;
-    struct Task { size_t a, b; uint32_t pos, exit; int depth; };
+    // A node of the host-built part: a leaf stands for one item (a cluster's subtree or a large shape) or, in the part above
+    // the worker tasks, for a whole task subtree (`sub`); an inner node keeps its children's boxes (what the reference's
+    // flattened records hold: a node's box is the one its PARENT kept for it, src/main.rs:214-231).
+    struct TNode { int32_t left = -1, right = -1, item = -1, sub = -1; float lo[2][3], hi[2][3]; uint32_t records = 0; float weight = 0; };
+    struct Tree { std::vector<TNode> n; };
+    struct Task { size_t a, b; int depth; };
     struct Builder {
       std::vector<Item>& items;
-      std::vector<uint32_t>& cbase;
-      std::vector<uint32_t>& cexit;
       std::vector<uint32_t> ids;
       size_t task_items = 0;                  // subtrees of at most this many items are set aside as tasks (0: never)
       int child_order = 3;                    // HJ_BVH_CHILD_ORDER (0: as split)
+      int rotate_passes = 8;                  // HJ_BVH_ROTATE
       std::vector<Task> tasks;
+      std::vector<Tree> task_trees;
       static float area(const float* lo, const float* hi) {
         const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
         return (dx >= 0 && dy >= 0 && dz >= 0) ? dx * dy + dy * dz + dz * dx : 0.f;
@@ -1713,29 +1719,29 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
       static void grow(float* lo, float* hi, const float* alo, const float* ahi) {
         for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], alo[k]); hi[k] = std::fmax(hi[k], ahi[k]); }
       }
-      // records of the subtree over ids[a, b): the items' own records + one inner record per split
-      uint32_t records(size_t a, size_t b) const {
-        uint32_t r = (uint32_t)(b - a) - 1;
-        for (size_t i = a; i < b; i++) r += items[ids[i]].records;
-        return r;
+      void bounds(size_t a, size_t b, float* lo, float* hi) const {
+        for (int k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+        for (size_t i = a; i < b; i++) grow(lo, hi, items[ids[i]].lo, items[ids[i]].hi);
       }
-      // pre-order (src/main.rs:203-231); `defer`: subtrees small enough become tasks for the worker threads instead
-      void emit(Records& out, size_t a, size_t b, uint32_t pos, uint32_t exit, int depth, bool defer) {
+      // binned-SAH tree over ids[a, b) into t; `defer`: subtrees small enough become tasks (leaves with `sub` = task number)
+      int32_t build(Tree& t, size_t a, size_t b, int depth, bool defer) {
+        const int32_t me = (int32_t)t.n.size();
+        t.n.emplace_back();
         if (b - a == 1) {
           const Item& it = items[ids[a]];
-          if (it.shape == HJ_BVH_INNER) { cbase[it.cluster] = pos; cexit[it.cluster] = exit; return; }
-          hj_bvh_node nd;
-          for (int k = 0; k < 3; k++) { nd.aabb_min[k] = it.lo[k]; nd.aabb_max[k] = it.hi[k]; }
-          nd.shape_index = it.shape; nd.exit_index = exit;
-          out.emplace_back(pos, nd);
-          return;
+          t.n[me].item = (int32_t)ids[a]; t.n[me].records = it.records; t.n[me].weight = it.weight;
+          return me;
         }
-        if (defer && b - a <= task_items) { tasks.push_back(Task{a, b, pos, exit, depth}); return; }
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        if (defer && b - a <= task_items) {
+          uint32_t rec = (uint32_t)(b - a) - 1; float w = 0.f;
+          for (size_t i = a; i < b; i++) { rec += items[ids[i]].records; w += items[ids[i]].weight; }
+          t.n[me].sub = (int32_t)tasks.size(); t.n[me].records = rec; t.n[me].weight = w;
+          tasks.push_back(Task{a, b, depth});
+          return me;
+        }
         float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (size_t i = a; i < b; i++) {
           const Item& it = items[ids[i]];
-          grow(lo, hi, it.lo, it.hi);
           for (int k = 0; k < 3; k++) { const float c = it.lo[k] + it.hi[k]; clo[k] = std::fmin(clo[k], c); chi[k] = std::fmax(chi[k], c); }
         }
         // binned SAH, 16 bins per axis, the three axes in one pass over the items: cost = area(L) * weight(L) + area(R) * weight(R)
@@ -1785,40 +1791,143 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
           mid = (size_t)(std::stable_partition(ids.begin() + (std::ptrdiff_t)a, ids.begin() + (std::ptrdiff_t)b, left_of) - ids.begin());
           if (mid == a || mid == b) mid = a + (b - a) / 2;
         }
-        {
-          // the side with fewer shapes first (host/scene.cpp order_children: what the first child's walk finds culls the second)
-          float wl = 0.f, wr = 0.f;
-          for (size_t i = a; i < mid; i++) wl += items[ids[i]].weight;
-          for (size_t i = mid; i < b; i++) wr += items[ids[i]].weight;
-          if (wr < wl && child_order != 0) {
-            std::rotate(ids.begin() + (std::ptrdiff_t)a, ids.begin() + (std::ptrdiff_t)mid, ids.begin() + (std::ptrdiff_t)b);
-            mid = a + (b - mid);
+        float lo2[2][3], hi2[2][3];
+        bounds(a, mid, lo2[0], hi2[0]);
+        bounds(mid, b, lo2[1], hi2[1]);
+        const int32_t l = build(t, a, mid, depth + 1, defer), r = build(t, mid, b, depth + 1, defer);
+        TNode& nd = t.n[me];
+        nd.left = l; nd.right = r;
+        for (int c = 0; c < 2; c++) for (int k = 0; k < 3; k++) { nd.lo[c][k] = lo2[c][k]; nd.hi[c][k] = hi2[c][k]; }
+        nd.records = 1 + t.n[l].records + t.n[r].records;
+        nd.weight = t.n[l].weight + t.n[r].weight;
+        return me;
+      }
+      // Tree rotations (host/scene.cpp Rotator; Kensler 2008): for a node with children A and B, B goes down into A in exchange
+      // for one of A's children when that shrinks A's box most, or two grandchildren swap across; bottom-up, pass after pass.
+      static float joined_area(const float* alo, const float* ahi, const float* blo, const float* bhi) {
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; k++) { lo[k] = std::fmin(alo[k], blo[k]); hi[k] = std::fmax(ahi[k], bhi[k]); }
+        return area(lo, hi);
+      }
+      static void refresh(Tree& t, int32_t nd) {                     // sums of an inner node after its children changed
+        TNode& n = t.n[nd];
+        n.records = 1 + t.n[n.left].records + t.n[n.right].records;
+        n.weight = t.n[n.left].weight + t.n[n.right].weight;
+      }
+      static void set_box(TNode& n, int c, const TNode& child) {     // n's box for child c = union of that child's two boxes
+        for (int k = 0; k < 3; k++) { n.lo[c][k] = std::fmin(child.lo[0][k], child.lo[1][k]); n.hi[c][k] = std::fmax(child.hi[0][k], child.hi[1][k]); }
+      }
+      double rotate(Tree& t, int32_t root) {
+        double gain = 0;
+        std::vector<int32_t> post, st{root};                        // post-order without recursion (chains can be deep)
+        while (!st.empty()) {
+          const int32_t i = st.back(); st.pop_back();
+          if (t.n[i].left < 0) continue;
+          post.push_back(i);
+          st.push_back(t.n[i].left); st.push_back(t.n[i].right);
+        }
+        for (size_t k = post.size(); k-- > 0;) {
+          TNode& n = t.n[post[k]];
+          int32_t* ch[2] = {&n.left, &n.right};
+          float best = 0.f; int bo = -1, bg = -1, xg = -1;
+          for (int o = 0; o < 2; o++) {                              // child o is opened, the other child goes down into it
+            const TNode& a = t.n[*ch[o]];
+            if (a.left < 0) continue;
+            for (int g = 0; g < 2; g++) {                            // a's child g comes up, a's child 1 - g stays
+              const float delta = joined_area(a.lo[1 - g], a.hi[1 - g], n.lo[1 - o], n.hi[1 - o]) - area(n.lo[o], n.hi[o]);
+              if (delta < best) { best = delta; bo = o; bg = g; }
+            }
+          }
+          if (t.n[n.left].left >= 0 && t.n[n.right].left >= 0) {     // grandchildren across: left's child g with right's child 0
+            const TNode &a = t.n[n.left], &c = t.n[n.right];
+            for (int g = 0; g < 2; g++) {
+              const float delta = joined_area(a.lo[1 - g], a.hi[1 - g], c.lo[0], c.hi[0]) + joined_area(c.lo[1], c.hi[1], a.lo[g], a.hi[g])
+                                  - area(n.lo[0], n.hi[0]) - area(n.lo[1], n.hi[1]);
+              if (delta < best) { best = delta; bo = -1; xg = g; }
+            }
+          }
+          if (xg >= 0) {
+            TNode &a = t.n[n.left], &c = t.n[n.right];
+            int32_t& ai = xg == 0 ? a.left : a.right;
+            std::swap(ai, c.left);
+            for (int k2 = 0; k2 < 3; k2++) { std::swap(a.lo[xg][k2], c.lo[0][k2]); std::swap(a.hi[xg][k2], c.hi[0][k2]); }
+            refresh(t, n.left); refresh(t, n.right);
+            set_box(n, 0, a); set_box(n, 1, c);
+            gain -= best;
+          } else if (bo >= 0) {
+            TNode& a = t.n[*ch[bo]];
+            int32_t& up = bg == 0 ? a.left : a.right;
+            std::swap(*ch[1 - bo], up);
+            for (int k2 = 0; k2 < 3; k2++) { std::swap(n.lo[1 - bo][k2], a.lo[bg][k2]); std::swap(n.hi[1 - bo][k2], a.hi[bg][k2]); }
+            refresh(t, *ch[bo]);
+            set_box(n, bo, a);
+            gain -= best;
           }
         }
-        hj_bvh_node nd;
-        for (int k = 0; k < 3; k++) { nd.aabb_min[k] = lo[k]; nd.aabb_max[k] = hi[k]; }
-        nd.shape_index = HJ_BVH_INNER; nd.exit_index = exit;
-        out.emplace_back(pos, nd);
-        const uint32_t right_pos = pos + 1 + records(a, mid);
-        emit(out, a, mid, pos + 1, right_pos, depth + 1, defer);        // exit of a left child = its sibling
-        emit(out, mid, b, right_pos, exit, depth + 1, defer);           // a right child inherits its parent's exit
+        return gain;
       }
-    } builder{items, cbase, cexit, {}, 0, env_int("HJ_BVH_CHILD_ORDER", 3, 0, 9), {}};
+      void polish(Tree& t, int32_t root) {
+        for (int p = 0; p < rotate_passes && t.n[root].left >= 0; p++)
+          if (rotate(t, root) <= 0) break;
+      }
+      // records in pre-order (src/main.rs:203-231), the child with fewer shapes first (host/scene.cpp order_children)
+      void emit(const Tree& t, int32_t nd, const float* lo, const float* hi, uint32_t pos, uint32_t exit, Records& out,
+                std::vector<uint32_t>& cbase, std::vector<uint32_t>& cexit, std::vector<std::array<uint32_t, 2>>* task_place) const {
+        struct F { int32_t nd; float lo[3], hi[3]; uint32_t pos, exit; };
+        std::vector<F> st;
+        F f0; f0.nd = nd; f0.pos = pos; f0.exit = exit;
+        for (int k = 0; k < 3; k++) { f0.lo[k] = lo[k]; f0.hi[k] = hi[k]; }
+        st.push_back(f0);
+        while (!st.empty()) {
+          const F f = st.back(); st.pop_back();
+          const TNode& n = t.n[f.nd];
+          if (n.sub >= 0) { (*task_place)[(size_t)n.sub] = {f.pos, f.exit}; continue; }
+          if (n.item >= 0) {
+            const Item& it = items[(size_t)n.item];
+            if (it.shape == HJ_BVH_INNER) { cbase[it.cluster] = f.pos; cexit[it.cluster] = f.exit; continue; }
+            hj_bvh_node rec;
+            for (int k = 0; k < 3; k++) { rec.aabb_min[k] = it.lo[k]; rec.aabb_max[k] = it.hi[k]; }
+            rec.shape_index = it.shape; rec.exit_index = f.exit;
+            out.emplace_back(f.pos, rec);
+            continue;
+          }
+          hj_bvh_node rec;
+          for (int k = 0; k < 3; k++) { rec.aabb_min[k] = f.lo[k]; rec.aabb_max[k] = f.hi[k]; }
+          rec.shape_index = HJ_BVH_INNER; rec.exit_index = f.exit;
+          out.emplace_back(f.pos, rec);
+          int first = 0;
+          if (child_order != 0) {
+            const float wl = t.n[n.left].weight, wr = t.n[n.right].weight;
+            if (wr < wl || (wr == wl && area(n.lo[1], n.hi[1]) < area(n.lo[0], n.hi[0]))) first = 1;
+          }
+          const int32_t c0 = first == 0 ? n.left : n.right, c1 = first == 0 ? n.right : n.left;
+          const uint32_t right_pos = f.pos + 1 + t.n[c0].records;
+          F a, b2;
+          a.nd = c0; a.pos = f.pos + 1; a.exit = right_pos;           // exit of a first child = its sibling
+          b2.nd = c1; b2.pos = right_pos; b2.exit = f.exit;            // a second child inherits its parent's exit
+          for (int k = 0; k < 3; k++) { a.lo[k] = n.lo[first][k]; a.hi[k] = n.hi[first][k]; b2.lo[k] = n.lo[1 - first][k]; b2.hi[k] = n.hi[1 - first][k]; }
+          st.push_back(b2); st.push_back(a);
+        }
+      }
+    } builder{items, {}, 0, env_int("HJ_BVH_CHILD_ORDER", 3, 0, 9), env_int("HJ_BVH_ROTATE", 8, 0, 64), {}, {}};
     builder.ids.resize(items.size());
     for (size_t k = 0; k < items.size(); k++) builder.ids[k] = (uint32_t)k;
-    // The top levels here, the subtrees below them on worker threads (disjoint ranges of ids[], disjoint records, disjoint
-    // clusters: nothing is shared but read-only data).  Every level costs one pass over all items, so this leaves about
-    // five sequential passes of the ~17 a 25 000-cluster tree takes.
+    // The top levels here, the subtrees below them on worker threads (disjoint ranges of ids[], nothing shared but read-only
+    // data): build + rotation passes per subtree in parallel, then the rotation passes over the part above them (its leaves
+    // are the finished subtrees), then the records.
     const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     builder.task_items = hw > 1 && items.size() >= 4096 ? items.size() / (4 * hw) : 0;
-    builder.emit(top_records, 0, items.size(), 0, root_exit, 0, builder.task_items != 0);
+    Tree top;
+    const int32_t top_root = builder.build(top, 0, items.size(), 0, builder.task_items != 0);
+    builder.task_trees.resize(builder.tasks.size());
     if (!builder.tasks.empty()) {
-      std::vector<Records> parts(builder.tasks.size());
       std::atomic<size_t> next{0};
       auto work = [&]() {
         for (size_t i; (i = next.fetch_add(1)) < builder.tasks.size();) {
           const Task& tk = builder.tasks[i];
-          builder.emit(parts[i], tk.a, tk.b, tk.pos, tk.exit, tk.depth, false);
+          Tree& tt = builder.task_trees[i];
+          const int32_t r = builder.build(tt, tk.a, tk.b, tk.depth, false);
+          builder.polish(tt, r);
         }
       };
       std::vector<std::thread> pool;
@@ -1827,7 +1936,17 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
       } catch (const std::exception&) {}                               // fewer threads than asked for: the rest is done here
       work();
       for (auto& th : pool) th.join();
-      for (const Records& part : parts) top_records.insert(top_records.end(), part.begin(), part.end());
+    }
+    builder.polish(top, top_root);
+    float rlo[3], rhi[3];
+    builder.bounds(0, items.size(), rlo, rhi);
+    std::vector<std::array<uint32_t, 2>> place(builder.tasks.size());
+    builder.emit(top, top_root, rlo, rhi, 0, root_exit, top_records, cbase, cexit, &place);
+    for (size_t i = 0; i < builder.tasks.size(); i++) {
+      const Task& tk = builder.tasks[i];
+      float lo[3], hi[3];
+      builder.bounds(tk.a, tk.b, lo, hi);
+      builder.emit(builder.task_trees[i], 0, lo, hi, place[i][0], place[i][1], top_records, cbase, cexit, nullptr);
     }
   }
   mark("host SAH over the clusters");

@@ -237,10 +237,16 @@ typedef struct {
   hjo_counters* ctr;
 } scene_t;
 
-typedef struct { uint64_t *nodes, *tri, *sphere, *quad; uint32_t* hist; } walk_ctr;
-static inline walk_ctr closest_ctr(hjo_counters* c) { walk_ctr w = {&c->nodes, &c->tri_tests, &c->sphere_tests, &c->quad_tests, NULL}; return w; }
+typedef struct { uint64_t *nodes, *tri, *sphere, *quad; uint32_t* hist; int anyhit; } walk_ctr;
+/* CPU-BASELINE switch (bench.py's cpu_baseline leg only; parity runs never set it): shadow rays stop at their first
+ * accepted hit, as a production CPU renderer (Nori) does, instead of the reference's full closest-hit walk
+ * (scene.glsl:92-96 "TODO: optimize").  The shadow overload only uses the boolean, and the first accepted hit in visiting
+ * order is the same with or without tMax shrinking, so the image is identical (tests/test_oracle_shading.py checks). */
+static int g_shadow_anyhit = 0;
+HJO_EXPORT void hjo_set_shadow_anyhit(int on) { g_shadow_anyhit = on; }
+static inline walk_ctr closest_ctr(hjo_counters* c) { walk_ctr w = {&c->nodes, &c->tri_tests, &c->sphere_tests, &c->quad_tests, NULL, 0}; return w; }
 static inline walk_ctr shadow_ctr(hjo_counters* c) {
-  walk_ctr w = {&c->shadow_nodes, &c->shadow_tri_tests, &c->shadow_sphere_tests, &c->shadow_quad_tests, NULL}; return w;
+  walk_ctr w = {&c->shadow_nodes, &c->shadow_tri_tests, &c->shadow_sphere_tests, &c->shadow_quad_tests, NULL, g_shadow_anyhit}; return w;
 }
 
 static inline v3 ld3(const float* p) { return V(p[0], p[1], p[2]); }
@@ -360,7 +366,7 @@ static int intersect_scene(const scene_t* S, ray_t ray, its_t* its, walk_ctr c) 
         if (shape < ns) { hit = intersect_sphere(&ray, &S->sc->spheres[shape], its); (*c.sphere)++; }
         else if (shape < ns + nq) { hit = intersect_quad(&ray, &S->sc->quads[shape - ns], its); (*c.quad)++; }
         else { hit = intersect_triangle(S, &ray, shape - ns - nq, its); (*c.tri)++; }
-        if (hit) { ray.tmax = its->t - M_EPSF; its->id = (int)shape; }
+        if (hit) { ray.tmax = its->t - M_EPSF; its->id = (int)shape; if (c.anyhit) return 1; }
         cur = ex;
       } else {
         float tnx = fmaf(nd->aabb_min[0], inv.x, off.x), tpx = fmaf(nd->aabb_max[0], inv.x, off.x);

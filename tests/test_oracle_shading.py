@@ -148,3 +148,21 @@ def test_direct_light_on_floor_matches_numeric_integral(oracle):
     integral = ((4.0 / np.sqrt(d2)) ** 2 / d2).mean() * 1.0
     want = 0.8 / np.pi * 10.0 * integral
     assert abs(got[0] - want) / want < 0.03, (got, want)
+
+
+def test_anyhit_shadow_switch_of_the_cpu_baseline_changes_no_bit(oracle, cbox_small):
+    """bench.py times the oracle with shadow rays that stop at their first accepted hit (a production CPU renderer's
+    behaviour; the reference walks on, scene.glsl:92-96).  The shadow overload only uses the boolean: same image, fewer
+    shadow node visits."""
+    from hijiki_amd import host
+    W = H = 64
+    blocks = host.make_blocks(W, H, 4, 3)
+    want, c0, _ = oracle.render_blocks(cbox_small, blocks, W, H)
+    oracle.lib().hjo_set_shadow_anyhit(1)
+    try:
+        got, c1, _ = oracle.render_blocks(cbox_small, blocks, W, H)
+    finally:
+        oracle.lib().hjo_set_shadow_anyhit(0)
+    assert (got.view("uint32") == want.view("uint32")).all()
+    assert c1["shadow_calls"] == c0["shadow_calls"] and c1["shadow_hits"] == c0["shadow_hits"]
+    assert c1["shadow_nodes"] < c0["shadow_nodes"] and c1["nodes"] == c0["nodes"]

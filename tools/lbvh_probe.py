@@ -1,21 +1,38 @@
-"""Device-built LBVH vs host-built SAH tree: build time and frame rate (cbox and the 1 M-triangle mesh)."""
+"""Device-built LBVH vs host-built SAH tree: build time and frame rate (cbox and the 1 M-triangle mesh).
+
+    python tools/lbvh_probe.py [--variants]      --variants: the device build with / without the rotation passes over its
+                                                 host-built top (HJ_BVH_ROTATE)
+"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hijiki_amd import host, device
 r = device.Renderer(0)
-for name, kind, tris, size, spp in (("cbox", host.SYNTH_CBOX, 0, 1024, 64), ("1 M-triangle mesh", host.SYNTH_CBOX_MESH, 1000000, 2048, 16)):
+variants = [("default", {})]
+if "--variants" in sys.argv:
+    variants += [("no rotations", {"HJ_BVH_ROTATE": "0"})]
+for name, kind, tris, size, spp in (("cbox", host.SYNTH_CBOX, 0, 1024, 128), ("1 M-triangle mesh", host.SYNTH_CBOX_MESH, 1000000, 2048, 32)):
     s = host.Scene.synthetic(kind, mesh_triangles=tris)
-    t = time.time(); cs = s.compile(); t_host = time.time() - t
-    r.build_bvh(cs)                                   # warm-up (module load, allocations)
-    t = time.time(); nodes = r.build_bvh(cs); t_dev = time.time() - t
-    rates = {}
-    for label in ("SAH (host)", "LBVH (device)"):
-        if label.startswith("LBVH"):
-            cs.set_bvh(nodes)
+    t = time.time(); cs = s.compile(); t_host = time.time() - t          # (the host tree: built with the environment as it is)
+    host_nodes = cs.bvh.copy()
+
+    def rate():
         r.upload_scene(cs); r.create_framebuffer(size, size)
         best = 1e9
-        for _ in range(3):
-            r.clear(); t = time.time(); st = r.render_frame(spp, 1); best = min(best, time.time() - t)
-        rates[label] = (size * size * spp / best / 1e6, (st["closest_rays"] + st["shadow_rays"]) / st["paths"])
-    print(f"{name}: {cs.desc.num_bvh_nodes} nodes; host compile {t_host*1e3:.0f} ms, device build {t_dev*1e3:.1f} ms; " +
-          "; ".join(f"{k}: {v[0]:.0f} Mpaths/s" for k, v in rates.items()), flush=True)
+        for _ in range(4):
+            r.clear(); t = time.time(); r.render_frame(spp, 1); best = min(best, time.time() - t)
+        return size * size * spp / best / 1e6
+
+    base = rate()
+    print(f"{name}: {cs.desc.num_bvh_nodes} nodes; host compile {t_host*1e3:.0f} ms: {base:.0f} Mpaths/s", flush=True)
+    for label, env in variants:
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        r.build_bvh(cs)                                   # warm-up (module load, allocations)
+        t = time.time(); nodes = r.build_bvh(cs); t_dev = time.time() - t
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+        cs.set_bvh(nodes)
+        v = rate()
+        cs.set_bvh(host_nodes)
+        print(f"  device build ({label}): {t_dev*1e3:.1f} ms, {v:.0f} Mpaths/s = {v / base:.3f} of the host tree", flush=True)
