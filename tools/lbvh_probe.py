@@ -1,7 +1,7 @@
 """Device-built LBVH vs host-built SAH tree: build time and frame rate (cbox and the 1 M-triangle mesh).
 
     python tools/lbvh_probe.py [--variants]      --variants: the device build with / without the rotation passes over its
-                                                 host-built top (HJ_BVH_ROTATE)
+                                                 host-built top (HJ_LBVH_TOP_ROTATE)
 """
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,7 @@ from hijiki_amd import host, device
 r = device.Renderer(0)
 variants = [("default", {})]
 if "--variants" in sys.argv:
-    variants += [("no rotations", {"HJ_BVH_ROTATE": "0"})]
+    variants += [("no rotations", {"HJ_LBVH_TOP_ROTATE": "0"}), ("rotations", {"HJ_LBVH_TOP_ROTATE": "8"})]
 for name, kind, tris, size, spp in (("cbox", host.SYNTH_CBOX, 0, 1024, 128), ("1 M-triangle mesh", host.SYNTH_CBOX_MESH, 1000000, 2048, 32)):
     s = host.Scene.synthetic(kind, mesh_triangles=tris)
     t = time.time(); cs = s.compile(); t_host = time.time() - t          # (the host tree: built with the environment as it is)
