@@ -10,7 +10,9 @@ r = device.Renderer(0)
 variants = [("default", {})]
 if "--variants" in sys.argv:
     variants += [("no rotations", {"HJ_LBVH_TOP_ROTATE": "0"}), ("rotations", {"HJ_LBVH_TOP_ROTATE": "8"})]
-for name, kind, tris, size, spp in (("cbox", host.SYNTH_CBOX, 0, 1024, 128), ("1 M-triangle mesh", host.SYNTH_CBOX_MESH, 1000000, 2048, 32)):
+# (the configurations' own sample counts: small frames run smaller batches, and the trees rank differently there - at 32 spp the
+# device-built tree of the mesh is 2 % AHEAD of the host's, at the benchmark's 256 spp 2.5 % behind)
+for name, kind, tris, size, spp in (("cbox", host.SYNTH_CBOX, 0, 1024, 512), ("1 M-triangle mesh", host.SYNTH_CBOX_MESH, 1000000, 2048, 256)):
     s = host.Scene.synthetic(kind, mesh_triangles=tris)
     t = time.time(); cs = s.compile(); t_host = time.time() - t          # (the host tree: built with the environment as it is)
     host_nodes = cs.bvh.copy()
@@ -18,7 +20,7 @@ for name, kind, tris, size, spp in (("cbox", host.SYNTH_CBOX, 0, 1024, 128), ("1
     def rate():
         r.upload_scene(cs); r.create_framebuffer(size, size)
         best = 1e9
-        for _ in range(4):
+        for _ in range(3):
             r.clear(); t = time.time(); r.render_frame(spp, 1); best = min(best, time.time() - t)
         return size * size * spp / best / 1e6
 

@@ -15,7 +15,10 @@ kind = int(argv[0]) if len(argv) > 0 else host.SYNTH_CBOX
 max_bounces = int(argv[1]) if len(argv) > 1 else 0     # 1 = camera rays and their shadow rays only
 spp = int(os.environ.get("HJ_STATS_SPP", "512")); size = int(os.environ.get("HJ_STATS_SIZE", "1024"))
 cs = host.Scene.synthetic(kind, mesh_triangles=int(os.environ.get("HJ_STATS_TRIS", "0"))).compile()
-r = device.Renderer(0); r.upload_scene(cs); r.create_framebuffer(size, size)
+r = device.Renderer(0)
+if os.environ.get("HJ_STATS_DEVICE_BVH") == "1":        # the tree bench.py's c4 uses
+    cs.set_bvh(r.build_bvh(cs))
+r.upload_scene(cs); r.create_framebuffer(size, size)
 L = device.lib()
 out = (C.c_ulonglong * 16)()
 L.hj_debug_walk_stats(out, 1)
