@@ -31,7 +31,7 @@ if [ -f build/variants/var_stats.so ]; then
   case $cfg in
     c2) HJ_STATS_SPP=512 timeout 300 python3 tools/walk_stats.py 0 --json $out/walk_stats.json > $out/walk_stats.txt 2>&1 ;;
     c3) HJ_STATS_SPP=1024 timeout 300 python3 tools/walk_stats.py 1 --json $out/walk_stats.json > $out/walk_stats.txt 2>&1 ;;
-    c4) HJ_STATS_DEVICE_BVH=1 HJ_STATS_SPP=256 HJ_STATS_SIZE=2048 HJ_STATS_TRIS=1000000 timeout 300 python3 tools/walk_stats.py 2 --json $out/walk_stats.json > $out/walk_stats.txt 2>&1 ;;
+    c4) HJ_STATS_SPP=256 HJ_STATS_SIZE=2048 HJ_STATS_TRIS=1000000 timeout 300 python3 tools/walk_stats.py 2 --json $out/walk_stats.json > $out/walk_stats.txt 2>&1 ;;
   esac
 fi
 # the inputs first, in place (profiles/ of this copy of the tree), so that the un-profiled bench line below quotes THESE counters
