@@ -91,7 +91,8 @@ struct hj_context {
   } slots[kMaxSlots];
   uint32_t num_slots = 3;
   uint32_t num_wg = 2048;                // grid size of every path kernel (= queue segments)
-  uint32_t pool = 8192;                  // path slots per workgroup of the fused kernel (HJ_POOL)
+  uint32_t pool = 65536;                 // path slots per workgroup of the fused kernel (HJ_POOL)
+  uint32_t pool_eff = 65536;             // ... as the current render call uses it (lowered when device memory is short)
 
   // timing
   std::vector<EventPair> events;
@@ -257,7 +258,7 @@ int ensure_batch(hj_context* ctx, hj_context::BatchSlot& sl, uint32_t num_blocks
   const uint32_t cap = num_blocks * hj::kSlotsPerBlock;
   const uint32_t G = ctx->num_wg;
   const uint32_t per_wg = (((cap + 63u) / 64u + G - 1u) / G) * 64u;     // samples of the busiest workgroup
-  const uint32_t pool = all_in_flight ? per_wg : std::min(per_wg, ctx->pool);
+  const uint32_t pool = all_in_flight ? per_wg : std::min(per_wg, ctx->pool_eff);
   hj::BatchState& st = sl.st;
   int rc = HJ_OK;
   auto alloc = [&](std::vector<DevBuf>& bufs, size_t bytes, void** out) -> int {
@@ -636,7 +637,10 @@ int hj_context_create(int device, hj_context** out) {
   // Tuning knobs (environment overrides exist only for sweeps; the defaults are the measured optima).
   ctx->num_wg = (uint32_t)ctx->num_cus * (uint32_t)env_int("HJ_WG_PER_CU", 8, 1, 32);   // 8 x 4 waves = the 32-wave CU limit
   ctx->num_slots = (uint32_t)env_int("HJ_SLOTS", 3, 1, (int)kMaxSlots);
-  ctx->pool = (uint32_t)env_int("HJ_POOL", 8192, 64, 1 << 20) / 64u * 64u;
+  // positions per workgroup: 65536 = every sample of a workgroup's share of an 8192-block batch in flight at once (the walk
+  // phases of a round are long, their ramp-down costs once per round: c2 +6 %, c3 +4 % over 8192 positions with path
+  // regeneration; 32768: +4.5 %; 24.7 GB of path state per batch slot, lowered by run_begin when the device is short of memory)
+  ctx->pool = (uint32_t)env_int("HJ_POOL", 65536, 64, 1 << 20) / 64u * 64u;
   for (auto& sl : ctx->slots) {
     if ((e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     if ((e = hipHostMalloc((void**)&sl.h_counts, sizeof(uint32_t) * 6 * ctx->num_wg, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
@@ -1065,15 +1069,16 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
   // per batch beats an eighth by 3.4 / 1.6 / 0.8 / 0.8 %, a half loses 3-5 %).  Path state does not grow with the batch
   // (pool), only the sample buffers do (0.5 GB per 1024 blocks).
   const size_t n = total_blocks;
-  static const size_t batch_cap = (size_t)env_int("HJ_BATCH_CAP", 8192, 64, 8192);
+  static const size_t batch_cap = (size_t)env_int("HJ_BATCH_CAP", 8192, 64, 32768);
   run.batch = run.o.batch_blocks ? run.o.batch_blocks
                                  : (uint32_t)std::min<size_t>(batch_cap, std::max<size_t>(256, ((n + 3) / 4 + 63) / 64 * 64));
-  run.batch = std::min<uint32_t>(run.batch, run.split ? 2048u : 8192u);   // the split path keeps every sample of a batch in flight
+  run.batch = std::min<uint32_t>(run.batch, run.split ? 2048u : 32768u);   // (a sample index has 31 bits: 131 072 blocks at most)   // the split path keeps every sample of a batch in flight
   // Footprint: per batch slot 512 KB of samples per ImageBlock of the batch + num_wg x pool positions of
-  // path state (164 B each, 196 B with tinted dielectrics): 4 + 2.75 GB per slot at the defaults, three slots.  A DEFAULT
-  // batch that does not fit the device's free memory (other contexts on the GPU, the host application) is halved until
-  // it does; an explicit hj_render_opts::batch_blocks is taken as given and fails with HJ_ERR_NOMEM if it does not fit.
-  if (!run.o.batch_blocks && !run.split) {
+  // path state (184 B each, 216 B with tinted dielectrics).  DEFAULTS that do not fit the device's free memory (other
+  // contexts on the GPU, the host application) shrink until they do: first the pool (down to 8192 positions), then the
+  // batch; an explicit hj_render_opts::batch_blocks is taken as given and fails with HJ_ERR_NOMEM if it does not fit.
+  ctx->pool_eff = ctx->pool;
+  if (!run.split) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
       size_t held = 0;
@@ -1081,15 +1086,20 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
         for (auto& b : sl.bufs) held += b.bytes;
         for (auto& b : sl.sample_bufs) held += b.bytes;
       }
-      const size_t slots_needed = std::min<size_t>(ctx->num_slots, (n + run.batch - 1) / std::max<uint32_t>(run.batch, 1u));
-      auto need = [&](uint32_t batch) {
+      auto need = [&](uint32_t batch, uint32_t pool_cap) {
+        const size_t slots_needed = std::max<size_t>(1, std::min<size_t>(ctx->num_slots, (n + batch - 1) / std::max<uint32_t>(batch, 1u)));
         const size_t per_wg = ((((size_t)batch * hj::kSlotsPerBlock + 63) / 64 + ctx->num_wg - 1) / ctx->num_wg) * 64;
-        const size_t pool = std::min<size_t>(per_wg, ctx->pool);
+        const size_t pool = std::min<size_t>(per_wg, pool_cap);
         const size_t state = (size_t)ctx->num_wg * pool * (ctx->scene.has_extinction ? 196u + 20u : 164u + 20u);
-        return std::max<size_t>(1, slots_needed) * (state + (size_t)batch * hj::kSlotsPerBlock * 32u);
+        return slots_needed * (state + (size_t)batch * hj::kSlotsPerBlock * 32u);
       };
       const size_t margin = (size_t)512 << 20;
-      while (run.batch > 64 && need(run.batch) > held + (free_b > margin ? free_b - margin : 0)) run.batch = std::max(64u, run.batch / 2 / 64 * 64);
+      const size_t avail = held + (free_b > margin ? free_b - margin : 0);
+      while (need(run.batch, ctx->pool_eff) > avail) {
+        if (ctx->pool_eff > 8192) ctx->pool_eff = std::max(8192u, ctx->pool_eff / 2 / 64 * 64);
+        else if (!run.o.batch_blocks && run.batch > 64) run.batch = std::max(64u, run.batch / 2 / 64 * 64);
+        else break;
+      }
     }
   }
   rc = sync_all(ctx);
