@@ -14,7 +14,8 @@ constexpr uint32_t kNumTags = 5;
 //   r4..r6 = triangle vertex normals
 constexpr uint32_t kEmitRecF4 = 7;
 #ifndef HJ_HOT_NODES
-#define HJ_HOT_NODES 384   // 12 KB of LDS per workgroup (256: -0.4 ... -1.3 %, 512: the same as 384, 640: -1 % on the large scene)
+#define HJ_HOT_NODES 512   // 16 KB of LDS per workgroup (at the configurations' own frame sizes, interleaved: 384: -1.2 ... -1.8 % on the two
+                           // box scenes, 640: -1 %; the 1 M-triangle scene does not care)
 #endif
 constexpr uint32_t kHotNodes = HJ_HOT_NODES;
 constexpr uint32_t kInnerFlag = 0x80000000u;

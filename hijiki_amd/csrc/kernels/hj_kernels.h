@@ -640,7 +640,7 @@ HJ_DEV v3 checkerboard(const DeviceScene& sc, uint32_t idx, float u, float v) {
 // A value every lane of the wave reads from the same LDS word: keep it in a scalar register (an LDS load lands in a VGPR).
 HJ_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-struct WgShared {                 // LDS of a path workgroup (12.4 KB)
+struct WgShared {                 // LDS of a path workgroup (16.5 KB)
   uint32_t head;                  // next unread entry of the merged queue being walked
   uint32_t cnt_hit[kNumTags];     // hits binned by material tag (this round)
   uint32_t wcnt[kBlockThreads / 64][kNumTags];   // per-wave tag counts of the ordered compaction
