@@ -1081,6 +1081,9 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
   if (!run.split) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      // HJ_MEM_LIMIT_MB (test rig): pretend that no more than this is free
+      const int limit_mb = env_int("HJ_MEM_LIMIT_MB", 0, 0, 1 << 30);
+      if (limit_mb > 0) free_b = std::min<size_t>(free_b, (size_t)limit_mb << 20);
       size_t held = 0;
       for (auto& sl : ctx->slots) {
         for (auto& b : sl.bufs) held += b.bytes;

@@ -945,3 +945,28 @@ def test_async_frame_state_and_statistics(cbox_small):
             if rc == abi.HJ_ERR_STATE:
                 assert st["paths"] == want_st["paths"] == W * H * 8 and st["closest_rays"] == want_st["closest_rays"]
                 assert (bits(r.read()) == bits(want)).all()
+
+
+@pytest.mark.gpu
+def test_defaults_shrink_to_the_free_device_memory(cbox_small, monkeypatch):
+    """A frame whose default pool and batches would take 21 GB of path state and samples, on a device that (HJ_MEM_LIMIT_MB: a test
+    rig) has 3 GB free: the render call lowers the pool, then the batch, instead of failing with HJ_ERR_NOMEM, and the frame is the
+    same bit for bit (pool and batch size steer scheduling only)."""
+    W = H = 1024
+    spp = 128
+    with device.Renderer(0) as r:
+        r.upload_scene(cbox_small)
+        r.create_framebuffer(W, H)
+        opts = device.default_opts()
+        opts.batch_blocks = 2048                       # (an explicit batch: the reference frame itself stays small)
+        st0 = r.render_frame(spp, 3, opts=opts)
+        want = r.read()
+    monkeypatch.setenv("HJ_MEM_LIMIT_MB", "3072")
+    with device.Renderer(0) as r:
+        r.upload_scene(cbox_small)
+        r.create_framebuffer(W, H)
+        st = r.render_frame(spp, 3)
+        got = r.read()
+    assert st["batches"] > st0["batches"]              # smaller batches than the default rule's 2048 blocks
+    assert st["paths"] == st0["paths"] == W * H * spp and st["closest_rays"] == st0["closest_rays"]
+    assert (bits(got) == bits(want)).all()
