@@ -329,7 +329,10 @@ def main():
     secondary = {}
     if args.config == "c2" and res["standard"] and world == 1 and not args.no_secondary:
         for name in ("c3", "c4"):
-            secondary[name] = run_config(name, CONFIGS[name], args, 3, 1, hj, barrier)
+            try:                                    # (the headline line is printed whatever happens here)
+                secondary[name] = run_config(name, CONFIGS[name], args, 3, 1, hj, barrier)
+            except Exception as e:                  # noqa: BLE001
+                secondary[name] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         paths = W * H * spp * args.steps
@@ -366,6 +369,9 @@ def main():
         if secondary:
             out["secondary"] = {}
             for name, r in secondary.items():
+                if "error" in r:
+                    out["secondary"][name] = r
+                    continue
                 c2 = CONFIGS[name]
                 p2 = r["W"] * r["H"] * r["spp"] * r["steps"]
                 out["secondary"][name] = {

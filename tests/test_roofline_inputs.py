@@ -50,4 +50,4 @@ def test_roofline_block_never_quotes_more_than_the_counters_saw():
     assert r["bound"] == "hbm" and r["limited_by"] == "latency"
     assert r["traffic"] is not None and r["achieved"] <= r["traffic"] * 1.001
     assert 0 < r["valu_issue_frac"] < 1 and 0 < r["lane_fill"] < 1
-    assert r["frac"] == round(r["achieved"] / 8000.0, 4)
+    assert abs(r["frac"] - r["achieved"] / 8000.0) < 2e-4
