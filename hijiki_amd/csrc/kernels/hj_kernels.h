@@ -642,6 +642,7 @@ HJ_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlan
 
 struct WgShared {                 // LDS of a path workgroup (16.5 KB)
   uint32_t head;                  // next unread entry of the merged queue being walked
+  uint32_t head_cam;              // next 64-ray packet of the round's new camera rays
   uint32_t cnt_hit[kNumTags];     // hits binned by material tag (this round)
   uint32_t wcnt[kBlockThreads / 64][kNumTags];   // per-wave tag counts of the ordered compaction
   uint32_t n_ray[2];              // paths in the arrays of each parity (continuing paths, written by shade)
@@ -836,6 +837,99 @@ HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint
     }
   }
   if ((threadIdx.x & 63u) == 0 && unocc != 0) atomicAdd(&sh.n_unocc, unocc);
+}
+
+// PACKET walk of the round's new camera rays: 64 consecutive queue entries (one 64-sample group of a block row when the
+// block is full) walk the device tree TOGETHER.  The node index is wave-uniform: a hot node comes from the LDS copy as a
+// broadcast read, a cold one and every shape record through the scalar cache into SGPRs - no divergent vector-memory
+// instruction at all - and every lane keeps its own state.  A lane whose box test fails at node a notes wake = exit(a) and
+// sits out until the wave arrives there: the wave goes down to a's first child when ANY lane entered, to exit(a) otherwise,
+// and whichever way it takes through a's subtree it leaves it through exit(a).  Per ray the tested boxes, the tested
+// shapes, their order and the tMax of every test are those of the merged walk, i.e. the reference's (scene.glsl:97-133).
+// Rays of a packet that point apart only lower the lane fill of the steps, never change a result, so ANY 64 entries may
+// form a packet.
+//   first / chunks: positions [first, first + 64 * chunks) of the path arrays of `parity`; results = hit records, as the
+//   merged walk writes them.  Needs sh.head_cam == 0 and the hot nodes loaded.
+#ifndef HJ_CAMERA_PACKETS
+#define HJ_CAMERA_PACKETS 1
+#endif
+typedef const __attribute__((address_space(4))) f4s* ScalarF4;        // constant address space: a uniform index gives an s_load
+HJ_DEV float4 lds4(ScalarF4 p, uint32_t i) { const f4s v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+template <bool NT>
+HJ_DEV void stage_camera_packets(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t first,
+                                 uint32_t chunks, WgShared& sh) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t seg = g * st.pool;
+  const ScalarF4 nodes = (ScalarF4)(uintptr_t)sc.nodes;
+  const ScalarF4 tris = (ScalarF4)(uintptr_t)sc.tri_isect;
+  const ScalarF4 pairs = (ScalarF4)(uintptr_t)sc.tri_pair;
+  const ScalarF4 sphs = (ScalarF4)(uintptr_t)sc.spheres;
+  const ScalarF4 quads = (ScalarF4)(uintptr_t)sc.quads;
+  const uint32_t nn = sc.num_nodes, nhot = sc.num_hot;
+  constexpr uint32_t kAwake = 0xFFFFFFFFu;
+  for (;;) {
+    const uint32_t c = lds_fetch_chunk(&sh.head_cam);
+    if (c >= 64u * chunks) break;
+    const uint32_t pos = seg + first + c + lane;
+    const float4 o4 = ldp<NT>(st.ray_o[parity], pos), d4 = ldp<NT>(st.ray_d[parity], pos);
+    Ray r;
+    r.o = xyz(o4); r.d = xyz(d4);
+    r.tmin = (__float_as_uint(o4.w) & kCameraFlag) != 0u ? kEps : 2.0f * kEps;   // render.glsl:33,132
+    r.tmax = kInf;
+    const v3 inv = V(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    const v3 off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
+    RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
+    uint32_t wake = kAwake;                  // the node at which a sleeping lane takes part again
+    uint32_t cur = sc.root;                  // wave-uniform
+    while (cur < nn) {
+      float4 n0, n1;
+      if (cur < nhot) { n0 = sh.nodes[2 * cur]; n1 = sh.nodes[2 * cur + 1]; }          // (uniform address: a broadcast read)
+      else { n0 = lds4(nodes, 2 * cur); n1 = lds4(nodes, 2 * cur + 1); }
+      const uint32_t a = __float_as_uint(n0.w), ex = __float_as_uint(n1.w);
+      if (wake == cur) wake = kAwake;
+      const bool live = wake == kAwake;
+      uint32_t nxt = ex;
+      if ((a & kInnerFlag) == 0u) {          // a leaf: its shape is tested by every lane that got here (scene.glsl:105-119)
+        if (live) {
+          bool hit;
+          if (a < sc.ns) {
+            hit = intersect_sphere(r, lds4(sphs, a), h);
+          } else if (a < sc.ns + sc.nq) {
+            const uint32_t q = 3u * (a - sc.ns);
+            hit = quad_test(r, lds4(quads, q), lds4(quads, q + 1), lds4(quads, q + 2), h);
+          } else {
+            const uint32_t t = 3u * (a - sc.ns - sc.nq);
+            hit = triangle_test(r, lds4(tris, t), lds4(tris, t + 1), lds4(tris, t + 2), h);
+          }
+          if (hit) { h.id = (int)a; r.tmax = h.t - kEps; }
+        }
+      } else {                               // scene.glsl:120-131
+        const float tnx = fmaf(n0.x, inv.x, off.x), tpx = fmaf(n1.x, inv.x, off.x);
+        const float tny = fmaf(n0.y, inv.y, off.y), tpy = fmaf(n1.y, inv.y, off.y);
+        const float tnz = fmaf(n0.z, inv.z, off.z), tpz = fmaf(n1.z, inv.z, off.z);
+        const float t0 = f_max(f_max(f_min(tnx, tpx), f_min(tny, tpy)), f_min(tnz, tpz));
+        const float t1 = f_min(f_min(f_max(tnx, tpx), f_max(tny, tpy)), f_max(tnz, tpz));
+        const bool enter = live && (t0 < t1 + kEps && t0 < r.tmax && t1 > r.tmin);
+        const bool any_enter = __ballot(enter) != 0;
+        if ((a & kPairFlag) != 0u) {         // a pair node: the lanes that entered test its two triangles, left then right (leaf_test)
+          if (any_enter) {
+            const uint32_t p = 6u * (a & kIndexMask);
+            const float4 A = lds4(pairs, p), B = lds4(pairs, p + 1), C = lds4(pairs, p + 2);
+            const float4 D = lds4(pairs, p + 3), E = lds4(pairs, p + 4), F = lds4(pairs, p + 5);
+            if (enter) {
+              if (triangle_test(r, A, B, C, h)) { h.id = (int)__float_as_uint(A.w); r.tmax = h.t - kEps; }
+              if (triangle_test(r, D, E, F, h)) { h.id = (int)__float_as_uint(D.w); r.tmax = h.t - kEps; }
+            }
+          }
+        } else {
+          if (live && !enter) wake = ex;     // (asleep until the wave leaves this subtree)
+          if (any_enter) nxt = a & kIndexMask;
+        }
+      }
+      cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
+    }
+    stp<NT>(st.hit, pos, make_float4(h.t, __int_as_float(h.id), h.u, h.v));
+  }
 }
 
 // Ordered compaction of the hits of this workgroup's n closest-hit rays by material tag (divergent-BSDF sort): every
@@ -1098,6 +1192,17 @@ __device__ __attribute__((noinline)) void compact_hits_call(uint32_t ka_lo, uint
   compact_hits_by_tag<NT, R>(st, sc, uni(g), uni(n), sh, uni(waves));
 }
 
+template <bool NT>
+__device__ __attribute__((noinline)) void stage_camera_packets_call(uint32_t ka_lo, uint32_t ka_hi, uint32_t g, uint32_t parity, uint32_t first,
+                                                                     uint32_t chunks, uint32_t sh_lds) {
+  typedef const __attribute__((address_space(4))) char* KArg;
+  KArg ka = (KArg)(((uint64_t)uni(ka_hi) << 32) | (uint64_t)uni(ka_lo));
+  const BatchState& st = *(const BatchState*)ka;
+  const DeviceScene& sc = *(const DeviceScene*)(ka + kSceneArgOffset);
+  WgShared& sh = *(WgShared*)(WgSharedLds)(uintptr_t)uni(sh_lds);
+  stage_camera_packets<NT>(st, sc, uni(g), uni(parity), uni(first), uni(chunks), sh);
+}
+
 // ------------------------------------------------------------------ kernels
 
 // The whole life of a batch in ONE launch.  Every workgroup walks through ITS samples (64-sample groups g, g + G, ...):
@@ -1175,13 +1280,22 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
       const uint32_t round_rays = n + ns;
 #endif
       wg_sync(waves);                        // everyone has read the counts before they are reset
-      if (threadIdx.x == 0) { sh.head = 0; sh.n_ray[parity ^ 1u] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; }
+      if (threadIdx.x == 0) { sh.head = 0; sh.head_cam = 0; sh.n_ray[parity ^ 1u] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; }
       if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
       wg_sync(waves);
 #ifdef HJ_WALK_STATS
       const unsigned long long st_t0 = wall_clock64();
 #endif
-      stage_trace_merged<USE_BVH, PAIRS, NT>(st, sc, g, parity, n, ns, sh);
+      // the round's new camera rays are the LAST entries of the closest-hit queue: whole packets of 64 of them are walked
+      // together over the uploaded array (stage_camera_packets), the merged walk takes the rest and the shadow rays
+      uint32_t cam = 0;
+#if HJ_CAMERA_PACKETS && HJ_SHADE_CALL >= 2
+      if (USE_BVH && PAIRS && waves > 1u) {
+        cam = ((n - n0) >> 6) << 6;
+        if (cam != 0) stage_camera_packets_call<NT>(ka_lo, ka_hi, g, parity, n - cam, cam >> 6, sh_lds);
+      }
+#endif
+      stage_trace_merged<USE_BVH, PAIRS, NT>(st, sc, g, parity, n - cam, ns, sh);
 #ifdef HJ_WALK_STATS
       const unsigned long long st_tw = wall_clock64();       // this wave has no ray left
       wg_sync(waves);                        // (diagnostic build only: the walk ends for all waves before the compaction is timed)
