@@ -883,8 +883,14 @@ HJ_DEV void stage_camera_packets(const BatchState& st, const DeviceScene& sc, ui
     uint32_t cur = sc.root;                  // wave-uniform
     while (cur < nn) {
       float4 n0, n1;
-      if (cur < nhot) { n0 = sh.nodes[2 * cur]; n1 = sh.nodes[2 * cur + 1]; }          // (uniform address: a broadcast read)
-      else { n0 = lds4(nodes, 2 * cur); n1 = lds4(nodes, 2 * cur + 1); }
+      if (cur < nhot) {                      // (uniform address: a broadcast read)
+        n0 = sh.nodes[2 * cur]; n1 = sh.nodes[2 * cur + 1];
+      } else {
+        // (the barrier keeps the compiler from issuing the scalar load ahead of the branch, for hot nodes too - loads from the
+        // constant address space may be speculated -, which made every step wait for a trip to the L2)
+        asm volatile("" ::: "memory");
+        n0 = lds4(nodes, 2 * cur); n1 = lds4(nodes, 2 * cur + 1);
+      }
       const uint32_t a = __float_as_uint(n0.w), ex = __float_as_uint(n1.w);
       if (wake == cur) wake = kAwake;
       const bool live = wake == kAwake;
