@@ -970,3 +970,40 @@ def test_defaults_shrink_to_the_free_device_memory(cbox_small, monkeypatch):
     assert st["batches"] > st0["batches"]              # smaller batches than the default rule's 2048 blocks
     assert st["paths"] == st0["paths"] == W * H * spp and st["closest_rays"] == st0["closest_rays"]
     assert (bits(got) == bits(want)).all()
+
+
+@pytest.mark.gpu
+def test_degenerate_rays_inside_camera_packets(gpu_renderer, oracle):
+    """An axis-aligned camera and a sample offset of exactly (0, 0): the rays of the pixel column x = W / 2 have d.x == 0 and those
+    of the row y = H / 2 have d.y == -0 - the slab test's inf - inf (such rays miss every box that straddles the
+    origin's plane, root included, as in the reference).  They sit in the middle of 64-ray packets whose other lanes walk on: the
+    packet walk's sleep / wake bookkeeping must leave both kinds exactly the oracle's results.  Triangle pairs (floor, wall,
+    light) switch the packet stage on."""
+    s = host.Scene()
+    s.set_camera((0.37, 0.21, 3.0), (0.0, 0.0, 0.0, 1.0), 50.0)      # (off the planes x = 0, y = 0: origin * inf = inf, not NaN)
+    white, red = s.add_diffuse((0.75, 0.75, 0.75)), s.add_diffuse((0.7, 0.2, 0.15))
+    mirror, lamp = s.add_mirror(), s.add_emissive((12, 11, 10))
+    P = np.array([[-2, -1, 1], [2, -1, 1], [2, -1, -3], [-2, -1, -3],       # floor (does not straddle y = 0)
+                  [-2, -1, -3], [2, -1, -3], [2, 2, -3], [-2, 2, -3],       # back wall (straddles x = 0 and y = 0)
+                  [-0.5, 1.9, -1.5], [0.5, 1.9, -1.5], [0.5, 1.9, -0.5], [-0.5, 1.9, -0.5],   # light, facing down
+                  [0.3, -1, -1], [1.3, -1, -1], [0.8, 0.4, -1.4]], np.float32)                # a triangle beside the axis
+    N = np.zeros_like(P)
+    N[0:4] = (0, 1, 0); N[4:8] = (0, 0, 1); N[8:12] = (0, -1, 0); N[12:15] = (0, 0.3, 1)
+    N /= np.linalg.norm(N, axis=1, keepdims=True)
+    b = s.add_vertices(P, N)
+    for q, m in ((0, white), (4, red), (8, lamp)):
+        s.add_triangle(b + q, b + q + 1, b + q + 2, m)
+        s.add_triangle(b + q, b + q + 2, b + q + 3, m)
+    s.add_triangle(b + 12, b + 13, b + 14, white)
+    s.add_sphere((-0.8, -0.5, -1.2), 0.5, mirror)
+    cs = s.compile()
+    W = H = 128
+    blocks = (abi.ImageBlock * 3)(*[abi.ImageBlock(id=i, seed=7 + 13 * i, origin=(0, 0), dimension=(W, H), original_dimension=(W, H),
+                                                   sample_offset=(0.0, 0.0)) for i in range(3)])
+    want, ctr, _ = oracle.render_blocks(cs, blocks, W, H)
+    got, st = render(gpu_renderer, cs, W, H, blocks)
+    assert_same(got, want, "degenerate rays in packets")
+    assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"]
+    smp = gpu_renderer.samples(blocks[0])
+    # the degenerate column / row really are special: no first hit there although the back wall fills the view
+    assert (smp[:, W // 2, 7] == 0).all() and (smp[H // 2, :, 7] == 0).all() and (smp[:, W // 2 + 1, 7] > 0).any()
