@@ -88,9 +88,13 @@ struct hj_context {
     hipEvent_t ev_done = nullptr;         // batch complete, statistics copied back
     bool pending = false, recon_recorded = false;
     uint32_t nb_in_flight = 0;            // ImageBlocks of the batch in flight (progress reporting)
+    uint32_t g_in_flight = 0;             // workgroups of the batch in flight (statistics read-back)
+    size_t alloc_positions = 0;           // record positions the path-state arrays hold (workgroups x pool)
   } slots[kMaxSlots];
   uint32_t num_slots = 3;
-  uint32_t num_wg = 2048;                // grid size of every path kernel (= queue segments)
+  uint32_t num_wg = 2048;                // grid size of the path kernels of a large render call (= queue segments), and the most a call uses
+  uint32_t num_wg_small = 1536;          // ... of a small one (run_begin)
+  uint32_t num_wg_eff = 2048;            // ... of the current call
   uint32_t pool = 65536;                 // path slots per workgroup of the fused kernel (HJ_POOL)
   uint32_t pool_eff = 65536;             // ... as the current render call uses it (lowered when device memory is short)
 
@@ -197,6 +201,7 @@ void release_slot(hj_context::BatchSlot& sl) {
   sl.bufs.clear();
   for (auto& b : sl.sample_bufs) b.release();
   sl.sample_bufs.clear();
+  sl.alloc_positions = 0;
   sl.st = hj::BatchState{};
 }
 void release_batch(hj_context* ctx) {
@@ -256,7 +261,7 @@ int validate_scene(hj_context* ctx, const hj_scene_desc* s) {
 // size (ctx->pool, HJ_POOL); the split-kernel path starts every sample of the batch at once and needs them all.
 int ensure_batch(hj_context* ctx, hj_context::BatchSlot& sl, uint32_t num_blocks, bool all_in_flight) {
   const uint32_t cap = num_blocks * hj::kSlotsPerBlock;
-  const uint32_t G = ctx->num_wg;
+  const uint32_t G = ctx->num_wg_eff, Gmax = ctx->num_wg;
   const uint32_t per_wg = (((cap + 63u) / 64u + G - 1u) / G) * 64u;     // samples of the busiest workgroup
   const uint32_t pool = all_in_flight ? per_wg : std::min(per_wg, ctx->pool_eff);
   hj::BatchState& st = sl.st;
@@ -290,10 +295,10 @@ int ensure_batch(hj_context* ctx, hj_context::BatchSlot& sl, uint32_t num_blocks
     }
     if (rc == HJ_OK) st.capacity = cap;
   }
-  if (rc == HJ_OK && (st.pool < pool || (ctx->scene.has_extinction && !st.ext[0]))) {
+  if (rc == HJ_OK && (sl.alloc_positions < (size_t)G * pool || (ctx->scene.has_extinction && !st.ext[0]))) {
     for (auto& b : sl.bufs) b.release();
     sl.bufs.clear();
-    st.pool = 0;
+    sl.alloc_positions = 0;
     const size_t n = (size_t)G * pool;
     for (int par = 0; par < 2; par++) {
       HJ_ALLOC(sl.bufs, ray_o[par], float4, n)
@@ -307,19 +312,20 @@ int ensure_batch(hj_context* ctx, hj_context::BatchSlot& sl, uint32_t num_blocks
     HJ_ALLOC(sl.bufs, sh_o, float4, n)
     HJ_ALLOC(sl.bufs, sh_d, float4, n)
     HJ_ALLOC(sl.bufs, sh_c, float4, n)
-    HJ_ALLOC(sl.bufs, cnt_ray[0], uint32_t, G)
-    HJ_ALLOC(sl.bufs, cnt_ray[1], uint32_t, G)
-    HJ_ALLOC(sl.bufs, cnt_hit, uint32_t, (size_t)G * hj::kNumTags)
-    HJ_ALLOC(sl.bufs, cnt_shadow, uint32_t, G)
-    HJ_ALLOC(sl.bufs, acc_closest, uint32_t, (size_t)4 * G)     // closest | shadow | hits | unoccluded, one read-back
-    if (rc == HJ_OK) {
-      st.acc_shadow = st.acc_closest + G;
-      st.acc_hits = st.acc_closest + 2 * (size_t)G;
-      st.acc_unoccluded = st.acc_closest + 3 * (size_t)G;
-      st.pool = pool;
-    }
+    HJ_ALLOC(sl.bufs, cnt_ray[0], uint32_t, Gmax)               // (per-workgroup arrays: for the most workgroups a call may use)
+    HJ_ALLOC(sl.bufs, cnt_ray[1], uint32_t, Gmax)
+    HJ_ALLOC(sl.bufs, cnt_hit, uint32_t, (size_t)Gmax * hj::kNumTags)
+    HJ_ALLOC(sl.bufs, cnt_shadow, uint32_t, Gmax)
+    HJ_ALLOC(sl.bufs, acc_closest, uint32_t, (size_t)4 * Gmax)  // closest | shadow | hits | unoccluded, one read-back
+    if (rc == HJ_OK) sl.alloc_positions = n;
   }
 #undef HJ_ALLOC
+  if (rc == HJ_OK) {
+    st.acc_shadow = st.acc_closest + G;
+    st.acc_hits = st.acc_closest + 2 * (size_t)G;
+    st.acc_unoccluded = st.acc_closest + 3 * (size_t)G;
+    st.pool = pool;
+  }
   st.num_wg = G;
   if (rc != HJ_OK) release_slot(sl);
   return rc;
@@ -431,7 +437,7 @@ int harvest(hj_context* ctx, hj_context::BatchSlot& sl, hj_render_stats* stats, 
     ctx->progress(ctx->progress_user, ctx->blocks_done, std::max(ctx->blocks_total, ctx->blocks_done));
   }
   if (stats) {
-    const uint32_t G = ctx->num_wg;
+    const uint32_t G = sl.g_in_flight;
     const uint32_t* h_acc = sl.h_counts + (size_t)2 * G;
     for (uint32_t i = 0; i < G; i++) {
       stats->closest_rays += h_acc[i];
@@ -465,6 +471,7 @@ int finish_batch(hj_context* ctx, hj_context::BatchSlot& sl, const hj::BatchStat
   HJ_HIP(ctx, hipEventRecord(sl.ev_done, sl.stream));
   sl.pending = true;
   sl.nb_in_flight = st.num_blocks;
+  sl.g_in_flight = G;
   return HJ_OK;
 }
 
@@ -636,6 +643,12 @@ int hj_context_create(int device, hj_context** out) {
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   // Tuning knobs (environment overrides exist only for sweeps; the defaults are the measured optima).
   ctx->num_wg = (uint32_t)ctx->num_cus * (uint32_t)env_int("HJ_WG_PER_CU", 8, 1, 32);   // 8 x 4 waves = the 32-wave CU limit
+  // Small render calls (a rank's share of a frame on many GPUs) run 6 workgroups per CU: all of a kernel's workgroups are then
+  // resident at once (7 x 4 waves fit a CU at 72 registers; with 8 per CU the last eighth of a batch's workgroups start when the
+  // first ones end, a thin second wave that nothing covers at the end of a short frame) - an 8-rank share of the c2 frame 24.6 ->
+  // 23.4 ms; large calls keep 8 (the 32768-block frame: 161 against 170 ms).  HJ_WG_SMALL / HJ_WG_SMALL_BLOCKS.
+  ctx->num_wg_small = std::min(ctx->num_wg, (uint32_t)ctx->num_cus * (uint32_t)env_int("HJ_WG_SMALL", 6, 1, 32));
+  ctx->num_wg_eff = ctx->num_wg;
   ctx->num_slots = (uint32_t)env_int("HJ_SLOTS", 3, 1, (int)kMaxSlots);
   // positions per workgroup: 65536 = every sample of a workgroup's share of an 8192-block batch in flight at once (the walk
   // phases of a round are long, their ramp-down costs once per round: c2 +6 %, c3 +4 % over 8192 positions with path
@@ -1077,6 +1090,8 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
   // path state (184 B each, 216 B with tinted dielectrics).  DEFAULTS that do not fit the device's free memory (other
   // contexts on the GPU, the host application) shrink until they do: first the pool (down to 8192 positions), then the
   // batch; an explicit hj_render_opts::batch_blocks is taken as given and fails with HJ_ERR_NOMEM if it does not fit.
+  static const size_t small_blocks = (size_t)env_int("HJ_WG_SMALL_BLOCKS", 12288, 0, 1 << 30);
+  ctx->num_wg_eff = (!run.split && n < small_blocks) ? ctx->num_wg_small : ctx->num_wg;
   ctx->pool_eff = ctx->pool;
   if (!run.split) {
     size_t free_b = 0, total_b = 0;
@@ -1091,9 +1106,9 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
       }
       auto need = [&](uint32_t batch, uint32_t pool_cap) {
         const size_t slots_needed = std::max<size_t>(1, std::min<size_t>(ctx->num_slots, (n + batch - 1) / std::max<uint32_t>(batch, 1u)));
-        const size_t per_wg = ((((size_t)batch * hj::kSlotsPerBlock + 63) / 64 + ctx->num_wg - 1) / ctx->num_wg) * 64;
+        const size_t per_wg = ((((size_t)batch * hj::kSlotsPerBlock + 63) / 64 + ctx->num_wg_eff - 1) / ctx->num_wg_eff) * 64;
         const size_t pool = std::min<size_t>(per_wg, pool_cap);
-        const size_t state = (size_t)ctx->num_wg * pool * (ctx->scene.has_extinction ? 196u + 20u : 164u + 20u);
+        const size_t state = (size_t)ctx->num_wg_eff * pool * (ctx->scene.has_extinction ? 196u + 20u : 164u + 20u);
         return slots_needed * (state + (size_t)batch * hj::kSlotsPerBlock * 32u);
       };
       const size_t margin = (size_t)512 << 20;
