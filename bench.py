@@ -165,6 +165,8 @@ def main_inproc(args, cfg):
     comm = device.Comm(rs)
     opts = device.default_opts()
     opts.flags = abi.RENDER_TIME_KERNELS
+    for r in rs:
+        r.reserve(spp * ((host.blocks_per_pass(W, H) + n - 1) // n), opts)      # set-up: device memory of the batch slots
 
     def step():
         for r in rs:
@@ -267,6 +269,7 @@ def run_config(name, cfg, args, steps, warmup, hj, barrier):
     sr = hjdist.ShardedRenderer(cs, W, H, local_rank=local)
     opts = device.default_opts()
     opts.flags = abi.RENDER_TIME_KERNELS      # HIP events around every kernel class, on the library's own streams
+    sr.reserve(spp, opts)                     # set-up: the batch slots' device memory (86 GB at the defaults) is allocated here, not in a frame
     for _ in range(warmup):
         sr.render_frame(spp, args.seed, opts=opts, reduce=True)
     barrier()

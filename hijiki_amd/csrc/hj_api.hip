@@ -1214,6 +1214,22 @@ int run_end(hj_context* ctx, RenderRun& run, int rc) {
 }
 }  // namespace
 
+int hj_reserve(hj_context* ctx, size_t total_blocks, const hj_render_opts* opts) {
+  if (!ctx) return HJ_ERR_INVALID;
+  HJ_NOT_BUSY(ctx);
+  if (total_blocks == 0) return HJ_OK;
+  RenderRun run;
+  int rc = run_begin(ctx, run, opts, nullptr, total_blocks);        // (the call's batch size, pool and workgroup count)
+  if (rc != HJ_OK || run.split) return rc;
+  size_t left = total_blocks;
+  for (uint32_t k = 0; k < ctx->num_slots && left != 0 && rc == HJ_OK; k++) {
+    const uint32_t nb = (uint32_t)std::min<size_t>(run.batch, left);
+    rc = ensure_batch(ctx, ctx->slots[k], nb, false);
+    left -= nb;
+  }
+  return rc;
+}
+
 int hj_render_blocks(hj_context* ctx, const hj_image_block* blocks, size_t n, const hj_render_opts* opts,
                      hj_render_stats* stats) {
   if (!ctx) return HJ_ERR_INVALID;

@@ -21,7 +21,7 @@ EXPORTS = ("hj_context_create", "hj_context_destroy", "hj_last_error", "hj_versi
            "hj_framebuffer_read", "hj_framebuffer_resolve", "hj_render_blocks", "hj_render_frame", "hj_block_seed",
            "hj_pass_offset", "hj_block_owner", "hj_debug_trace", "hj_debug_samples", "hj_reduce_framebuffers",
            "hj_build_bvh_device", "hj_render_frame_async", "hj_sync", "hj_set_progress_callback", "hj_device_count",
-           "hj_comm_create", "hj_comm_destroy", "hj_comm_reduce_framebuffers")
+           "hj_comm_create", "hj_comm_destroy", "hj_comm_reduce_framebuffers", "hj_reserve")
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
 
@@ -53,6 +53,7 @@ def lib():
                                        C.POINTER(abi.RenderStats)]
         L.hj_render_frame.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.POINTER(abi.RenderOpts), C.POINTER(abi.RenderStats)]
+        L.hj_reserve.argtypes = [vp, C.c_size_t, C.POINTER(abi.RenderOpts)]
         L.hj_reduce_framebuffers.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
         L.hj_render_frame_async.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                             C.POINTER(abi.RenderOpts)]
@@ -182,6 +183,10 @@ class Renderer:
         self._check(lib().hj_render_frame(self._h, spp, master_seed, pass_begin, pass_end, rank, world,
                                           C.byref(opts) if opts is not None else None, C.byref(st)))
         return stats_dict(st)
+
+    def reserve(self, total_blocks, opts=None):
+        """hj_reserve: allocate now what a render call of `total_blocks` ImageBlocks will use (set-up, not rendering)."""
+        self._check(lib().hj_reserve(self._h, int(total_blocks), C.byref(opts) if opts is not None else None))
 
     def render_frame_async(self, spp, master_seed, pass_begin=0, pass_end=None, rank=0, world=1, opts=None):
         """hj_render_frame on the context's worker thread; `sync()` waits for it and returns the statistics."""

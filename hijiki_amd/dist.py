@@ -73,6 +73,12 @@ class ShardedRenderer:
         self.renderer.create_framebuffer(width, height, external_device_ptr=self.fb.data_ptr())
         self.width, self.height = width, height
 
+    def reserve(self, spp, opts=None):
+        """Allocate the batch slots this rank's share of an spp-pass frame needs (set-up: the first frame then renders at speed)."""
+        from . import host
+        per_pass = host.blocks_per_pass(self.width, self.height)
+        self.renderer.reserve(spp * ((per_pass + self.world - 1) // self.world), opts)
+
     def render_frame(self, spp, master_seed, opts=None, reduce=True):
         """Zero the buffer, render this rank's blocks of all passes, reduce to rank 0.  Returns the stats dict."""
         import torch

@@ -223,6 +223,12 @@ int hj_framebuffer_resolve(hj_context* ctx, float* host_rgb /* W*H*3 */);
 
 /* ------------------------------------------------------------------- render */
 
+/* Optional set-up step (no counterpart upstream: Renderer::new creates every resource it needs, src/main.rs:1167-1314):
+ * allocates the batch slots - path state and sample buffers - that a render call of `total_blocks` ImageBlocks with
+ * these options will use (for hj_render_frame: spp x blocks per pass / world), so that the first frame does not pay for
+ * them (86 GB and 1.3 s for the benchmark's frames at the defaults).  A render call allocates whatever is missing. */
+int hj_reserve(hj_context* ctx, size_t total_blocks, const hj_render_opts* opts /* NULL = defaults */);
+
 /* Replaces the body of Renderer::render (src/main.rs:1316-1355): for every
  * block IN ORDER, integrate (shader/render.glsl:149-175) and accumulate
  * (shader/reconstruction.glsl:22-66).  The result equals running the

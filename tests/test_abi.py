@@ -100,6 +100,7 @@ def test_argument_checks_need_no_gpu():
     assert L.hj_device_count() >= 0
     assert L.hj_sync(None, None) == abi.HJ_ERR_INVALID
     assert L.hj_render_frame_async(None, 1, 1, 0, 1, 0, 1, None) == abi.HJ_ERR_INVALID
+    assert L.hj_reserve(None, 1, None) == abi.HJ_ERR_INVALID
     out = C.c_void_p()
     assert L.hj_comm_create(None, 1, C.byref(out)) == abi.HJ_ERR_INVALID and not out.value
     arr = (C.c_void_p * 1)(None)

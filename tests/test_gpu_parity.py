@@ -920,6 +920,26 @@ def test_small_pool_with_partial_block_rows(oracle, cbox_spheres, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_reserve_changes_nothing_but_the_first_frame_s_time(cbox_small):
+    """hj_reserve allocates the batch slots ahead of the first frame (set-up); the frame is the same bit for bit, and a second
+    reserve (or one for a smaller call) is a no-op."""
+    W = H = 256
+    with device.Renderer(0) as r:
+        r.upload_scene(cbox_small)
+        r.create_framebuffer(W, H)
+        r.render_frame(8, 5)
+        want = r.read()
+    with device.Renderer(0) as r:
+        r.upload_scene(cbox_small)
+        r.create_framebuffer(W, H)
+        r.reserve(8 * host.blocks_per_pass(W, H))
+        r.reserve(8 * host.blocks_per_pass(W, H))
+        r.reserve(1)
+        r.render_frame(8, 5)
+        assert (bits(r.read()) == bits(want)).all()
+
+
+@pytest.mark.gpu
 def test_async_frame_state_and_statistics(cbox_small):
     """hj_render_frame_async: other entry points answer HJ_ERR_STATE while the frame is in flight (never a race with the
     worker thread); the frame's statistics stay retrievable after a reduce has already joined it; a second frame reuses

@@ -23,6 +23,8 @@ if a.device_bvh:
     cs.set_bvh(r.build_bvh(cs))
 r.upload_scene(cs); r.create_framebuffer(a.size, a.size)
 o = device.default_opts(); o.batch_blocks = a.batch; o.flags = (abi.RENDER_TIME_KERNELS if a.time_kernels else 0) | (abi.RENDER_SPLIT_KERNELS if a.split else 0)
+if os.environ.get("HJ_PROBE_RESERVE", "1") == "1":
+    r.reserve(a.spp * host.blocks_per_pass(a.size, a.size), o)      # set-up: the batch slots' device memory
 for i in range(a.reps):
     r.clear(); t = time.time(); st = r.render_frame(a.spp, 1, opts=o); dt = time.time() - t
     print(f"[perf] {a.size}x{a.size}x{a.spp}: {dt*1e3:.2f} ms  {a.size*a.size*a.spp/dt/1e6:.1f} Mpaths/s",
