@@ -112,6 +112,10 @@ int main(int argc, char** argv) {
                    (unsigned long long)done, (unsigned long long)total);
       if (done >= total) std::fprintf(stderr, "\n");
     }, nullptr, opt.present_interval);
+    {   // resource creation belongs to Renderer::new (src/main.rs:1167-1314), not to the timed render
+      const uint64_t per_pass = (uint64_t)((opt.width + HJ_BLOCK_SIZE - 1) / HJ_BLOCK_SIZE) * ((opt.height + HJ_BLOCK_SIZE - 1) / HJ_BLOCK_SIZE);
+      check(ctx, hj_reserve(ctx, (size_t)(per_pass * opt.sample_count), &ro), "reserve");
+    }
     std::printf("Starting to render...\n");                            // src/main.rs:1488
     const auto t0 = std::chrono::steady_clock::now();
     check(ctx, hj_render_frame(ctx, opt.sample_count, opt.seed, 0, opt.sample_count, 0, 1, &ro, &st), "render");
