@@ -231,13 +231,27 @@ def roofline_block(config, agg, elapsed, steps, world, standard, oracle_counters
     if traffic_per_launch is not None and alg / launches > traffic_per_launch:
         alg, capped = traffic_per_launch * launches, True          # never quote more bytes than the counters saw
     achieved = alg / launches / (excl_ms * 1e-3) / 1e9
+    # SURVEY 8(d)'s split: the path / hit / shadow record traffic of the wavefront design is IMPLEMENTATION OVERHEAD; what the
+    # algorithm itself has to move through HBM is the sample (48 B written, 48 B read by the reconstruction, 32 B accumulated =
+    # 128 B per path) plus the scene bytes no cache serves.  `frac` is therefore an HBM *utilisation* figure of a kernel whose
+    # bytes are mostly overhead: it rises when the kernel moves more.  `overhead_ratio` = measured traffic / compulsory bytes.
+    paths = max(1, agg["paths"])
+    compulsory = 128.0 + scene_bytes / paths
+    traffic_per_path = None if traffic_per_launch is None else traffic_per_launch * launches / paths
+    limited_by, shares = limited_by_counters(lim, None if traffic is None else traffic / HBM_PEAK_GBS)
     return {
         # `bound` names the roof `frac` is measured against (the contract's vocabulary: this path has no MFMA work, its
         # roof is HBM); `limited_by` names what the counters say actually binds the kernel today.
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "limited_by": "latency" if lim else None,
+        "limited_by": limited_by, "limited_by_shares": shares,
         "valu_issue_frac": lim.get("valu_issue_frac"), "lane_fill": lim.get("lane_fill"),
+        # traffic / limiter / valu_issue_frac / lane_fill come from the rocprofv3 PMC passes committed under profiles/
+        # (`traffic_source`), scaled by THIS run's path count and kernel time: counters cannot be read inside an un-profiled run
+        "replayed_from_profile": bool(inputs),
+        "compulsory_bytes_per_path": round(compulsory, 1),
+        "traffic_bytes_per_path": None if traffic_per_path is None else round(traffic_per_path, 1),
+        "overhead_ratio": None if traffic_per_path is None else round(traffic_per_path / compulsory, 2),
         "kernel": "k_path_wavefront", "launches": int(launches),
         "algorithmic_bytes_per_launch": round(alg / launches),
         "algorithmic_bytes_per_path": round(alg / max(1, agg["paths"]), 1),
@@ -250,15 +264,28 @@ def roofline_block(config, agg, elapsed, steps, world, standard, oracle_counters
         "achieved_wall": round(alg * world / elapsed / 1e9, 1),
         "reference_algorithm_bytes_per_path": None if oracle_counters is None else reference_bytes_per_path(oracle_counters),
         "limiter": lim or None,
-        "note": "bytes of the implemented algorithm (path/hit/shadow records and samples; scene data only where it is "
-                "neither LDS- nor L2-resident, and never more than the PMC traffic) over the kernel's exclusive time; "
-                "`limited_by` / `valu_issue_frac` / `lane_fill` say what binds the kernel instead (DESIGN.md 6, profiles/)"}
+        "note": "`achieved` / `frac` = HBM UTILISATION: bytes of the implemented wavefront algorithm (path/hit/shadow records and "
+                "samples - queue traffic SURVEY 8(d) calls implementation overhead; scene data only where it is neither LDS- nor "
+                "L2-resident; never more than the PMC traffic) over the kernel's exclusive time.  The algorithm's compulsory HBM "
+                "bytes are `compulsory_bytes_per_path`; `overhead_ratio` = traffic / compulsory.  `limited_by` is derived from "
+                "the replayed counters (`limited_by_shares`; DESIGN.md 6, profiles/)"}
+
+
+def limited_by_counters(lim, hbm_frac):
+    """What binds the kernel, from the counters: "hbm" when the measured traffic is above 0.6 of the peak, "valu" when
+    the VALU issue slots are (the walk issues them at partial lane fill), else "latency" (waves waiting on dependent
+    fetches: `waiting_share_of_wave_cycles`).  None without counters."""
+    if not lim:
+        return None, None
+    shares = {"hbm": None if hbm_frac is None else round(hbm_frac, 4), "valu": lim.get("valu_issue_frac"),
+              "waiting": lim.get("waiting_share_of_wave_cycles")}
+    cand = {k: v for k, v in shares.items() if k != "waiting" and v is not None}
+    top = max(cand, key=cand.get) if cand else None
+    return (top if top is not None and cand[top] >= 0.6 else "latency"), shares
 
 
 def run_config(name, cfg, args, steps, warmup, hj, barrier):
     """W warm-up frames, then exactly `steps` timed frames of one configuration between barriers; MAX over ranks."""
-    import torch
-    import torch.distributed as dist
     from hijiki_amd import abi, device
     hjdist, rank, world, local = hj
     cs = build_scene(cfg)
@@ -279,11 +306,10 @@ def run_config(name, cfg, args, steps, warmup, hj, barrier):
         st = sr.render_frame(spp, args.seed, opts=opts, reduce=True)
         agg = st if agg is None else {k: agg[k] + v for k, v in st.items()}
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{sr.local}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = hjdist.max_over_ranks(time.perf_counter() - t0, device=sr.local)     # the slowest rank's wall time
+    if getattr(args, "dump_frame", None) and name == args.config and rank == 0:
+        import numpy as np
+        np.save(args.dump_frame, sr.fb.cpu().numpy())          # the reduced frame of the last timed step (tests compare it)
     sr.close()
     return dict(cs=cs, W=W, H=H, spp=spp, agg=agg, elapsed=elapsed, steps=steps,
                 standard=(W, H, spp) == (cfg["size"], cfg["size"], cfg["spp"]))
@@ -302,6 +328,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="only the headline configuration (the default c2 run on one GPU also times 3 frames each of c3 and c4)")
+    ap.add_argument("--dump-frame", default=None, metavar="FILE.npy",
+                    help="rank 0 saves the reduced RGBA32F accumulation buffer of the last timed frame (after the timed region)")
     ap.add_argument("--inproc", action="store_true",
                     help="ONE process drives all --gpus GPUs through the C ABI alone (hj_render_frame_async per context, "
                          "hj_comm_reduce_framebuffers): no torch, no torchrun")
@@ -321,9 +349,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        hjdist.barrier()
 
     hj = (hjdist, rank, world, local)
     res = run_config(args.config, cfg, args, args.steps, args.warmup, hj, barrier)

@@ -1,7 +1,6 @@
 """Multi-GPU tile sharding: one process per GPU, one RCCL reduce of the framebuffer.
 
-The path shards by ImageBlock: block j (column bx, row by) of every pass belongs to
-pass p belongs to
+The path shards by ImageBlock: block j (column bx, row by) of pass p belongs to
 rank (bx + by + p) mod world (hj_block_owner), every rank accumulates its blocks (and their 2-pixel aprons)
 into a private full-frame RGBA32F buffer that starts at zero, and one
 sum-reduce over xGMI (`torch.distributed`, backend "nccl" == RCCL) produces the
@@ -44,16 +43,53 @@ def init_process_group(backend=None):
     return rank, world, local
 
 
+def _active():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _through_host(t):
+    """gloo (the shared-GPU / CPU test rigs) moves host memory: a device tensor goes through a host copy there.  RCCL
+    ("nccl") reduces the device tensor in place over xGMI."""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
 def reduce_framebuffer(fb, root=0, all_ranks=False):
     """Sum the per-rank accumulation buffers (torch tensor, in place).  No-op for world == 1."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return fb
+    buf = fb.cpu() if _through_host(fb) else fb
     if all_ranks:
-        dist.all_reduce(fb, op=dist.ReduceOp.SUM)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     else:
-        dist.reduce(fb, dst=root, op=dist.ReduceOp.SUM)
+        dist.reduce(buf, dst=root, op=dist.ReduceOp.SUM)
+    if buf is not fb and (all_ranks or dist.get_rank() == root):
+        fb.copy_(buf)
     return fb
+
+
+def barrier(device=None):
+    """All ranks have arrived AND this rank's GPU is idle (bench.py brackets its timed region with this)."""
+    import torch
+    import torch.distributed as dist
+    if _active():
+        dist.barrier()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value, device=None):
+    """MAX of a host scalar over the ranks (the wall time of the slowest rank), returned on every rank."""
+    import torch
+    import torch.distributed as dist
+    if not _active():
+        return float(value)
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=(f"cuda:{device}" if on_gpu else "cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 class ShardedRenderer:

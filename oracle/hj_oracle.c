@@ -665,18 +665,20 @@ static void integrate_block(const scene_t* S, const hj_image_block* b, const hj_
 
 /* ----------------------------------------------------------- reconstruction */
 
-/* shader/reconstruction.glsl:22-66 for output rows [gy0, gy1) of the image.
- * `smp` is the block's sample image (pitch = block width).  Out-of-block
- * centre loads read 0 (out-of-range imageLoad). */
+/* shader/reconstruction.glsl:22-66 for the output rows gy of the image with gy % row_mod == row_rem
+ * (every pixel has ONE owner thread, so its sum keeps block order whatever the number of threads).
+ * `smp` is the block's sample image (pitch = block width).  Centre loads outside the block read 0: for the
+ * reference's own block lists (ragged blocks only at the right / bottom image edge, where the store is dropped)
+ * that is exactly what reconstruction.glsl:31 sees; see DESIGN.md section 2 for custom interior blocks. */
 static void reconstruct_block_rows(const hj_image_block* b, const hj_render_opts* o, const sample_t* smp,
-                                   float* accum, uint32_t W, uint32_t H, uint32_t gy0, uint32_t gy1) {
+                                   float* accum, uint32_t W, uint32_t H, uint32_t row_mod, uint32_t row_rem) {
   const int R = (int)o->recon_radius;
   const int Dx = (int)b->dimension[0], Dy = (int)b->dimension[1];
   const float gaussFac = -1.0f / ((2.0f * o->recon_stddev) * o->recon_stddev);
   const float curveOffset = hj_exp(gaussFac * (float)(R * R));
   for (int ly = -R; ly < Dy + R; ly++) {
     long gy = (long)b->origin[1] + ly;
-    if (gy < (long)gy0 || gy >= (long)gy1 || gy >= (long)H) continue;
+    if (gy < 0 || gy >= (long)H || (uint32_t)gy % row_mod != row_rem) continue;
     for (int lx = -R; lx < Dx + R; lx++) {
       long gx = (long)b->origin[0] + lx;
       if (gx < 0 || gx >= (long)W) continue;
@@ -744,10 +746,12 @@ static void* worker_main(void* arg) {
       integrate_block(&S, b, J->opts, J->tanHalf, J->smp[bi], r0, r1);
     }
     pthread_barrier_wait(&J->bar);            /* samples complete */
-    uint32_t gy0 = (uint32_t)((uint64_t)J->H * (uint64_t)w->tid / (uint64_t)J->nthreads);
-    uint32_t gy1 = (uint32_t)((uint64_t)J->H * (uint64_t)(w->tid + 1) / (uint64_t)J->nthreads);
-    for (size_t bi = 0; bi < J->batch_n; bi++) /* phase 2: accumulate, block order preserved per pixel */
-      reconstruct_block_rows(&J->blocks[J->batch_begin + bi], J->opts, J->smp[bi], J->accum, J->W, J->H, gy0, gy1);
+    /* phase 2: accumulate, block order preserved per pixel.  Rows are dealt to the threads INTERLEAVED: a batch of
+     * consecutive blocks covers a few block rows of a large frame, and contiguous row ranges left most threads
+     * without work there (the 4096 x 4096 frame ran at 0.4 of the 1024 x 1024 frame's rate). */
+    for (size_t bi = 0; bi < J->batch_n; bi++)
+      reconstruct_block_rows(&J->blocks[J->batch_begin + bi], J->opts, J->smp[bi], J->accum, J->W, J->H,
+                             (uint32_t)J->nthreads, (uint32_t)w->tid);
     pthread_barrier_wait(&J->bar);            /* batch end */
   }
   w->ctr = local;
@@ -943,7 +947,7 @@ HJO_EXPORT int hjo_integrate_block(const hj_scene_desc* sc, const hj_image_block
 /* Reconstruction of one block from given samples into accum (whole image rows). */
 HJO_EXPORT int hjo_reconstruct_block(const hj_image_block* b, const hj_render_opts* opts, const float* samples,
                                      float* accum, uint32_t W, uint32_t H) {
-  reconstruct_block_rows(b, opts, (const sample_t*)samples, accum, W, H, 0, H);
+  reconstruct_block_rows(b, opts, (const sample_t*)samples, accum, W, H, 1u, 0u);
   return HJ_OK;
 }
 

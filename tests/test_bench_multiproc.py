@@ -1,0 +1,62 @@
+"""`bench.py --gpus N` exactly as the driver launches it (python -m torch.distributed.run, one process per rank), with
+N = 2 ranks on the ONE GPU of the test box: HIJIKI_DIST_BACKEND=gloo lets the ranks share the device (RCCL wants one GPU
+per rank), everything else - the torchrun environment, hijiki_amd.dist, ShardedRenderer, the barriers, the MAX over the
+ranks' wall times, the framebuffer reduce to rank 0, the one JSON line - is the code path of the 1/2/4/8-GPU scaling run.
+Child processes: nothing here initialises the GPU before torchrun starts.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _bench(tmp_path, nranks, extra, tag):
+    frame = str(tmp_path / f"frame_{tag}.npy")
+    args = ["bench.py", "--gpus", str(nranks), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary",
+            "--dump-frame", frame] + extra
+    if nranks == 1:
+        cmd = [sys.executable] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + args
+    env = dict(os.environ, HIJIKI_DIST_BACKEND="gloo", GPU_MAX_HW_QUEUES="8", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-6000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line (rank 0 only), got {len(lines)}:\n{p.stdout[-3000:]}"
+    return json.loads(lines[0]), np.load(frame)
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("config,size,spp", [("c2", 1024, 8), ("c5", 4096, 8)])
+def test_bench_two_ranks_under_torchrun(tmp_path, config, size, spp):
+    extra = ["--config", config, "--spp", str(spp)]
+    one, f1 = _bench(tmp_path, 1, extra, "n1")
+    two, f2 = _bench(tmp_path, 2, extra, "n2")
+    assert one["n_gpus"] == 1 and one["rccl_ranks"] == 1
+    assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2 and two["rccl_backend"] == "gloo"
+    for out in (one, two):
+        assert out["unit"] == "Mrays/s" and out["steps"] == 1 and out["warmup"] == 0 and out["scaling"] == "strong"
+        assert out["value"] > 0 and abs(out["value"] - size * size * spp / (out["ms_per_step"] * 1e-3) / 1e6) < 0.01 * out["value"]
+        assert out["roofline"]["launches"] >= 1 and out["roofline"]["achieved"] > 0
+        assert config + ":" in out["config"]["workload"] and f"{size}x{size} {spp}spp" in out["config"]["workload"]
+    assert "mod 2" in two["config"]["partition"]
+    # the reduced two-rank frame is the one-rank frame: every pixel's passes are summed as two partial sums (a few ulp)
+    assert f1.shape == f2.shape == (size, size, 4) and np.isfinite(f2).all() and (f2[..., 3] > 0).all()
+    np.testing.assert_allclose(f2, f1, rtol=5e-5, atol=1e-5)
+    assert (f1 != f2).any() or spp == 1          # (really two partial sums: not the same bits everywhere)

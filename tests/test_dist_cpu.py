@@ -40,10 +40,15 @@ def _worker(rank, world, port, W, H, spp, seed, static, out_path):
     arr = (abi.ImageBlock * len(mine))(*mine)
     acc, _, _ = hj_oracle.render_blocks(cs, arr, W, H, nthreads=2)
     fb = torch.from_numpy(acc)
+    hjdist.barrier()                                           # bench.py's bracket around the timed region
     hjdist.reduce_framebuffer(fb, root=0)
+    assert hjdist.max_over_ranks(10.0 + rank) == 10.0 + world - 1      # bench.py: the slowest rank's wall time, on every rank
     if rank == 0:
         np.save(out_path, fb.numpy())
-    dist.barrier()
+    both = torch.full((4,), float(rank + 1))
+    hjdist.reduce_framebuffer(both, all_ranks=True)
+    assert both.tolist() == [float(sum(range(1, world + 1)))] * 4
+    hjdist.barrier()
     dist.destroy_process_group()
 
 

@@ -61,6 +61,49 @@ def test_config1_cbox_256x256_4spp(gpu_renderer, oracle, cbox):
     assert float(np.sqrt(np.mean((a - b) ** 2))) < 1e-4       # the bar BASELINE.json states; actual: 0
 
 
+def test_render_frame_entry_point_against_the_oracle(gpu_renderer, oracle, cbox):
+    """hj_render_frame - the entry point bench.py times - against the oracle: the frame's ImageBlock list is generated
+    inside the library (BlockGrid::make; src/main.rs:619-682 made deterministic), the oracle renders host.make_blocks' list.
+    Whole frame bit for bit; then three ranks (rank / world as bench.py --gpus N passes them), each against the oracle on
+    ITS block list (hj_block_owner), and their float64 sum against the frame."""
+    from hijiki_amd import dist as hjdist
+    W = H = 384
+    spp, seed = 5, 7
+    r = gpu_renderer
+    r.upload_scene(cbox)
+    r.create_framebuffer(W, H)
+    st = r.render_frame(spp, seed)
+    all_blocks = host.make_blocks(W, H, spp, seed)
+    want, ctr, _ = oracle.render_blocks(cbox, all_blocks, W, H)
+    assert_same(r.read(), want, "hj_render_frame")
+    assert st["paths"] == W * H * spp and st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"]
+    per, world = host.blocks_per_pass(W, H), 3
+    total, owned = np.zeros((H, W, 4), np.float64), 0
+    for rank in range(world):
+        mine = [all_blocks[p * per + j] for p in range(spp) for j in hjdist.owned_blocks(W, H, rank, world, p)]
+        owned += len(mine)
+        want_r, _, _ = oracle.render_blocks(cbox, (abi.ImageBlock * len(mine))(*mine), W, H)
+        r.clear()
+        r.render_frame(spp, seed, rank=rank, world=world)
+        got_r = r.read()
+        assert_same(got_r, want_r, f"rank {rank} of {world}")
+        total += got_r
+    assert owned == len(all_blocks)
+    np.testing.assert_allclose(total, want, rtol=5e-6, atol=1e-6)
+
+
+def test_config3_scene_512x512x16_against_the_oracle(gpu_renderer, oracle, cbox_spheres):
+    """BASELINE.json configs[2]'s scene at a size the oracle takes seconds for: 4.2 M paths through the mirror and the
+    dielectric sphere (long specular chains, total internal reflection, 5-way material sort), bit for bit."""
+    W = H = 512
+    blocks = host.make_blocks(W, H, 16, 3)
+    want, ctr, _ = oracle.render_blocks(cbox_spheres, blocks, W, H)
+    got, st = render(gpu_renderer, cbox_spheres, W, H, blocks)
+    assert_same(got, want, "C3 scene 512x512x16")
+    assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"] and st["hits"] == ctr["hits"]
+    assert ctr["closest_calls"] > 3.3 * ctr["paths"]
+
+
 def test_divergent_materials_and_many_bounces(gpu_renderer, oracle, cbox_spheres):
     """configs[2] shape (mirror + dielectric spheres): long specular chains, 5-way material sort."""
     W, H = 256, 128
@@ -491,6 +534,16 @@ def test_config4_million_triangles_bit_exact(gpu_renderer, oracle, mesh_1m):
         cs.set_bvh(sah)
 
 
+def test_config4_scene_256x256x4_against_the_oracle(gpu_renderer, oracle, mesh_1m):
+    """configs[3]'s 1 M-triangle scene, 262 k paths (bounce rays deep in the tree, not only camera rays), bit for bit."""
+    W = H = 256
+    blocks = host.make_blocks(W, H, 4, 9)
+    want, ctr, _ = oracle.render_blocks(mesh_1m, blocks, W, H)
+    got, st = render(gpu_renderer, mesh_1m, W, H, blocks)
+    assert_same(got, want, "1M mesh 256x256x4")
+    assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"] and st["hits"] == ctr["hits"]
+
+
 def test_config4_full_size_properties(gpu_renderer, mesh_1m):
     """configs[3] at FULL size: 1 M triangles, 2048 x 2048, 256 spp (1.07 G paths; deep BVH traversal)."""
     gpu_renderer.upload_scene(mesh_1m)
@@ -504,6 +557,35 @@ def test_config5_frame_size_eight_virtual_ranks(gpu_renderer, cbox):
     gpu_renderer.upload_scene(cbox)
     _frame_properties(gpu_renderer, 4096, 4096, 64, 2, split_at=24, virtual_ranks=8)
     gpu_renderer.create_framebuffer(64, 64)              # release the 268 MB buffer for the tests that follow
+
+
+def test_config5_full_size(gpu_renderer, cbox):
+    """configs[4] at its OWN size on one GPU: cbox 4096 x 4096, 4096 spp = 2^36 camera paths (the product that overflows
+    the reference's u32 ray count, src/main.rs:1491), 4.19 M ImageBlocks generated chunk by chunk.  About 21 s.  Checked:
+    the 64-bit path count, a finite frame with positive weight everywhere, the statistics' consistency, and additivity
+    over pass ranges on the 512-pass prefix (two calls == one call, bit for bit)."""
+    W = H = 4096
+    spp = 4096
+    r = gpu_renderer
+    r.upload_scene(cbox)
+    r.create_framebuffer(W, H)
+    st = r.render_frame(spp, 1)
+    assert st["paths"] == 2 ** 36 == W * H * spp
+    assert st["closest_rays"] > 3 * st["paths"] and st["shadow_rays"] > st["paths"] and st["hits"] <= st["closest_rays"]
+    assert 0 < st["unoccluded_shadow_rays"] <= st["shadow_rays"]
+    a = r.read()
+    assert np.isfinite(a).all() and (a[..., 3] > 0).all()
+    rgb = a[..., :3] / a[..., 3:4]
+    assert 0.05 < rgb.mean() < 1.0 and rgb.min() >= 0
+    del a, rgb
+    r.clear()
+    r.render_frame(spp, 1, pass_begin=0, pass_end=512)
+    prefix = r.read()
+    r.clear()
+    r.render_frame(spp, 1, pass_begin=0, pass_end=200)
+    r.render_frame(spp, 1, pass_begin=200, pass_end=512)
+    assert (bits(r.read()) == bits(prefix)).all()
+    r.create_framebuffer(64, 64)
 
 
 def test_large_mesh_and_large_frame(gpu_renderer, oracle):

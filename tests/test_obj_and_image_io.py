@@ -302,6 +302,11 @@ def test_cli_renders_like_the_library(tmp_path, obj_path):
         rr.render_frame(3, 9)
         want = rr.resolve()
     assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    # ... and like the ORACLE: main() of the reference = from_obj + put_cbox_spheres + compile + render + rgb / w
+    # (src/main.rs:414-530,1463-1483,1395-1400), restated on the CPU for the same ImageBlock list
+    from oracle import hj_oracle
+    acc, _, _ = hj_oracle.render_blocks(cs, host.make_blocks(160, 128, 3, 9), 160, 128)
+    assert (got.view(np.uint32) == hj_oracle.resolve(acc).view(np.uint32)).all()
     # default traversal is the linear scan, as upstream (--use-bvh off)
     out2 = str(tmp_path / "o2.exr")
     r = subprocess.run([exe, "-w", "128", "-h", "128", "-s", "1", "-o", out2, obj_path], capture_output=True, text=True)
@@ -312,6 +317,41 @@ def test_cli_renders_like_the_library(tmp_path, obj_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "Built BVH with" in r.stdout and open(out3, "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+
+
+@pytest.mark.gpu
+def test_obj_loaded_scene_against_the_oracle(obj_path):
+    """Scene::from_obj (+ --put-cbox-spheres) -> compile -> HIP frame, against the oracle on the same compiled scene: the
+    loader's output (fan triangulation, re-indexed vertices, material mapping by name prefix, Ke light) feeds the hot path.
+    Host tree and device-built tree, BVH walk and the CLI default linear scan."""
+    from hijiki_amd import device
+    from oracle import hj_oracle
+    s = host.Scene.from_obj(obj_path)
+    s.put_cbox_spheres()
+    cs = s.compile()
+    W, H, spp, seed = 192, 160, 4, 13
+    blocks = host.make_blocks(W, H, spp, seed)
+    want, ctr, _ = hj_oracle.render_blocks(cs, blocks, W, H)
+    assert ctr["tri_tests"] > 0 and ctr["sphere_tests"] > 0 and ctr["nee_evals"] > 0
+    with device.Renderer(0) as rr:
+        rr.upload_scene(cs)
+        rr.create_framebuffer(W, H)
+        st = rr.render_frame(spp, seed)
+        got = rr.read()
+        assert (got.view(np.uint32) == want.view(np.uint32)).all()
+        assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"]
+        o = device.default_opts()
+        o.use_bvh = 0                                                   # the reference CLI's default (scene.glsl:134-158)
+        lin, _, _ = hj_oracle.render_blocks(cs, blocks, W, H, opts=o)
+        rr.clear()
+        rr.render_frame(spp, seed, opts=o)
+        assert (rr.read().view(np.uint32) == lin.view(np.uint32)).all()
+        cs.set_bvh(rr.build_bvh(cs))                                    # --device-bvh
+        want2, _, _ = hj_oracle.render_blocks(cs, blocks, W, H)
+        rr.upload_scene(cs)
+        rr.clear()
+        rr.render_frame(spp, seed)
+        assert (rr.read().view(np.uint32) == want2.view(np.uint32)).all()
 
 
 @pytest.mark.gpu

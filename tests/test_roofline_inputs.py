@@ -47,7 +47,21 @@ def test_roofline_block_never_quotes_more_than_the_counters_saw():
     agg = {"paths": P, "closest_rays": int(2.9 * P), "shadow_rays": int(1.85 * P), "hits": int(2.7 * P),
            "unoccluded_shadow_rays": int(1.2 * P), "path_launches": 8, "path_busy_ms": 960.0, "path_ms": 2800.0}
     r = bench.roofline_block("c4", agg, 0.99, 1, 1, True)
-    assert r["bound"] == "hbm" and r["limited_by"] == "latency"
+    assert r["bound"] == "hbm" and r["replayed_from_profile"] is True
+    sh = r["limited_by_shares"]                              # `limited_by` follows from the counters, not from a literal
+    top = max(("hbm", "valu"), key=lambda k: sh[k])
+    assert r["limited_by"] == (top if sh[top] >= 0.6 else "latency")
+    assert r["compulsory_bytes_per_path"] >= 128 and r["overhead_ratio"] > 1
+    assert abs(r["overhead_ratio"] - r["traffic_bytes_per_path"] / r["compulsory_bytes_per_path"]) < 0.01
     assert r["traffic"] is not None and r["achieved"] <= r["traffic"] * 1.001
     assert 0 < r["valu_issue_frac"] < 1 and 0 < r["lane_fill"] < 1
     assert abs(r["frac"] - r["achieved"] / 8000.0) < 2e-4
+
+
+def test_limited_by_follows_the_counters():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.limited_by_counters({}, None) == (None, None)
+    assert bench.limited_by_counters({"valu_issue_frac": 0.66, "waiting_share_of_wave_cycles": 0.67}, 0.39)[0] == "valu"
+    assert bench.limited_by_counters({"valu_issue_frac": 0.55, "waiting_share_of_wave_cycles": 0.64}, 0.42)[0] == "latency"
+    assert bench.limited_by_counters({"valu_issue_frac": 0.30}, 0.81)[0] == "hbm"
