@@ -68,11 +68,14 @@ def implemented_bytes(st):
     A = C - P                      # continuing paths written by shade (every closest ray that is not a camera ray)
     first_hits = P * (Hh / C) if C else 0.0
     b = 0.0
-    b += P * (3 * 16 + 2 * 16)     # top-up: ray_o, ray_d, thr + sample init (smp_rgb, smp_nd)
-    b += C * (2 * 16 + 16)         # walk: fetch ray_o, ray_d; write the hit record
+    # camera paths have NO records (round 4): the packet stage builds the ray from the sample index, shade rebuilds the path
+    b += P * (2 * 16)              # packet stage: sample init (smp_rgb, smp_nd)
+    b += A * (2 * 16)              # walk: fetch ray_o, ray_d of a continuing path
+    b += C * 16                    # walk / packet stage: the hit record
     b += C * (2 * 16)              # compaction: two passes over the hit records
     b += Hh * (4 + 4)              # hit queue: write + read of the position
-    b += Hh * (4 * 16)             # shade: hit, ray_o, ray_d, thr
+    b += Hh * 16                   # shade: the hit record
+    b += max(0.0, Hh - first_hits) * (3 * 16)   # shade: ray_o, ray_d, thr of a continuing path that hit
     b += A * (3 * 16)              # shade: record of the continuing path (ray_o, ray_d, thr)
     b += S * (3 * 16)              # shade: shadow record (origin, direction + tMax, contribution + sample)
     b += S * (3 * 16)              # walk: fetch shadow origin, direction, contribution + sample index (carried in registers)
@@ -87,7 +90,9 @@ def coalesced_read_bytes(st):
     rocprofv3's FETCH_SIZE counts these at half their size on gfx950 (MI355X_MICROARCH.md, section HBM), while it counts
     the 64-byte sectors of 16/32/48-byte gathers exactly (profiles/r02_fetch_size_calibration.txt)."""
     P, C, S, Hh = st["paths"], st["closest_rays"], st["shadow_rays"], st["hits"]
-    return C * (2 * 16) + C * (2 * 16) + Hh * (4 * 16) + S * (3 * 16) + P * (2 * 16 * (20 * 20) / (16 * 16))
+    first_hits = P * (Hh / C) if C else 0.0
+    return (C - P) * (2 * 16) + C * (2 * 16) + Hh * 16 + max(0.0, Hh - first_hits) * (3 * 16) + S * (3 * 16) \
+        + P * (2 * 16 * (20 * 20) / (16 * 16))
 
 
 def roofline_inputs(config):

@@ -649,6 +649,12 @@ struct WgShared {                 // LDS of a path workgroup (16.5 KB)
   uint32_t n_gen;                 // new camera paths the current top-up has appended behind them
   uint32_t n_shadow;              // shadow records
   uint32_t n_unocc;               // statistics: unoccluded shadow rays of this round
+  // IMPLICIT camera paths of the current round (kernels with the packet stage): positions [cam_first, n) of the closest-hit
+  // queue are the samples of groups cam_k0, cam_k0 + 1, ... of the workgroup's sequence, 64 positions per group, lane = sample:
+  // nothing of them is in the path arrays, every stage rebuilds what it needs from the sample index (camera_ray)
+  uint32_t cam_first;             // 0xFFFFFFFF: none (every camera path of the round has explicit records)
+  uint32_t cam_k0;
+  uint32_t n_cam_dead;            // statistics: positions of those groups that hold no sample (ragged blocks)
   float4 nodes[2 * kHotNodes];    // LDS copy of the hottest BVH nodes (same record layout as DeviceScene::nodes)
 };
 
@@ -683,50 +689,55 @@ HJ_DEV uint32_t wg_group(const BatchState& st, uint32_t g, uint32_t k) {
   return g + k * st.num_wg;
 }
 
-// reference shader/render.glsl:26-36,149-162: camera paths for groups [k0, k0 + ngen) of this workgroup's sample
-// sequence, appended to the path arrays of `parity` behind the n0 continuing paths (positions n0 + sh.n_gen...; the
-// caller guarantees n0 + 64 * ngen <= pool).
+// reference shader/render.glsl:26-36,149-162 for sample `smp` of the batch (block smp / 16384, local pixel from the low bits):
+// is the sample inside its block and the image (render.glsl:152 compares the LOCAL id with the image size), its RNG state
+// after seedRng(block.seed + lx + ly * dimension.x) and the normalised camera direction (origin = camera.position,
+// tMin = eps).  ONE text for the top-up, the packet walk and the shade stage: a camera path that is never written to the
+// path arrays (below) is rebuilt from its sample index with exactly these operations.
+HJ_DEV bool camera_ray(const BatchState& st, const DeviceScene& sc, uint32_t smp, uint32_t& rng, v3& d) {
+  if (smp >= st.num_blocks * kSlotsPerBlock) return false;
+  const hj_image_block b = st.blocks[smp / kSlotsPerBlock];
+  const uint32_t lx = smp & (HJ_BLOCK_SIZE - 1u);
+  const uint32_t ly = (smp / HJ_BLOCK_SIZE) & (HJ_BLOCK_SIZE - 1u);
+  if (!(lx < b.dimension[0] && ly < b.dimension[1] && lx < b.original_dimension[0] && ly < b.original_dimension[1])) return false;
+  const uint32_t seed = b.seed + lx + ly * b.dimension[0];          // render.glsl:156
+  rng = rng_seed(seed);
+  const float W = (float)b.original_dimension[0], H = (float)b.original_dimension[1];
+  const float px = (float)(lx + b.origin[0]) + b.sample_offset[0];
+  const float py = (float)(ly + b.origin[1]) + b.sample_offset[1];
+  float x = px - 0.5f * W, y = py - 0.5f * H;
+  x = (x * sc.tan_half_fov) / (0.5f * W);
+  y = (y * sc.tan_half_fov) / (0.5f * W);
+  // quaternionRotate(v, q) = (q (x) (v,0)) (x) conj(q), quaternion.glsl:1-19
+  const v3 qv = V(sc.camera.rotation[0], sc.camera.rotation[1], sc.camera.rotation[2]);
+  const float qw = sc.camera.rotation[3];
+  const v3 vv = V(x, -y, -1.0f);
+  const float tw = qw * 0.0f - dot3(qv, vv);
+  const v3 c1 = cross3(qv, vv);
+  const v3 txyz = V((c1.x + qv.x * 0.0f) + vv.x * qw, (c1.y + qv.y * 0.0f) + vv.y * qw, (c1.z + qv.z * 0.0f) + vv.z * qw);
+  const v3 cq = -qv;
+  const v3 c2 = cross3(txyz, cq);
+  const v3 rot = V((c2.x + txyz.x * qw) + cq.x * tw, (c2.y + txyz.y * qw) + cq.y * tw, (c2.z + txyz.z * qw) + cq.z * tw);
+  d = normalize3(rot);
+  return true;
+}
+
+// EXPLICIT top-up (kernels without the packet stage: linear scan, trees without pair nodes, the split-kernel path): camera
+// paths for groups [k0, k0 + ngen) of this workgroup's sample sequence, written to the path arrays of `parity` behind the
+// n0 continuing paths (positions n0 + sh.n_gen...; the caller guarantees n0 + 64 * ngen <= pool).
 template <bool NT>
 HJ_DEV void stage_gen_camera(const BatchState& st, const DeviceScene& sc, uint32_t g, WgShared& sh, uint32_t parity,
                              uint32_t n0, uint32_t k0, uint32_t ngen, uint32_t waves) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t total = st.num_blocks * kSlotsPerBlock;
   const uint32_t seg = g * st.pool + n0;
   for (uint32_t k = k0 + wave; k < k0 + ngen; k += waves) {
     const uint32_t smp = wg_group(st, g, k) * 64u + lane;
-    bool valid = smp < total;
-    hj_image_block b;
-    uint32_t lx = 0, ly = 0;
-    if (valid) {
-      b = st.blocks[smp / kSlotsPerBlock];
-      lx = smp & (HJ_BLOCK_SIZE - 1u);
-      ly = (smp / HJ_BLOCK_SIZE) & (HJ_BLOCK_SIZE - 1u);
-      valid = lx < b.dimension[0] && ly < b.dimension[1];
-      // render.glsl:152 compares the LOCAL id with the image size
-      valid = valid && lx < b.original_dimension[0] && ly < b.original_dimension[1];
-    }
+    uint32_t rng = 0;
+    v3 d = V(0, 0, 0);
+    const bool valid = camera_ray(st, sc, smp, rng, d);
     const uint32_t qi = lds_push(&sh.n_gen, valid);
     if (valid) {
       const uint32_t pos = seg + qi;
-      const uint32_t seed = b.seed + lx + ly * b.dimension[0];          // render.glsl:156
-      const uint32_t rng = rng_seed(seed);
-      const float W = (float)b.original_dimension[0], H = (float)b.original_dimension[1];
-      const float px = (float)(lx + b.origin[0]) + b.sample_offset[0];
-      const float py = (float)(ly + b.origin[1]) + b.sample_offset[1];
-      float x = px - 0.5f * W, y = py - 0.5f * H;
-      x = (x * sc.tan_half_fov) / (0.5f * W);
-      y = (y * sc.tan_half_fov) / (0.5f * W);
-      // quaternionRotate(v, q) = (q (x) (v,0)) (x) conj(q), quaternion.glsl:1-19
-      const v3 qv = V(sc.camera.rotation[0], sc.camera.rotation[1], sc.camera.rotation[2]);
-      const float qw = sc.camera.rotation[3];
-      const v3 vv = V(x, -y, -1.0f);
-      const float tw = qw * 0.0f - dot3(qv, vv);
-      const v3 c1 = cross3(qv, vv);
-      const v3 txyz = V((c1.x + qv.x * 0.0f) + vv.x * qw, (c1.y + qv.y * 0.0f) + vv.y * qw, (c1.z + qv.z * 0.0f) + vv.z * qw);
-      const v3 cq = -qv;
-      const v3 c2 = cross3(txyz, cq);
-      const v3 rot = V((c2.x + txyz.x * qw) + cq.x * tw, (c2.y + txyz.y * qw) + cq.y * tw, (c2.z + txyz.z * qw) + cq.z * tw);
-      const v3 d = normalize3(rot);
       // the sample index rides in origin.w, the RNG state in direction.w
       stp<NT>(st.ray_o[parity], pos, make_float4(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2], __uint_as_float(smp | kCameraFlag)));
       stp<NT>(st.ray_d[parity], pos, make_float4(d.x, d.y, d.z, __uint_as_float(rng)));
@@ -857,7 +868,8 @@ typedef const __attribute__((address_space(4))) f4s* ScalarF4;        // constan
 HJ_DEV float4 lds4(ScalarF4 p, uint32_t i) { const f4s v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
 template <bool NT>
 HJ_DEV void stage_camera_packets(const BatchState& st, const DeviceScene& sc, uint32_t g, uint32_t parity, uint32_t first,
-                                 uint32_t chunks, WgShared& sh) {
+                                 uint32_t chunks, uint32_t k0, WgShared& sh) {
+  (void)parity;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t seg = g * st.pool;
   const ScalarF4 nodes = (ScalarF4)(uintptr_t)sc.nodes;
@@ -866,20 +878,32 @@ HJ_DEV void stage_camera_packets(const BatchState& st, const DeviceScene& sc, ui
   const ScalarF4 sphs = (ScalarF4)(uintptr_t)sc.spheres;
   const ScalarF4 quads = (ScalarF4)(uintptr_t)sc.quads;
   const uint32_t nn = sc.num_nodes, nhot = sc.num_hot;
-  constexpr uint32_t kAwake = 0xFFFFFFFFu;
+  constexpr uint32_t kAwake = 0xFFFFFFFFu, kNever = 0xFFFFFFFEu;
+  uint32_t dead = 0;                         // wave-uniform: positions without a sample
   for (;;) {
     const uint32_t c = lds_fetch_chunk(&sh.head_cam);
     if (c >= 64u * chunks) break;
     const uint32_t pos = seg + first + c + lane;
-    const float4 o4 = ldp<NT>(st.ray_o[parity], pos), d4 = ldp<NT>(st.ray_d[parity], pos);
+    // IMPLICIT camera paths: chunk c is group k0 + c / 64 of the workgroup's sample sequence, lane = sample.  The ray is built
+    // here (render.glsl:26-36,156-162) and never written: shade rebuilds it for the paths that hit something.  The sample's
+    // two layers are initialised here (render.glsl:172-174 writes them whatever the path does).
+    const uint32_t smp = wg_group(st, g, k0 + (c >> 6)) * 64u + lane;
+    uint32_t rng_unused = 0;
     Ray r;
-    r.o = xyz(o4); r.d = xyz(d4);
-    r.tmin = (__float_as_uint(o4.w) & kCameraFlag) != 0u ? kEps : 2.0f * kEps;   // render.glsl:33,132
+    r.o = V(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]);
+    r.d = V(0, 0, 0);
+    const bool valid = camera_ray(st, sc, smp, rng_unused, r.d);
+    dead += 64u - (uint32_t)__popcll(__ballot(valid));
+    if (valid) {
+      stp<NT>(st.smp_rgb, smp, make_float4(0.f, 0.f, 0.f, 1.f));
+      stp<NT>(st.smp_nd, smp, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    r.tmin = kEps;                           // render.glsl:33
     r.tmax = kInf;
     const v3 inv = V(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     const v3 off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
     RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
-    uint32_t wake = kAwake;                  // the node at which a sleeping lane takes part again
+    uint32_t wake = valid ? kAwake : kNever; // the node at which a sleeping lane takes part again (a position without a sample: never)
     uint32_t cur = sc.root;                  // wave-uniform
     while (cur < nn) {
       float4 n0, n1;
@@ -936,6 +960,7 @@ HJ_DEV void stage_camera_packets(const BatchState& st, const DeviceScene& sc, ui
     }
     stp<NT>(st.hit, pos, make_float4(h.t, __int_as_float(h.id), h.u, h.v));
   }
+  if (lane == 0 && dead != 0) atomicAdd(&sh.n_cam_dead, dead);
 }
 
 // Ordered compaction of the hits of this workgroup's n closest-hit rays by material tag (divergent-BSDF sort): every
@@ -1024,6 +1049,7 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t seg = g * st.pool;
   const uint32_t np = parity ^ 1u;
+  const uint32_t cam_first = uni(sh.cam_first), cam_k0 = uni(sh.cam_k0);
   // one material tag at a time: every wave shades ONE tag (no divergent BSDF switch)
   for (uint32_t tag = 0; tag < kNumTags; tag++) {
     const uint32_t n = uni(sh.cnt_hit[tag]);
@@ -1037,17 +1063,33 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
     Its its; its.p = V(0, 0, 0);
     uint32_t rng = 0, smp = 0, flags_out = 0;
     if (valid) {
-      const uint32_t slot = seg + q[i];
+      const uint32_t qpos = q[i];
+      const uint32_t slot = seg + qpos;
       const float4 hr = ldp<NT>(st.hit, slot);
-      const float4 ro4 = ldp<NT>(st.ray_o[parity], slot), rd4 = ldp<NT>(st.ray_d[parity], slot);
-      const float4 th4 = ldp<NT>(st.thr[parity], slot);
-      const v3 ro = xyz(ro4), rd = xyz(rd4);
-      T = xyz(th4);
-      const uint32_t flags = __float_as_uint(th4.w);
+      // An IMPLICIT camera path (position >= cam_first: its ray was walked as part of a packet) has no record: origin,
+      // direction, RNG state, throughput 1 and "bounce 0, wasDiscrete" follow from its sample index (render.glsl:156-169, 86-90).
+      const bool implicit = qpos >= cam_first;
+      v3 ro, rd;
+      uint32_t flags;
+      if (implicit) {
+        const uint32_t c = qpos - cam_first;
+        smp = wg_group(st, g, cam_k0 + (c >> 6)) * 64u + (c & 63u);
+        ro = V(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]);
+        rd = V(0, 0, 0);
+        (void)camera_ray(st, sc, smp, rng, rd);
+        T = V(1.f, 1.f, 1.f);
+        flags = 1u;
+      } else {
+        const float4 ro4 = ldp<NT>(st.ray_o[parity], slot), rd4 = ldp<NT>(st.ray_d[parity], slot);
+        const float4 th4 = ldp<NT>(st.thr[parity], slot);
+        ro = xyz(ro4); rd = xyz(rd4);
+        T = xyz(th4);
+        flags = __float_as_uint(th4.w);
+        smp = __float_as_uint(ro4.w) & ~kCameraFlag;
+        rng = __float_as_uint(rd4.w);
+      }
       const bool was_discrete = (flags & 1u) != 0u;
       const uint32_t bounce = flags >> 1;
-      smp = __float_as_uint(ro4.w) & ~kCameraFlag;
-      rng = __float_as_uint(rd4.w);
       const uint32_t id = (uint32_t)__float_as_int(hr.y);
       its.p = V(fmaf(hr.x, rd.x, ro.x), fmaf(hr.x, rd.y, ro.y), fmaf(hr.x, rd.z, ro.z));   // scene.glsl:164
       if (id < sc.ns) populate_sphere(sc.spheres[id], its);
@@ -1057,7 +1099,7 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
       const uint32_t mat = sc.materials[id];
       const uint32_t midx = mat & HJ_MATERIAL_INDEX_MASK;
       if (sc.has_extinction) {                                                             // render.glsl:111-112
-        ext = xyz(ldp<NT>(st.ext[parity], slot));
+        if (!implicit) ext = xyz(ldp<NT>(st.ext[parity], slot));                           // (a camera path starts with extinction 0)
         const float dist = len3(ro - its.p);
         T = T * V(hj_exp(-ext.x * dist), hj_exp(-ext.y * dist), hj_exp(-ext.z * dist));
       }
@@ -1200,13 +1242,13 @@ __device__ __attribute__((noinline)) void compact_hits_call(uint32_t ka_lo, uint
 
 template <bool NT>
 __device__ __attribute__((noinline)) void stage_camera_packets_call(uint32_t ka_lo, uint32_t ka_hi, uint32_t g, uint32_t parity, uint32_t first,
-                                                                     uint32_t chunks, uint32_t sh_lds) {
+                                                                     uint32_t chunks, uint32_t k0, uint32_t sh_lds) {
   typedef const __attribute__((address_space(4))) char* KArg;
   KArg ka = (KArg)(((uint64_t)uni(ka_hi) << 32) | (uint64_t)uni(ka_lo));
   const BatchState& st = *(const BatchState*)ka;
   const DeviceScene& sc = *(const DeviceScene*)(ka + kSceneArgOffset);
   WgShared& sh = *(WgShared*)(WgSharedLds)(uintptr_t)uni(sh_lds);
-  stage_camera_packets<NT>(st, sc, uni(g), uni(parity), uni(first), uni(chunks), sh);
+  stage_camera_packets<NT>(st, sc, uni(g), uni(parity), uni(first), uni(chunks), uni(k0), sh);
 }
 
 // ------------------------------------------------------------------ kernels
@@ -1238,35 +1280,42 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
   const uint64_t ka_ = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
   const uint32_t ka_lo = (uint32_t)ka_, ka_hi = (uint32_t)(ka_ >> 32), sh_lds = (uint32_t)(uintptr_t)(WgSharedLds)&sh;
 #endif
+  // Camera paths without records: kernels that have the packet stage (BVH walk over a tree with pair nodes, stages called)
+  constexpr bool IMPLICIT = HJ_CAMERA_PACKETS && HJ_SHADE_CALL >= 2 && USE_BVH && PAIRS;
   uint32_t groups_left = wg_num_groups(st, g);
   uint32_t total_closest = 0, total_shadow = 0, total_hits = 0, total_unocc = 0;   // (thread 0's copies are published)
   if (groups_left != 0) {
     uint32_t k_next = 0;                     // next group of this workgroup's sample sequence
-    if (threadIdx.x == 0) { sh.n_ray[0] = 0; sh.n_ray[1] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; }
+    if (threadIdx.x == 0) { sh.n_ray[0] = 0; sh.n_ray[1] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; sh.cam_first = 0xFFFFFFFFu; sh.cam_k0 = 0; sh.n_cam_dead = 0; }
     if (USE_BVH) load_hot_nodes(sc, sh);
     uint32_t waves = blockDim.x >> 6;
     wg_sync(waves);
     for (uint32_t parity = 0;; parity ^= 1u) {
-      // top-up: new camera paths behind the continuing ones, whole 64-sample groups while they fit
+      // top-up: new camera paths behind the continuing ones, whole 64-sample groups while they fit.  IMPLICIT (kernels with
+      // the packet stage): nothing is written - positions [n0, n0 + 64 * ngen) simply ARE the samples of groups k0 ... of the
+      // workgroup's sequence; the packet stage builds their rays and shade rebuilds the paths that hit (camera_ray).
       const uint32_t n0 = uni(sh.n_ray[parity]);
       const uint32_t ngen = min(groups_left, (st.pool - n0) >> 6);
+      const uint32_t k0 = k_next;
       if (ngen != 0) {
+        if (!IMPLICIT) {
 #ifdef HJ_WALK_STATS
-        const unsigned long long gen_t0 = wall_clock64();
+          const unsigned long long gen_t0 = wall_clock64();
 #endif
 #if HJ_SHADE_CALL >= 2
-        stage_gen_camera_call<NT>(ka_lo, ka_hi, g, sh_lds, parity, n0, k_next, ngen, waves);
+          stage_gen_camera_call<NT>(ka_lo, ka_hi, g, sh_lds, parity, n0, k_next, ngen, waves);
 #else
-        stage_gen_camera<NT>(st, sc, g, sh, parity, n0, k_next, ngen, waves);
+          stage_gen_camera<NT>(st, sc, g, sh, parity, n0, k_next, ngen, waves);
 #endif
+          wg_sync(waves);
+#ifdef HJ_WALK_STATS
+          if (threadIdx.x == 0) atomicAdd(&g_round_stats[24], (wall_clock64() - gen_t0) * waves);
+#endif
+        }
         k_next += ngen;
         groups_left -= ngen;
-        wg_sync(waves);
-#ifdef HJ_WALK_STATS
-        if (threadIdx.x == 0) atomicAdd(&g_round_stats[24], (wall_clock64() - gen_t0) * waves);
-#endif
       }
-      const uint32_t n = n0 + uni(sh.n_gen), ns = uni(sh.n_shadow);
+      const uint32_t n = IMPLICIT ? n0 + 64u * ngen : n0 + uni(sh.n_gen), ns = uni(sh.n_shadow);
       if (n + ns == 0) {
         if (groups_left == 0) break;
         // every sample of the new groups lay outside its block: next groups.  The other parity's path count is the one the
@@ -1286,19 +1335,22 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
       const uint32_t round_rays = n + ns;
 #endif
       wg_sync(waves);                        // everyone has read the counts before they are reset
-      if (threadIdx.x == 0) { sh.head = 0; sh.head_cam = 0; sh.n_ray[parity ^ 1u] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; }
+      if (threadIdx.x == 0) {
+        sh.head = 0; sh.head_cam = 0; sh.n_ray[parity ^ 1u] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0;
+        sh.cam_first = (IMPLICIT && ngen != 0) ? n0 : 0xFFFFFFFFu; sh.cam_k0 = k0; sh.n_cam_dead = 0;
+      }
       if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
       wg_sync(waves);
 #ifdef HJ_WALK_STATS
       const unsigned long long st_t0 = wall_clock64();
 #endif
-      // the round's new camera rays are the LAST entries of the closest-hit queue: whole packets of 64 of them are walked
-      // together over the uploaded array (stage_camera_packets), the merged walk takes the rest and the shadow rays
+      // the round's new camera rays are the LAST entries of the closest-hit queue: they are walked as packets of 64
+      // (stage_camera_packets: one group of a block row each), the merged walk takes the continuing paths and the shadow rays
       uint32_t cam = 0;
 #if HJ_CAMERA_PACKETS && HJ_SHADE_CALL >= 2
-      if (USE_BVH && PAIRS && waves > 1u) {
-        cam = ((n - n0) >> 6) << 6;
-        if (cam != 0) stage_camera_packets_call<NT>(ka_lo, ka_hi, g, parity, n - cam, cam >> 6, sh_lds);
+      if (IMPLICIT && ngen != 0) {
+        cam = 64u * ngen;
+        stage_camera_packets_call<NT>(ka_lo, ka_hi, g, parity, n0, ngen, k0, sh_lds);
       }
 #endif
       stage_trace_merged<USE_BVH, PAIRS, NT>(st, sc, g, parity, n - cam, ns, sh);
@@ -1322,7 +1374,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
 #else
       if (n != 0) stage_shade<NT>(st, sc, g, parity, max_bounces, rr_start, sh, waves);
 #endif
-      total_closest += n;
+      total_closest += n - uni(sh.n_cam_dead);   // (positions of ragged blocks' groups that hold no sample are not rays)
       total_shadow += ns;
       for (uint32_t k = 0; k < kNumTags; k++) total_hits += uni(sh.cnt_hit[k]);
       total_unocc += uni(sh.n_unocc);
@@ -1410,7 +1462,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(BatchState st, DeviceSc
                                                          uint32_t max_bounces, uint32_t rr_start) {
   __shared__ WgShared sh;
   const uint32_t g = blockIdx.x;
-  if (threadIdx.x == 0) { sh.n_ray[parity ^ 1u] = 0; sh.n_shadow = 0; }
+  if (threadIdx.x == 0) { sh.n_ray[parity ^ 1u] = 0; sh.n_shadow = 0; sh.cam_first = 0xFFFFFFFFu; sh.cam_k0 = 0; }   // (every camera path has records here)
   if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = st.cnt_hit[g * kNumTags + threadIdx.x];
   __syncthreads();
   stage_shade<false>(st, sc, g, parity, max_bounces, rr_start, sh, blockDim.x >> 6);

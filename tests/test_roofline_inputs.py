@@ -32,7 +32,7 @@ def test_bench_byte_model_is_consistent():
     import bench
     st = {"paths": 1000, "closest_rays": 3050, "shadow_rays": 1790, "hits": 2900, "unoccluded_shadow_rays": 1200}
     b = bench.implemented_bytes(st)
-    assert 800 < b / st["paths"] < 1000                     # cbox: 880 B/path
+    assert 700 < b / st["paths"] < 850                      # cbox: 780 B/path (880 before camera paths lost their records)
     assert 0 < bench.coalesced_read_bytes(st) < b
     st2 = {k: 2 * v for k, v in st.items()}
     assert abs(bench.implemented_bytes(st2) - 2 * b) < 1e-6 * b
