@@ -80,7 +80,6 @@ struct hj_context {
     hipStream_t stream = nullptr;
     hipStream_t rstream = nullptr;        // the reconstruction's stream (high priority: see hj_context_create)
     hipEvent_t ev_path = nullptr;         // this slot's path kernel has finished (the reconstruction stream waits for it)
-    hipEvent_t ev_main = nullptr, ev_tail = nullptr;   // MAIN launch done (the TAIL launch on the priority stream waits for it); TAIL launch done
     hj_image_block* h_blocks = nullptr;   // pinned staging of the block list
     uint32_t h_blocks_cap = 0;
     uint32_t* h_counts = nullptr;         // pinned read-back: 2 (split-path ray counts) + 4 (statistics) arrays of num_wg words
@@ -98,9 +97,6 @@ struct hj_context {
   uint32_t num_wg_eff = 2048;            // ... of the current call
   uint32_t pool = 65536;                 // path slots per workgroup of the fused kernel (HJ_POOL)
   uint32_t pool_eff = 65536;             // ... as the current render call uses it (lowered when device memory is short)
-  uint32_t tail_export = 256;            // rays of a round at which a workgroup hands its paths to the batch's TAIL launch (HJ_TAIL_EXPORT; 0: never)
-  uint32_t tail_merge = 8;               // tails per workgroup of the TAIL launch (HJ_TAIL_MERGE)
-  bool tail_priority = true;             // the TAIL launch runs on the slot's high-priority stream (HJ_TAIL_PRIORITY)
 
   // timing
   std::vector<EventPair> events;
@@ -321,8 +317,6 @@ int ensure_batch(hj_context* ctx, hj_context::BatchSlot& sl, uint32_t num_blocks
     HJ_ALLOC(sl.bufs, cnt_hit, uint32_t, (size_t)Gmax * hj::kNumTags)
     HJ_ALLOC(sl.bufs, cnt_shadow, uint32_t, Gmax)
     HJ_ALLOC(sl.bufs, acc_closest, uint32_t, (size_t)4 * Gmax)  // closest | shadow | hits | unoccluded, one read-back
-    HJ_ALLOC(sl.bufs, tail_list, uint4, Gmax)                   // tail hand-off (kernels/hj_kernels.h)
-    HJ_ALLOC(sl.bufs, tail_ctr, uint32_t, 4)
     if (rc == HJ_OK) sl.alloc_positions = n;
   }
 #undef HJ_ALLOC
@@ -488,46 +482,17 @@ int enqueue_batch_fused(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::
   int rc = stage_blocks(ctx, sl, blocks, nb, st, false);
   if (rc != HJ_OK) return rc;
   const dim3 blk(hj::kBlockThreads), grid(st.num_wg);
-  // Tail hand-off (kernels/hj_kernels.h): the MAIN launch's workgroups stop at tail_export rays, the TAIL launch behind it
-  // finishes tail_merge of those tails per workgroup.  HJ_TAIL_EXPORT (rays; 0: every workgroup finishes its own paths, as in
-  // rounds 1-3) / HJ_TAIL_MERGE, read at context creation.  The merged tails must fit the first one's segment:
-  // tail_export * tail_merge <= pool (tiny batches hand over later, at pool / tail_merge rays).
-  st.tail_merge = ctx->tail_merge;
-  st.tail_export = std::min(ctx->tail_export, st.pool / st.tail_merge);
-  if (st.num_wg < 2u * st.tail_merge) st.tail_export = 0;
-  if (st.tail_export != 0) HJ_HIP(ctx, hipMemsetAsync(st.tail_ctr, 0, sizeof(uint32_t) * 4, sl.stream));
   const int ev = tm.begin(EV_PATH, sl.stream);
   // HJ_LDS_PAD_KB (diagnostic): unused dynamic LDS that lowers the number of resident workgroups per CU without
   // touching the code, to measure how the frame rate scales with occupancy.
   static const size_t lds_pad = (size_t)env_int("HJ_LDS_PAD_KB", 0, 0, 64) * 1024;
   const bool pairs = ctx->scene.has_pairs != 0, nt = ctx->scene.stream_state != 0;
-#define HJ_LAUNCH_PATH(TAIL, GRID, STREAM)                                                                                              \
-  do {                                                                                                                           \
-    if (!o.use_bvh) hipLaunchKernelGGL((hj::k_path_wavefront<false, false, false, TAIL>), GRID, blk, lds_pad, STREAM, st, ctx->scene, o.max_bounces, o.rr_start); \
-    else if (pairs && nt) hipLaunchKernelGGL((hj::k_path_wavefront<true, true, true, TAIL>), GRID, blk, lds_pad, STREAM, st, ctx->scene, o.max_bounces, o.rr_start); \
-    else if (pairs) hipLaunchKernelGGL((hj::k_path_wavefront<true, true, false, TAIL>), GRID, blk, lds_pad, STREAM, st, ctx->scene, o.max_bounces, o.rr_start); \
-    else if (nt) hipLaunchKernelGGL((hj::k_path_wavefront<true, false, true, TAIL>), GRID, blk, lds_pad, STREAM, st, ctx->scene, o.max_bounces, o.rr_start); \
-    else hipLaunchKernelGGL((hj::k_path_wavefront<true, false, false, TAIL>), GRID, blk, lds_pad, STREAM, st, ctx->scene, o.max_bounces, o.rr_start); \
-  } while (0)
-  HJ_LAUNCH_PATH(false, grid, sl.stream);
-  hipStream_t ts = sl.stream;
-  if (st.tail_export != 0) {
-    // The TAIL launch goes to the slot's high-priority stream (the reconstruction's): its few workgroups must not queue
-    // behind the thousands of waiting workgroups of the other slots' MAIN launches - the slot is not free before they ran.
-    const dim3 tail_grid((st.num_wg + st.tail_merge - 1u) / st.tail_merge);
-    if (sl.rstream && ctx->tail_priority) {
-      HJ_HIP(ctx, hipEventRecord(sl.ev_main, sl.stream));
-      HJ_HIP(ctx, hipStreamWaitEvent(sl.rstream, sl.ev_main, 0));
-      ts = sl.rstream;
-    }
-    HJ_LAUNCH_PATH(true, tail_grid, ts);
-    if (ts != sl.stream) {
-      HJ_HIP(ctx, hipEventRecord(sl.ev_tail, ts));
-      HJ_HIP(ctx, hipStreamWaitEvent(sl.stream, sl.ev_tail, 0));
-    }
-  }
-#undef HJ_LAUNCH_PATH
-  tm.end(ev, ts);
+  if (!o.use_bvh) hipLaunchKernelGGL((hj::k_path_wavefront<false, false, false>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  else if (pairs && nt) hipLaunchKernelGGL((hj::k_path_wavefront<true, true, true>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  else if (pairs) hipLaunchKernelGGL((hj::k_path_wavefront<true, true, false>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  else if (nt) hipLaunchKernelGGL((hj::k_path_wavefront<true, false, true>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  else hipLaunchKernelGGL((hj::k_path_wavefront<true, false, false>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  tm.end(ev, sl.stream);
   if (reconstruct) {
     rc = enqueue_reconstruct(ctx, sl, other, st, nb, o, tm);
     if (rc != HJ_OK) return rc;
@@ -689,13 +654,10 @@ int hj_context_create(int device, hj_context** out) {
   // phases of a round are long, their ramp-down costs once per round: c2 +6 %, c3 +4 % over 8192 positions with path
   // regeneration; 32768: +4.5 %; 24.7 GB of path state per batch slot, lowered by run_begin when the device is short of memory)
   ctx->pool = (uint32_t)env_int("HJ_POOL", 65536, 64, 1 << 20) / 64u * 64u;
-  ctx->tail_export = (uint32_t)env_int("HJ_TAIL_EXPORT", 256, 0, 1 << 20);
-  ctx->tail_merge = (uint32_t)env_int("HJ_TAIL_MERGE", 8, 1, 64);
-  ctx->tail_priority = env_int("HJ_TAIL_PRIORITY", 1, 0, 1) != 0;
   for (auto& sl : ctx->slots) {
     if ((e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     if ((e = hipHostMalloc((void**)&sl.h_counts, sizeof(uint32_t) * 6 * ctx->num_wg, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
-    for (hipEvent_t* ev : {&sl.ev_count[0], &sl.ev_count[1], &sl.ev_recon, &sl.ev_done, &sl.ev_path, &sl.ev_main, &sl.ev_tail})
+    for (hipEvent_t* ev : {&sl.ev_count[0], &sl.ev_count[1], &sl.ev_recon, &sl.ev_done, &sl.ev_path})
       if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   }
   // HJ_RECON_PRIORITY (default 1): the reconstructions run on one stream per slot of the device's highest priority.
@@ -734,7 +696,7 @@ void hj_context_destroy(hj_context* ctx) {
     if (sl.h_tiles) (void)hipHostFree(sl.h_tiles);
     if (sl.h_blocks) (void)hipHostFree(sl.h_blocks);
     if (sl.h_counts) (void)hipHostFree(sl.h_counts);
-    for (hipEvent_t ev : {sl.ev_count[0], sl.ev_count[1], sl.ev_recon, sl.ev_done, sl.ev_path, sl.ev_main, sl.ev_tail})
+    for (hipEvent_t ev : {sl.ev_count[0], sl.ev_count[1], sl.ev_recon, sl.ev_done, sl.ev_path})
       if (ev) (void)hipEventDestroy(ev);
     if (sl.rstream) (void)hipStreamDestroy(sl.rstream);
     if (sl.stream) (void)hipStreamDestroy(sl.stream);

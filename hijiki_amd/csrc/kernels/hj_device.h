@@ -103,13 +103,6 @@ struct BatchState {
   uint32_t* acc_shadow;   // [num_wg] shadow rays
   uint32_t* acc_hits;     // [num_wg] closest-hit rays that hit something
   uint32_t* acc_unoccluded;   // [num_wg] shadow rays that reached their light
-  // Tail hand-off (hj_kernels.h k_path_wavefront): a workgroup whose samples are used up and whose round has shrunk to
-  // tail_export rays leaves its paths where they are, notes (g, parity, paths, shadow records) in tail_list and exits; the
-  // batch's TAIL launch merges tail_merge of them per workgroup and finishes them.  tail_ctr[0] = tails noted, [1] = claimed.
-  uint4* tail_list;       // [num_wg]
-  uint32_t* tail_ctr;     // [2], zeroed before the batch's first launch
-  uint32_t tail_export;   // rays of a round at which a workgroup hands its paths over (0: it finishes them itself)
-  uint32_t tail_merge;    // tails per workgroup of the TAIL launch
   const hj_image_block* blocks;  // the batch's ImageBlocks
   uint32_t num_blocks;
   uint32_t capacity;             // samples allocated

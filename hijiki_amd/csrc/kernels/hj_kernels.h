@@ -655,8 +655,6 @@ struct WgShared {                 // LDS of a path workgroup (16.5 KB)
   uint32_t cam_first;             // 0xFFFFFFFF: none (every camera path of the round has explicit records)
   uint32_t cam_k0;
   uint32_t n_cam_dead;            // statistics: positions of those groups that hold no sample (ragged blocks)
-  uint32_t tail_base;             // TAIL launch: first entry of tail_list this workgroup claimed,
-  uint32_t tail_g, tail_parity, tail_n, tail_ns;   // ... and what it runs: segment (0xFFFFFFFF: nothing claimed), parity, paths, shadow records
   float4 nodes[2 * kHotNodes];    // LDS copy of the hottest BVH nodes (same record layout as DeviceScene::nodes)
 };
 
@@ -1253,50 +1251,6 @@ __device__ __attribute__((noinline)) void stage_camera_packets_call(uint32_t ka_
   stage_camera_packets<NT>(st, sc, uni(g), uni(parity), uni(first), uni(chunks), uni(k0), sh);
 }
 
-// TAIL launch: claim up to st.tail_merge noted tails and gather them in the first one's segment (copies of the records of
-// the others behind the first one's: paths into the arrays of the first one's parity, shadow records behind its shadow
-// records).  Leaves segment, parity and counts in sh.tail_*; ends with the copies issued, not yet synchronised.
-template <bool NT>
-HJ_DEV void tail_claim(const BatchState& st, const DeviceScene& sc, WgShared& sh) {
-  if (threadIdx.x == 0) sh.tail_base = atomicAdd(&st.tail_ctr[1], st.tail_merge);
-  __syncthreads();
-  const uint32_t base = uni(sh.tail_base), noted = st.tail_ctr[0];
-  if (base >= noted) {
-    if (threadIdx.x == 0) sh.tail_g = 0xFFFFFFFFu;
-    return;
-  }
-  const uint32_t m = min(st.tail_merge, noted - base);
-  const uint4 first = st.tail_list[base];
-  const uint32_t parity0 = first.y, dst = first.x * st.pool;
-  uint32_t tail_n = first.z, tail_ns = first.w;
-  for (uint32_t j = 1; j < m; j++) {
-    const uint4 t = st.tail_list[base + j];
-    const uint32_t src = t.x * st.pool;
-    for (uint32_t i = threadIdx.x; i < t.z; i += blockDim.x) {      // (tail_export * tail_merge <= pool: the host sees to it)
-      stp<NT>(st.ray_o[parity0], dst + tail_n + i, ldp<NT>(st.ray_o[t.y], src + i));
-      stp<NT>(st.ray_d[parity0], dst + tail_n + i, ldp<NT>(st.ray_d[t.y], src + i));
-      stp<NT>(st.thr[parity0], dst + tail_n + i, ldp<NT>(st.thr[t.y], src + i));
-      if (sc.has_extinction) stp<NT>(st.ext[parity0], dst + tail_n + i, ldp<NT>(st.ext[t.y], src + i));
-    }
-    for (uint32_t i = threadIdx.x; i < t.w; i += blockDim.x) {
-      stp<NT>(st.sh_o, dst + tail_ns + i, ldp<NT>(st.sh_o, src + i));
-      stp<NT>(st.sh_d, dst + tail_ns + i, ldp<NT>(st.sh_d, src + i));
-      stp<NT>(st.sh_c, dst + tail_ns + i, ldp<NT>(st.sh_c, src + i));
-    }
-    tail_n += t.z; tail_ns += t.w;
-  }
-  if (threadIdx.x == 0) { sh.tail_g = first.x; sh.tail_parity = parity0; sh.tail_n = tail_n; sh.tail_ns = tail_ns; }
-}
-template <bool NT>
-__device__ __attribute__((noinline)) void tail_claim_call(uint32_t ka_lo, uint32_t ka_hi, uint32_t sh_lds) {
-  typedef const __attribute__((address_space(4))) char* KArg;
-  KArg ka = (KArg)(((uint64_t)uni(ka_hi) << 32) | (uint64_t)uni(ka_lo));
-  const BatchState& st = *(const BatchState*)ka;
-  const DeviceScene& sc = *(const DeviceScene*)(ka + kSceneArgOffset);
-  WgShared& sh = *(WgShared*)(WgSharedLds)(uintptr_t)uni(sh_lds);
-  tail_claim<NT>(st, sc, sh);
-}
-
 // ------------------------------------------------------------------ kernels
 
 // The whole life of a batch in ONE launch.  Every workgroup walks through ITS samples (64-sample groups g, g + G, ...):
@@ -1316,51 +1270,27 @@ __device__ __attribute__((noinline)) void tail_claim_call(uint32_t ka_lo, uint32
 #ifndef HJ_PATH_WAVES
 #define HJ_PATH_WAVES 7   // 72 VGPRs; measured on the compacted-record kernel: 6 waves (80 VGPRs) -6 %, 8 waves (64 VGPRs) -2 %, 5 waves -5 %
 #endif
-// TAIL hand-off (st.tail_export != 0).  The rounds of a workgroup whose samples are used up shrink bounce by bounce, and a
-// workgroup down to a few rays still holds its 16.5 KB of LDS and a wave on a SIMD for hundreds of rounds when a specular
-// chain lives on (a CU is full at 9 workgroups by LDS: seven one-wave tails leave room for two full workgroups).  So the
-// MAIN launch (TAIL = false) stops there: at tail_export rays the workgroup notes (g, parity, paths, shadow records) in
-// st.tail_list - its records already lie compacted in its segment - and exits.  The batch's TAIL launch (same code, TAIL =
-// true, a grid of num_wg / tail_merge workgroups behind the main launch on the same stream) claims tail_merge entries per
-// workgroup, copies the records of all but the first behind the first one's in ITS segment and runs the ordinary rounds on
-// them to the end: an eighth of the workgroups for the same tail.  Per path nothing changes (same records, same stages).
-template <bool USE_BVH, bool PAIRS, bool NT, bool TAIL>
+template <bool USE_BVH, bool PAIRS, bool NT>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(HJ_PATH_WAVES, 8))) void k_path_wavefront(BatchState st, DeviceScene sc, uint32_t max_bounces,
                                                                   uint32_t rr_start) {
   // NT (large trees): the path state is streamed past the caches (ldp / stp)
   __shared__ WgShared sh;
-  uint32_t g = blockIdx.x;
+  const uint32_t g = blockIdx.x;
 #if HJ_SHADE_CALL
   const uint64_t ka_ = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
   const uint32_t ka_lo = (uint32_t)ka_, ka_hi = (uint32_t)(ka_ >> 32), sh_lds = (uint32_t)(uintptr_t)(WgSharedLds)&sh;
 #endif
   // Camera paths without records: kernels that have the packet stage (BVH walk over a tree with pair nodes, stages called)
   constexpr bool IMPLICIT = HJ_CAMERA_PACKETS && HJ_SHADE_CALL >= 2 && USE_BVH && PAIRS;
-  uint32_t groups_left = TAIL ? 0u : wg_num_groups(st, g);
+  uint32_t groups_left = wg_num_groups(st, g);
   uint32_t total_closest = 0, total_shadow = 0, total_hits = 0, total_unocc = 0;   // (thread 0's copies are published)
-  uint32_t parity0 = 0, tail_n = 0, tail_ns = 0;
-  bool run = groups_left != 0;
-  if (TAIL) {
-#if HJ_SHADE_CALL >= 2
-    tail_claim_call<NT>(ka_lo, ka_hi, sh_lds);
-#else
-    tail_claim<NT>(st, sc, sh);
-#endif
-    __syncthreads();
-    if (uni(sh.tail_g) == 0xFFFFFFFFu) return;          // nothing left to claim
-    g = uni(sh.tail_g); parity0 = uni(sh.tail_parity); tail_n = uni(sh.tail_n); tail_ns = uni(sh.tail_ns);
-    run = true;
-  }
-  if (run) {
+  if (groups_left != 0) {
     uint32_t k_next = 0;                     // next group of this workgroup's sample sequence
-    if (threadIdx.x == 0) {
-      sh.n_ray[0] = 0; sh.n_ray[1] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; sh.cam_first = 0xFFFFFFFFu; sh.cam_k0 = 0; sh.n_cam_dead = 0;
-      if (TAIL) { sh.n_ray[parity0] = tail_n; sh.n_shadow = tail_ns; }
-    }
+    if (threadIdx.x == 0) { sh.n_ray[0] = 0; sh.n_ray[1] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; sh.cam_first = 0xFFFFFFFFu; sh.cam_k0 = 0; sh.n_cam_dead = 0; }
     if (USE_BVH) load_hot_nodes(sc, sh);
     uint32_t waves = blockDim.x >> 6;
     wg_sync(waves);
-    for (uint32_t parity = parity0;; parity ^= 1u) {
+    for (uint32_t parity = 0;; parity ^= 1u) {
       // top-up: new camera paths behind the continuing ones, whole 64-sample groups while they fit.  IMPLICIT (kernels with
       // the packet stage): nothing is written - positions [n0, n0 + 64 * ngen) simply ARE the samples of groups k0 ... of the
       // workgroup's sequence; the packet stage builds their rays and shade rebuilds the paths that hit (camera_ray).
@@ -1393,12 +1323,6 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
         if (threadIdx.x == 0) sh.n_ray[parity ^ 1u] = 0;
         wg_sync(waves);
         continue;
-      }
-      // Hand-over (MAIN launch): the samples are used up and the round is down to tail_export rays, all of them with records
-      // (ngen == 0: no implicit camera path in this round) - the TAIL launch takes them from here.
-      if (!TAIL && st.tail_export != 0u && ngen == 0u && groups_left == 0u && n + ns <= st.tail_export) {
-        if (threadIdx.x == 0) st.tail_list[atomicAdd(&st.tail_ctr[0], 1u)] = make_uint4(g, parity, n, ns);
-        break;
       }
       // Tail of the workgroup: one wave can hold every ray of a round and the counts never grow again.
       if (waves > 1u && groups_left == 0 && n + ns <= HJ_TAIL1) {
@@ -1471,11 +1395,11 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
 #endif
     }
   }
-  if (threadIdx.x == 0) {                    // (the TAIL launch adds to what the segment's own workgroup counted)
-    st.acc_closest[g] = (TAIL ? st.acc_closest[g] : 0u) + total_closest;
-    st.acc_shadow[g] = (TAIL ? st.acc_shadow[g] : 0u) + total_shadow;
-    st.acc_hits[g] = (TAIL ? st.acc_hits[g] : 0u) + total_hits;
-    st.acc_unoccluded[g] = (TAIL ? st.acc_unoccluded[g] : 0u) + total_unocc;
+  if (threadIdx.x == 0) {
+    st.acc_closest[g] = total_closest;
+    st.acc_shadow[g] = total_shadow;
+    st.acc_hits[g] = total_hits;
+    st.acc_unoccluded[g] = total_unocc;
   }
 }
 

@@ -124,7 +124,7 @@ def test_walk_of_the_fused_kernel_is_spill_free():
     res = spill_scan.scan()
     walks = [e for e in res if e["name"].startswith("k_path_wavefront<USE_BVH=1")]
     packets = [e for e in res if e["name"].startswith("stage_camera_packets_call")]
-    assert len(walks) == 8 and len(packets) == 2, [e["name"] for e in res]   # pair nodes x streamed path state x MAIN / TAIL launch; NT on / off
+    assert len(walks) == 4 and len(packets) == 2, [e["name"] for e in res]   # pair nodes x streamed path state; NT on / off
     for e in walks + packets:
         assert e["max_loop_depth"] >= e["hot_depth"], e["name"]               # (the scan saw the loops it is meant to check)
         assert e["scratch_in_hot_loops"] == 0, (e["name"], e["hot_list"])

@@ -964,9 +964,6 @@ def test_four_contexts_in_flight_on_one_gpu(cbox, monkeypatch):
     {"HJ_PAIR_LEAVES": "0", "HJ_STREAM_STATE": "1"},                # the plain-leaf instantiation with streamed state
     {"HJ_COLLAPSE_PCT": "0", "HJ_NODE_ORDER": "1"},                 # no collapse, sibling groups
     {"HJ_SLOTS": "1", "HJ_WG_PER_CU": "1", "batch_blocks": "1"},    # one batch slot, 256 workgroups, one ImageBlock per batch
-    {"HJ_TAIL_EXPORT": "0"},                                        # no tail hand-off: every workgroup finishes its own paths
-    {"HJ_TAIL_EXPORT": "100000", "HJ_TAIL_MERGE": "2", "HJ_POOL": "4096"},   # hand-over as early as the pool allows, two tails per workgroup
-    {"HJ_TAIL_EXPORT": "16", "HJ_TAIL_MERGE": "64", "HJ_WG_PER_CU": "2"},    # late hand-over, 64 tails per workgroup
 ], ids=lambda e: ",".join(f"{k.replace('HJ_', '')}={v}" for k, v in e.items()))
 def test_tuning_switches_never_change_a_bit(oracle, cbox_spheres, monkeypatch, env):
     """DESIGN.md section 4's tuning switches (read by the library at context creation / scene upload) steer scheduling
@@ -985,25 +982,6 @@ def test_tuning_switches_never_change_a_bit(oracle, cbox_spheres, monkeypatch, e
         got, st = render(r, cbox_spheres, W, H, blocks, opts)
     assert_same(got, want, f"switches {env}")
     assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"]
-
-
-@pytest.mark.gpu
-def test_tail_hand_off_at_a_larger_frame(oracle, cbox_spheres, monkeypatch):
-    """The tail hand-off with real tails: 512 x 384 x 6 on the mirror + glass scene gives every workgroup some hundred paths,
-    so its rounds decay through the hand-over threshold while specular chains are still alive; merged eight (default) and
-    three to a workgroup, and switched off: the same frame and the same ray counts, bit for bit the oracle's."""
-    W, H = 512, 384
-    blocks = host.make_blocks(W, H, 6, 23)
-    want, ctr, _ = oracle.render_blocks(cbox_spheres, blocks, W, H)
-    for env in ({}, {"HJ_TAIL_EXPORT": "64", "HJ_TAIL_MERGE": "3"}, {"HJ_TAIL_EXPORT": "0"}):
-        for k in ("HJ_TAIL_EXPORT", "HJ_TAIL_MERGE"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        with device.Renderer(0) as r:
-            got, st = render(r, cbox_spheres, W, H, blocks)
-        assert_same(got, want, f"tail hand-off {env}")
-        assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"] and st["hits"] == ctr["hits"]
 
 
 @pytest.mark.gpu

@@ -17,7 +17,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # function-name pattern -> (label, loop depth from which a scratch instruction counts as "hot")
 FUNCS = [
-    (r"_ZN2hj16k_path_wavefrontILb([01])ELb([01])ELb([01])ELb([01])E", "k_path_wavefront<USE_BVH={0}, PAIRS={1}, NT={2}, TAIL={3}>", 2),
+    (r"_ZN2hj16k_path_wavefrontILb([01])ELb([01])ELb([01])E", "k_path_wavefront<USE_BVH={0}, PAIRS={1}, NT={2}>", 2),
     (r"_ZN2hj25stage_camera_packets_callILb([01])E", "stage_camera_packets_call<NT={0}>", 2),
     (r"_ZN2hj17compact_hits_callILb([01])ELj(\d+)E", "compact_hits_call<NT={0}, R={1}>", 1),
     (r"_ZN2hj16stage_shade_callILb([01])E", "stage_shade_call<NT={0}>", 99),
