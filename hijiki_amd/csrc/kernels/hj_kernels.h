@@ -399,9 +399,15 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     // then, so that result STORES and new-ray LOADS are issued together, once per phase: vmcnt counts loads and
     // stores in one in-order counter on gfx950, and a store between two node fetches would stall the walk for
     // a full write acknowledgement.
+#ifdef HJ_LANE_LIMIT   // diagnostic: only the first HJ_LANE_LIMIT lanes of a wave ever hold a ray - how the cost of a wave-step depends on its active lanes
+    const unsigned long long idle = __ballot(!active && lane < (uint32_t)(HJ_LANE_LIMIT));
+    const uint32_t nidle = (uint32_t)__popcll(idle);
+    const bool service = nidle >= (sc.refill_min * (uint32_t)(HJ_LANE_LIMIT) + 63u) / 64u || nidle == (uint32_t)(HJ_LANE_LIMIT);
+#else
     const unsigned long long idle = __ballot(!active);
     const uint32_t nidle = (uint32_t)__popcll(idle);
     const bool service = nidle >= sc.refill_min || nidle == 64u;
+#endif
     // The loads of the NEW rays are issued first, the results of the finished ones are written (and, for an unoccluded
     // shadow ray, its sample read, added to and written) after them: both memory round trips are then in flight
     // together, and the wait for the new rays does not include the stores (vmcnt retires in order: only what was
@@ -414,7 +420,11 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
       uint32_t base = 0;
       if (lane == 0) base = atomicAdd(s_head, nidle);
       base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#ifdef HJ_LANE_LIMIT
+      if (!active && lane < (uint32_t)(HJ_LANE_LIMIT)) {
+#else
       if (!active) {
+#endif
         const uint32_t my = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
         if (my < n) { fetch(my, slot2, r2, any2, h2); got = true; }
       }
@@ -432,6 +442,33 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
       cur = sc.root; active = true;
     }
     if (__ballot(active || pending) == 0) break;   // (a lane can finish in the merged first step: its result is written by the next service phase)
+#ifdef HJ_LDS_RT_PROBE
+    // What ONE re-grouping of the wave's rays through LDS costs at the very least: a queue push (ballot + LDS atomic) and the
+    // ray's state (12 dwords here; a design needs 14 or more) written to a slot and read back - here to the lane's own slot
+    // (conflict-free; slots picked from a queue would be scattered).  HJ_LDS_RT_PROBE = how many of them per round of the walk loop.
+    {
+      // (WgShared is declared further down: rt_ctr and rt follow its node copy, which is what s_nodes points to)
+      char* rt_base = reinterpret_cast<char*>(const_cast<float4*>(s_nodes)) + 32u * kHotNodes;
+      uint32_t* rt_ctr = reinterpret_cast<uint32_t*>(rt_base);
+      float4* rt = reinterpret_cast<float4*>(rt_base + 16);
+      const uint32_t a0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)(rt + 3u * threadIdx.x);
+#pragma unroll
+      for (int k_ = 0; k_ < HJ_LDS_RT_PROBE; k_++) {
+        const uint32_t qpos = lds_push(&rt_ctr[k_ & 1], active);
+        f4s w0, w1, w2;
+        w0.x = r.o.x; w0.y = r.o.y; w0.z = r.o.z; w0.w = r.tmax;
+        w1.x = r.d.x; w1.y = r.d.y; w1.z = r.d.z; w1.w = r.tmin;
+        w2.x = h.t; w2.y = __int_as_float(h.id); w2.z = __uint_as_float(cur); w2.w = __uint_as_float(slot + (qpos & 0u));
+        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\tds_write_b128 %0, %3 offset:32"
+                     :: "v"(a0), "v"(w0), "v"(w1), "v"(w2) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(w0), "=&v"(w1), "=&v"(w2) : "v"(a0) : "memory");
+        r.o = V(w0.x, w0.y, w0.z); r.tmax = w0.w; r.d = V(w1.x, w1.y, w1.z); r.tmin = w1.w;
+        h.t = w2.x; h.id = __float_as_int(w2.y); cur = __float_as_uint(w2.z); slot = __float_as_uint(w2.w);
+      }
+    }
+#endif
     HJ_STAT(0, 1); HJ_STAT(7, __popcll(__ballot(active)));
 #ifdef HJ_WALK_STATS
     const unsigned long long t_b = clock64();
@@ -656,6 +693,10 @@ struct WgShared {                 // LDS of a path workgroup (16.5 KB)
   uint32_t cam_k0;
   uint32_t n_cam_dead;            // statistics: positions of those groups that hold no sample (ragged blocks)
   float4 nodes[2 * kHotNodes];    // LDS copy of the hottest BVH nodes (same record layout as DeviceScene::nodes)
+#ifdef HJ_LDS_RT_PROBE            // diagnostic: 48 bytes per lane, what a ray's state would occupy if rays were re-grouped through LDS
+  uint32_t rt_ctr[4];
+  float4 rt[3 * kBlockThreads];
+#endif
 };
 
 HJ_DEV void load_hot_nodes(const DeviceScene& sc, WgShared& sh) {
