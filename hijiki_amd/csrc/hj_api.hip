@@ -37,11 +37,16 @@ namespace {
 
 thread_local std::string g_create_error;
 
+std::atomic<size_t> g_dev_bytes{0};   // device memory held through DevBuf by every context of the process
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) {
+      (void)hipFree(p);
+      g_dev_bytes.fetch_sub(bytes, std::memory_order_relaxed);
+    }
     p = nullptr;
     bytes = 0;
   }
@@ -92,6 +97,7 @@ struct hj_context {
     size_t alloc_positions = 0;           // record positions the path-state arrays hold (workgroups x pool)
   } slots[kMaxSlots];
   uint32_t num_slots = 3;
+  uint32_t slots_eff = 3;                // ... the current render call rotates through (1 when device memory is very short)
   uint32_t num_wg = 2048;                // grid size of the path kernels of a large render call (= queue segments), and the most a call uses
   uint32_t num_wg_small = 1536;          // ... of a small one (run_begin)
   uint32_t num_wg_eff = 2048;            // ... of the current call
@@ -173,8 +179,14 @@ int dev_alloc(hj_context* ctx, DevBuf& b, size_t bytes) {
   if (b.bytes >= bytes && b.p) return HJ_OK;
   b.release();
   if (bytes == 0) bytes = 16;
+  // HJ_ALLOC_LIMIT_MB (test rig): the process's contexts together may hold no more than this; an allocation beyond it fails
+  // the way hipMalloc does on a full device - how the out-of-memory paths run on a 288 GB card.
+  static const size_t limit = (size_t)env_int("HJ_ALLOC_LIMIT_MB", 0, 0, 1 << 30) << 20;
+  if (limit != 0 && g_dev_bytes.load(std::memory_order_relaxed) + bytes > limit)
+    return set_error(ctx, HJ_ERR_NOMEM, "hipMalloc(%zu bytes): out of memory (HJ_ALLOC_LIMIT_MB)", bytes);
   HJ_HIP(ctx, hipMalloc(&b.p, bytes));
   b.bytes = bytes;
+  g_dev_bytes.fetch_add(bytes, std::memory_order_relaxed);
   return HJ_OK;
 }
 
@@ -1060,6 +1072,7 @@ struct RenderRun {
   size_t k = 0;            // batches enqueued so far (slot rotation)
   uint64_t paths = 0;
   uint32_t batch = 0;
+  uint32_t shrunk = 0;     // times run_submit lowered the pool or the batch after an allocation failed
   std::chrono::steady_clock::time_point wall0;
 };
 
@@ -1093,6 +1106,7 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
   static const size_t small_blocks = (size_t)env_int("HJ_WG_SMALL_BLOCKS", 12288, 0, 1 << 30);
   ctx->num_wg_eff = (!run.split && n < small_blocks) ? ctx->num_wg_small : ctx->num_wg;
   ctx->pool_eff = ctx->pool;
+  ctx->slots_eff = ctx->num_slots;
   if (!run.split) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -1128,6 +1142,18 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
   return HJ_OK;
 }
 
+// One step of the out-of-memory fallback (run_submit, hj_reserve): positions per workgroup down to 1024, then the batch down to
+// 64 ImageBlocks (unless the caller fixed it), then ONE batch slot instead of three, then 256 positions.  False: nothing left.
+bool shrink_footprint(hj_context* ctx, RenderRun& run) {
+  if (ctx->pool_eff > 1024u) ctx->pool_eff = std::max(1024u, ctx->pool_eff / 2u / 64u * 64u);
+  else if (!run.o.batch_blocks && run.batch > 64u) run.batch = std::max(64u, run.batch / 2u / 64u * 64u);
+  else if (ctx->slots_eff > 1u) ctx->slots_eff = 1u;
+  else if (ctx->pool_eff > 256u) ctx->pool_eff = std::max(256u, ctx->pool_eff / 2u / 64u * 64u);
+  else return false;
+  run.shrunk++;
+  return true;
+}
+
 // Enqueues the batches of `blocks` (copied into the slots' pinned staging before this returns).
 int run_submit(hj_context* ctx, RenderRun& run, const hj_image_block* blocks, size_t n) {
   for (size_t i = 0; i < n; i++) {
@@ -1144,12 +1170,28 @@ int run_submit(hj_context* ctx, RenderRun& run, const hj_image_block* blocks, si
   // frame loses to pipeline fill and drain does not depend on the size of the last kernels.)
   for (size_t begin = 0; begin < n && rc == HJ_OK; run.k++) {
     const uint32_t nb = (uint32_t)std::min<size_t>(run.batch, n - begin);
-    hj_context::BatchSlot& sl = ctx->slots[run.k % ctx->num_slots];
-    hj_context::BatchSlot& other = ctx->slots[(run.k + ctx->num_slots - 1) % ctx->num_slots];   // the previous batch's slot
+    hj_context::BatchSlot& sl = ctx->slots[run.k % ctx->slots_eff];
+    hj_context::BatchSlot& other = ctx->slots[(run.k + ctx->slots_eff - 1) % ctx->slots_eff];   // the previous batch's slot
     rc = harvest(ctx, sl, run.st);          // an older batch used this slot: its state arrays are free again
     if (rc != HJ_OK) break;
     rc = run.split ? render_batch_split(ctx, sl, other, blocks + begin, nb, run.o, run.tm, run.st, true)
                    : enqueue_batch_fused(ctx, sl, other, blocks + begin, nb, run.o, run.tm, run.st, true);
+    if (rc == HJ_ERR_NOMEM && !run.split) {
+      // The device ran out of memory AT the allocation (run_begin's estimate from hipMemGetInfo was taken before another
+      // context or the host application grew): nothing of this batch has been enqueued.  Wait for the batches in flight,
+      // give back every slot's arrays, shrink - the pool first (down to 1024 positions), then the batch unless the caller
+      // fixed it - and try this batch again; HJ_ERR_NOMEM only when nothing is left to shrink.
+      const std::string first_error = get_error(ctx);
+      int rc2 = HJ_OK;
+      for (auto& s2 : ctx->slots) { const int r3 = harvest(ctx, s2, run.st); if (rc2 == HJ_OK) rc2 = r3; }
+      if (rc2 == HJ_OK) rc2 = sync_all(ctx);
+      if (rc2 != HJ_OK) { rc = rc2; break; }
+      release_batch(ctx);
+      if (!shrink_footprint(ctx, run)) { set_error(ctx, HJ_ERR_NOMEM, "%s (pool, batch and slots are at their minimum)", first_error.c_str()); break; }
+      rc = HJ_OK;
+      run.k--;                               // (the loop's increment: this batch has not been enqueued)
+      continue;
+    }
     begin += nb;
   }
   return rc;
@@ -1221,13 +1263,19 @@ int hj_reserve(hj_context* ctx, size_t total_blocks, const hj_render_opts* opts)
   RenderRun run;
   int rc = run_begin(ctx, run, opts, nullptr, total_blocks);        // (the call's batch size, pool and workgroup count)
   if (rc != HJ_OK || run.split) return rc;
-  size_t left = total_blocks;
-  for (uint32_t k = 0; k < ctx->num_slots && left != 0 && rc == HJ_OK; k++) {
-    const uint32_t nb = (uint32_t)std::min<size_t>(run.batch, left);
-    rc = ensure_batch(ctx, ctx->slots[k], nb, false);
-    left -= nb;
+  for (;;) {
+    size_t left = total_blocks;
+    rc = HJ_OK;
+    for (uint32_t k = 0; k < ctx->slots_eff && left != 0 && rc == HJ_OK; k++) {
+      const uint32_t nb = (uint32_t)std::min<size_t>(run.batch, left);
+      rc = ensure_batch(ctx, ctx->slots[k], nb, false);
+      left -= nb;
+    }
+    if (rc != HJ_ERR_NOMEM) return rc;
+    // as in a render call (run_submit): give everything back, shrink the pool, then the batch, and try again
+    release_batch(ctx);
+    if (!shrink_footprint(ctx, run)) return rc;
   }
-  return rc;
 }
 
 int hj_render_blocks(hj_context* ctx, const hj_image_block* blocks, size_t n, const hj_render_opts* opts,

@@ -226,7 +226,15 @@ int hj_framebuffer_resolve(hj_context* ctx, float* host_rgb /* W*H*3 */);
 /* Optional set-up step (no counterpart upstream: Renderer::new creates every resource it needs, src/main.rs:1167-1314):
  * allocates the batch slots - path state and sample buffers - that a render call of `total_blocks` ImageBlocks with
  * these options will use (for hj_render_frame: spp x blocks per pass / world), so that the first frame does not pay for
- * them (86 GB and 1.3 s for the benchmark's frames at the defaults).  A render call allocates whatever is missing. */
+ * them (86 GB and 1.3 s for the benchmark's frames at the defaults).  A render call allocates whatever is missing.
+ * Preconditions: a scene has been uploaded and a framebuffer created (HJ_ERR_STATE otherwise, as for a render call: the
+ * sizes depend on both); no asynchronous frame in flight.  MEMORY: the defaults take up to 30 % of a 288 GB device (three
+ * batch slots of 24.7 GB of path state + 4.3 GB of samples each, for calls of 32768 ImageBlocks and more; a call of n
+ * blocks takes about n x 2.7 MB up to that).  Both hj_reserve and the render calls first fit their request to the free
+ * device memory (hipMemGetInfo) and, when an allocation fails all the same - another context or the host application took
+ * the memory in between -, give back every slot, halve the positions per workgroup (down to 1024), then the batch (down to
+ * 64 ImageBlocks), then run ONE batch slot instead of three, and try again: HJ_ERR_NOMEM is returned only when the smallest
+ * configuration (about 100 MB) does not fit, or hj_render_opts::batch_blocks fixed a batch that does not.  Slots keep what they hold until the context is destroyed or a larger request re-allocates them. */
 int hj_reserve(hj_context* ctx, size_t total_blocks, const hj_render_opts* opts /* NULL = defaults */);
 
 /* Replaces the body of Renderer::render (src/main.rs:1316-1355): for every

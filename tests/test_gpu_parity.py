@@ -1025,28 +1025,35 @@ def test_reserve_changes_nothing_but_the_first_frame_s_time(cbox_small):
 def test_async_frame_state_and_statistics(cbox_small):
     """hj_render_frame_async: other entry points answer HJ_ERR_STATE while the frame is in flight (never a race with the
     worker thread); the frame's statistics stay retrievable after a reduce has already joined it; a second frame reuses
-    the same worker thread; the frame equals the synchronous one bit for bit."""
-    W = H = 256
+    the same worker thread; the frame equals the synchronous one bit for bit.  The probe that must be refused does not
+    change anything when it is not (hj_framebuffer_read into a scratch buffer), and the frame is long enough (512 x 512 x
+    64: tens of milliseconds) to be in flight for certain when the probe runs right behind the call."""
+    import threading
+    W = H = 512
+    spp = 64
     with device.Renderer(0) as r:
         r.upload_scene(cbox_small)
         r.create_framebuffer(W, H)
-        want_st = r.render_frame(8, 5)
+        want_st = r.render_frame(spp, 5)
         want = r.read()
+        L = device.lib()
+        scratch = np.zeros((H, W, 4), np.float32)
         for _ in range(2):
             r.clear()
-            r.render_frame_async(8, 5)
-            L = device.lib()
-            rc = L.hj_framebuffer_clear(r._h)        # in flight (or just finished): HJ_ERR_STATE or HJ_OK, never a crash
-            assert rc in (abi.HJ_OK, abi.HJ_ERR_STATE)
-            if rc == abi.HJ_ERR_STATE:
-                assert b"in flight" in L.hj_last_error(r._h)
+            before = threading.active_count()
+            r.render_frame_async(spp, 5)
+            rc = L.hj_framebuffer_read(r._h, scratch.ctypes.data_as(C.POINTER(C.c_float)))
+            assert rc == abi.HJ_ERR_STATE and b"in flight" in L.hj_last_error(r._h)
+            assert L.hj_framebuffer_clear(r._h) == abi.HJ_ERR_STATE          # (refused: the frame's sums are not wiped)
+            assert threading.active_count() == before                        # (the worker is the library's own, not a Python thread)
             comm = device.Comm([r])
             comm.reduce(0)                            # joins the frame (hj_sync(ctx, NULL) inside)
             comm.close()
-            st = r.sync()                             # ... and the statistics are still there
-            if rc == abi.HJ_ERR_STATE:
-                assert st["paths"] == want_st["paths"] == W * H * 8 and st["closest_rays"] == want_st["closest_rays"]
-                assert (bits(r.read()) == bits(want)).all()
+            st = r.sync()                             # ... and the statistics are still there, unconditionally
+            assert st["paths"] == want_st["paths"] == W * H * spp and st["closest_rays"] == want_st["closest_rays"]
+            assert st["shadow_rays"] == want_st["shadow_rays"] and st["hits"] == want_st["hits"]
+            assert (bits(r.read()) == bits(want)).all()
+            assert r.sync() == st                     # the result stays retrievable until the next asynchronous frame
 
 
 @pytest.mark.gpu
@@ -1072,6 +1079,65 @@ def test_defaults_shrink_to_the_free_device_memory(cbox_small, monkeypatch):
     assert st["batches"] > st0["batches"]              # smaller batches than the default rule's 2048 blocks
     assert st["paths"] == st0["paths"] == W * H * spp and st["closest_rays"] == st0["closest_rays"]
     assert (bits(got) == bits(want)).all()
+
+
+_ALLOC_LIMIT_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np
+from hijiki_amd import abi, device, host
+cs = host.Scene.synthetic(host.SYNTH_CBOX, mesh_triangles=320).compile()
+W = H = 1024; spp = 64
+want = np.load(sys.argv[1])
+a, b = device.Renderer(0), device.Renderer(0)
+for r in (a, b):
+    r.upload_scene(cs); r.create_framebuffer(W, H)
+# run_begin's estimate sees a nearly empty 288 GB device; the allocations hit the (process-wide) limit
+st = a.render_frame(spp, 3)
+assert (a.read().view(np.uint32) == want.view(np.uint32)).all(), "context a"
+assert st["batches"] >= 4
+# the second context renders while the first one still holds its slots: less is left for it
+st2 = b.render_frame(spp, 3)
+assert (b.read().view(np.uint32) == want.view(np.uint32)).all(), "context b"
+assert st2["batches"] >= st["batches"]
+# both at once (worker threads), then hj_reserve of a whole large frame on top: shrinks, never crashes
+a.clear(); b.clear()
+a.render_frame_async(spp, 3); b.render_frame_async(spp, 3)
+a.sync(); b.sync()
+assert (a.read().view(np.uint32) == want.view(np.uint32)).all() and (b.read().view(np.uint32) == want.view(np.uint32)).all()
+a.reserve(64 * 512)
+# an explicit batch that cannot fit fails cleanly, with the allocation's message, and the context stays usable
+o = device.default_opts(); o.batch_blocks = 8192
+try:
+    b.render_frame(spp * 4, 3, opts=o)
+    raise SystemExit("an 8192-block batch (4.3 GB of samples) fitted a 3 GB limit?")
+except abi.HijikiError as e:
+    assert e.status == abi.HJ_ERR_NOMEM and "out of memory" in str(e), str(e)
+b.clear(); b.render_frame(spp, 3)
+assert (b.read().view(np.uint32) == want.view(np.uint32)).all()
+print("alloc-limit-ok", st["batches"], st2["batches"])
+"""
+
+
+@pytest.mark.gpu
+def test_out_of_memory_at_the_allocation_shrinks_and_retries(cbox_small, tmp_path):
+    """run_begin fits the defaults to the free memory it SEES; two contexts on one GPU (or a host allocator) can
+    still over-commit it between that check and the allocations.  HJ_ALLOC_LIMIT_MB (test rig: the process's contexts may
+    hold 3 GB together) makes the allocations themselves fail: the render call gives its slots back, halves the pool, then
+    the batch, retries, and the frame is the same bit for bit; a second context beside the first, both at once, hj_reserve;
+    an explicit batch that cannot fit fails with HJ_ERR_NOMEM and leaves the context usable.  Child process: the limit is
+    read once per process."""
+    W = H = 1024
+    with device.Renderer(0) as r:
+        r.upload_scene(cbox_small)
+        r.create_framebuffer(W, H)
+        r.render_frame(64, 3)
+        np.save(tmp_path / "want.npy", r.read())
+    script = tmp_path / "alloc_limit.py"
+    script.write_text(_ALLOC_LIMIT_SCRIPT)
+    env = dict(os.environ, HJ_ALLOC_LIMIT_MB="3072", GPU_MAX_HW_QUEUES="8")
+    p = subprocess.run([sys.executable, str(script), str(tmp_path / "want.npy")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "alloc-limit-ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
 @pytest.mark.gpu
