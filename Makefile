@@ -12,8 +12,13 @@ FP_STRICT = -ffp-contract=off -fno-fast-math
 HOST_SRC = hijiki_amd/csrc/host/scene.cpp hijiki_amd/csrc/host/synth.cpp hijiki_amd/csrc/host/blockgen.cpp \
            hijiki_amd/csrc/host/obj_loader.cpp hijiki_amd/csrc/host/image_io.cpp hijiki_amd/csrc/host/host_api.cpp
 HOST_HDR = hijiki_amd/csrc/host/scene.hpp hijiki_amd/csrc/host/blockgen.hpp include/hijiki_hip.h include/hijiki_host.h
-HIP_SRC = hijiki_amd/csrc/hj_api.hip hijiki_amd/csrc/host/blockgen.cpp
-HIP_HDR = $(wildcard hijiki_amd/csrc/kernels/*.h) $(wildcard hijiki_amd/csrc/*.h) include/hijiki_hip.h hijiki_amd/csrc/host/blockgen.hpp
+# libhijiki_hip.so: five translation units (hijiki_amd/csrc/api/hj_internal.h lists them); only render.hip and
+# lbvh_build.hip hold device code.  The register / scratch / LDS report of the path kernels: hijiki_amd/lib/resource_usage.txt.
+HIP_UNITS = context scene_upload render comm lbvh_build
+HIP_OBJ = $(HIP_UNITS:%=build/obj/%.o) build/obj/blockgen.o
+HIP_HDR = $(wildcard hijiki_amd/csrc/kernels/*.h) hijiki_amd/csrc/api/hj_internal.h include/hijiki_hip.h hijiki_amd/csrc/host/blockgen.hpp
+HIP_FLAGS = --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC $(FP_STRICT) -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden \
+            -Wall -Wno-unused-function $(HIP_EXTRA)
 
 all: host hip oracle cli
 host: hijiki_amd/lib/libhijiki_host.so
@@ -26,11 +31,22 @@ hijiki_amd/lib/libhijiki_host.so: $(HOST_SRC) $(HOST_HDR)
 	$(CXX) -std=c++17 -O2 -g0 -fPIC -shared -Wall -Wextra $(FP_STRICT) -fvisibility=hidden \
 	  -DHJ_BUILDING -pthread -o $@ $(HOST_SRC)
 
-hijiki_amd/lib/libhijiki_hip.so: $(HIP_SRC) $(HIP_HDR)
+build/obj/render.o: hijiki_amd/csrc/api/render.hip $(HIP_HDR)
+	@mkdir -p build/obj hijiki_amd/lib
+	$(HIPCC) $(HIP_FLAGS) -c $< -o $@ -Rpass-analysis=kernel-resource-usage 2> hijiki_amd/lib/resource_usage.txt \
+	  || (cat hijiki_amd/lib/resource_usage.txt; false)
+
+build/obj/%.o: hijiki_amd/csrc/api/%.hip $(HIP_HDR)
+	@mkdir -p build/obj
+	$(HIPCC) $(HIP_FLAGS) -c $< -o $@
+
+build/obj/blockgen.o: hijiki_amd/csrc/host/blockgen.cpp hijiki_amd/csrc/host/blockgen.hpp include/hijiki_hip.h
+	@mkdir -p build/obj
+	$(CXX) -std=c++17 -O2 -fPIC $(FP_STRICT) -fvisibility=hidden -c $< -o $@
+
+hijiki_amd/lib/libhijiki_hip.so: $(HIP_OBJ)
 	@mkdir -p hijiki_amd/lib
-	$(HIPCC) --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -shared $(FP_STRICT) -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden \
-	  -Wall -Wno-unused-function hijiki_amd/csrc/hj_api.hip hijiki_amd/csrc/host/blockgen.cpp -ldl -o $@ \
-	  -Rpass-analysis=kernel-resource-usage 2> hijiki_amd/lib/resource_usage.txt || (cat hijiki_amd/lib/resource_usage.txt; false)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJ) -ldl -o $@
 	@strings $@ | grep -q 'amdgcn-amd-amdhsa--$(ARCH)' || (echo 'ERROR: no $(ARCH) code object in $@'; rm -f $@; false)
 
 oracle/_build/libhj_oracle.so: oracle/hj_oracle.c include/hijiki_hip.h
@@ -45,6 +61,6 @@ hijiki_amd/bin/hijiki-hip: $(CLI_SRC) $(HOST_HDR) hijiki_amd/lib/libhijiki_hip.s
 	  -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,$(ROCM)/lib -L$(ROCM)/lib -lamdhip64
 
 clean:
-	rm -rf hijiki_amd/lib hijiki_amd/bin oracle/_build
+	rm -rf hijiki_amd/lib hijiki_amd/bin oracle/_build build/obj
 
 .PHONY: all host hip oracle cli clean

@@ -1,0 +1,329 @@
+// hj_scene_upload: validation of the reference's scene arrays (src/main.rs:561-605) and their re-layout for the kernels
+// (kernels/hj_device.h: collapsed tree, pair nodes, hot-first node order, pre-gathered triangle and emitter records).
+#include "hj_internal.h"
+
+#pragma clang fp contract(off)
+
+using namespace hjapi;
+
+namespace {
+
+// Same invariants the reference asserts while packing (src/main.rs:562-565)
+// plus every index range a kernel dereferences, and the monotonic-exit
+// property that makes the skip-link walk terminate on any input.
+int validate_scene(hj_context* ctx, const hj_scene_desc* s) {
+  const size_t shapes = s->num_spheres + s->num_quads + s->num_triangles;
+  if (s->num_materials != shapes)
+    return set_error(ctx, HJ_ERR_INVALID, "materials (%zu) != spheres+quads+triangles (%zu) (assert src/main.rs:562-565)",
+                     s->num_materials, shapes);
+  if (shapes >= 0x7FFFFFFFu || s->num_bvh_nodes >= 0x7FFFFFFFu) return set_error(ctx, HJ_ERR_INVALID, "scene too large");
+  auto need = [&](const void* p, size_t n) { return n == 0 || p != nullptr; };
+  if (!need(s->bvh, s->num_bvh_nodes) || !need(s->spheres, s->num_spheres) || !need(s->quads, s->num_quads) ||
+      !need(s->triangles, s->num_triangles) || !need(s->vertices, s->num_vertices) ||
+      !need(s->materials, s->num_materials) || !need(s->emitters, s->num_emitters) ||
+      !need(s->diffuse, s->num_diffuse) || !need(s->diffusecb, s->num_diffusecb) ||
+      !need(s->dielectric, s->num_dielectric) || !need(s->emissive, s->num_emissive))
+    return set_error(ctx, HJ_ERR_INVALID, "null array with non-zero count");
+  for (size_t i = 0; i < s->num_bvh_nodes; i++) {
+    const hj_bvh_node& n = s->bvh[i];
+    if (n.exit_index <= i) return set_error(ctx, HJ_ERR_INVALID, "bvh node %zu: exit index %u does not move forward", i, n.exit_index);
+    if (n.shape_index != HJ_BVH_INNER && n.shape_index >= shapes)
+      return set_error(ctx, HJ_ERR_INVALID, "bvh node %zu: shape index %u out of range", i, n.shape_index);
+  }
+  for (size_t i = 0; i < s->num_triangles; i++)
+    for (int k = 0; k < 3; k++)
+      if (s->triangles[i].v[k] >= s->num_vertices)
+        return set_error(ctx, HJ_ERR_INVALID, "triangle %zu refers to vertex %u of %zu", i, s->triangles[i].v[k], s->num_vertices);
+  for (size_t i = 0; i < s->num_materials; i++) {
+    const uint32_t tag = s->materials[i] >> HJ_MATERIAL_TAG_SHIFT, idx = s->materials[i] & HJ_MATERIAL_INDEX_MASK;
+    size_t lim = 0;
+    switch (tag) {
+      case HJ_MAT_DIFFUSE: lim = s->num_diffuse; break;
+      case HJ_MAT_DIFFUSECBOARD: lim = s->num_diffusecb; break;
+      case HJ_MAT_MIRROR: lim = 1; break;
+      case HJ_MAT_DIELECTRIC: lim = s->num_dielectric; break;
+      case HJ_MAT_EMISSIVE: lim = s->num_emissive; break;
+      default: return set_error(ctx, HJ_ERR_INVALID, "shape %zu: unknown material tag %u", i, tag);
+    }
+    if (idx >= lim) return set_error(ctx, HJ_ERR_INVALID, "shape %zu: material index %u out of range for tag %u", i, idx, tag);
+  }
+  for (size_t i = 0; i < s->num_emitters; i++) {
+    const uint32_t sh = s->emitters[i].shape;
+    if (sh >= shapes) return set_error(ctx, HJ_ERR_INVALID, "emitter %zu: shape %u out of range", i, sh);
+    if ((s->materials[sh] >> HJ_MATERIAL_TAG_SHIFT) != HJ_MAT_EMISSIVE)
+      return set_error(ctx, HJ_ERR_INVALID, "emitter %zu: shape %u is not emissive", i, sh);
+  }
+  return HJ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
+  if (!ctx) return HJ_ERR_INVALID;
+  HJ_NOT_BUSY(ctx);
+  if (!s) return set_error(ctx, HJ_ERR_INVALID, "null scene");
+  int rc = validate_scene(ctx, s);
+  if (rc != HJ_OK) return rc;
+  HJ_HIP(ctx, hipSetDevice(ctx->device));
+  rc = sync_all(ctx);
+  if (rc != HJ_OK) return rc;
+  release_scene(ctx);
+
+  hj::DeviceScene d{};
+  d.camera = s->camera;
+  d.tan_half_fov = (float)std::tan((double)(0.5f * s->camera.fov) * (3.14159265358979323846 / 180.0));
+  d.ns = (uint32_t)s->num_spheres;
+  d.nq = (uint32_t)s->num_quads;
+  d.nt = (uint32_t)s->num_triangles;
+  d.num_emitters = (uint32_t)s->num_emitters;
+  d.num_nodes = (uint32_t)s->num_bvh_nodes;
+  d.has_extinction = 0;
+  for (size_t i = 0; i < s->num_dielectric; i++)
+    if (s->dielectric[i].extinction[0] != 0.f || s->dielectric[i].extinction[1] != 0.f || s->dielectric[i].extinction[2] != 0.f)
+      d.has_extinction = 1;
+
+  // pre-gathered triangle records (see kernels/hj_device.h)
+  std::vector<float4> isect, shade;
+  try {
+    isect.resize(3 * s->num_triangles);
+    shade.resize(4 * s->num_triangles);
+  } catch (const std::bad_alloc&) {
+    return set_error(ctx, HJ_ERR_NOMEM, "out of host memory");
+  }
+  for (size_t i = 0; i < s->num_triangles; i++) {
+    const hj_vertex& A = s->vertices[s->triangles[i].v[0]];
+    const hj_vertex& B = s->vertices[s->triangles[i].v[1]];
+    const hj_vertex& C = s->vertices[s->triangles[i].v[2]];
+    isect[3 * i + 0] = make_float4(A.pos[0], A.pos[1], A.pos[2], 0.f);
+    isect[3 * i + 1] = make_float4(B.pos[0] - A.pos[0], B.pos[1] - A.pos[1], B.pos[2] - A.pos[2], 0.f);
+    isect[3 * i + 2] = make_float4(C.pos[0] - A.pos[0], C.pos[1] - A.pos[1], C.pos[2] - A.pos[2], 0.f);
+    shade[4 * i + 0] = make_float4(A.normal[0], A.normal[1], A.normal[2], A.u);
+    shade[4 * i + 1] = make_float4(B.normal[0], B.normal[1], B.normal[2], B.u);
+    shade[4 * i + 2] = make_float4(C.normal[0], C.normal[1], C.normal[2], C.u);
+    shade[4 * i + 3] = make_float4(A.v, B.v, C.v, 0.f);
+  }
+  static_assert(sizeof(hj_bvh_node) == 2 * sizeof(float4), "node = 2 x float4");
+  static_assert(sizeof(hj_quad) == 3 * sizeof(float4) && sizeof(hj_sphere) == sizeof(float4), "shape records");
+  static_assert(sizeof(hj_diffuse_cb) == 2 * sizeof(float4), "checkerboard record");
+#define HJ_UP(expr) do { rc = (expr); if (rc != HJ_OK) { release_scene(ctx); return rc; } } while (0)
+  // device node array (kernels/hj_device.h): redundant inner nodes dropped, hottest (largest surface area) nodes
+  // first, explicit left/exit links.
+  {
+    const size_t N = s->num_bvh_nodes;
+    std::vector<float> sa(N);
+    for (size_t i = 0; i < N; i++) {
+      const float dx = s->bvh[i].aabb_max[0] - s->bvh[i].aabb_min[0], dy = s->bvh[i].aabb_max[1] - s->bvh[i].aabb_min[1],
+                  dz = s->bvh[i].aabb_max[2] - s->bvh[i].aabb_min[2];
+      sa[i] = (dx >= 0 && dy >= 0 && dz >= 0) ? dx * dy + dy * dz + dz * dx : 0.f;
+    }
+    // Collapse: an inner node P whose two children are inner nodes can be removed from the walk without changing
+    // which leaves are tested, in which order, with which tMax: a child box lies inside P's box and every term of
+    // the slab test is monotone in the bounds, so "child passes => P passes" and "P fails => both children fail";
+    // the children keep their own box tests and exits.  (Not for leaf children: a leaf's box is never tested, so
+    // P's test is the only guard in front of its shape test.)  It pays when P usually passes: with pass
+    // probability p ~ area(P) / area(nearest kept ancestor), testing P costs 1 + 2p box tests against 2 without.
+    std::vector<char> del(N, 0);
+    {
+      const float thr = (float)env_int("HJ_COLLAPSE_PCT", 50, 0, 1000) / 100.0f;
+      auto inner = [&](size_t i) { return s->bvh[i].shape_index == HJ_BVH_INNER; };
+      auto inside = [&](size_t c, size_t p) {   // false for NaN bounds
+        bool ok = true;
+        for (int k = 0; k < 3; k++)
+          ok = ok && s->bvh[c].aabb_min[k] >= s->bvh[p].aabb_min[k] && s->bvh[c].aabb_max[k] <= s->bvh[p].aabb_max[k];
+        return ok;
+      };
+      std::vector<float> anc(N, 0.f);   // area of the nearest kept ancestor
+      for (size_t i = 0; i < N; i++) {  // pre-order: ancestors come first
+        if (!inner(i) || i + 1 >= N) continue;
+        const size_t l = i + 1, r = s->bvh[l].exit_index;
+        if (r >= N || r <= l) continue;                       // not a well-formed pre-order pair: leave it alone
+        // (an uploaded tree whose child boxes stick out of P's box keeps P: the argument above needs containment)
+        if (i != 0 && inner(l) && inner(r) && anc[i] > 0.f && sa[i] > thr * anc[i] && inside(l, i) && inside(r, i)) del[i] = 1;
+        anc[l] = anc[r] = del[i] ? anc[i] : sa[i];
+      }
+    }
+    // Pair nodes (kernels/hj_kernels.h leaf_test): an inner node whose two children are triangle leaves keeps its
+    // record, the two leaves lose theirs (nothing but the pair's own walk ever reaches them: the left one is the
+    // node's first child, the right one the left one's exit) and their triangles go side by side into `pairs`.
+    std::vector<uint32_t> pair_of(N, 0xFFFFFFFFu);
+    std::vector<float4> pairs;
+    // A fifth fewer dependent fetch rounds per ray.  Before the walk's merged first step (hj_kernels.h) the longer leaf phase
+    // - two tests while the rest of the wave waits - cost more than the rounds saved on cache-resident scenes (-3 % on the
+    // 6 k-triangle box against +12 % at 1 M triangles); with the shape fetch riding along with the other lanes' node fetch
+    // they pay everywhere: 6 k triangles +3 %, with the spheres +5 %, 60 k +7 %, 200 k +8 %.  HJ_PAIR_LEAVES = 0 / 1 forces;
+    // default: trees of >= HJ_PAIR_MIN_NODES records (0: all).
+    const int pair_env = env_int("HJ_PAIR_LEAVES", -1, -1, 1);
+    if (pair_env == 1 || (pair_env < 0 && N >= (size_t)env_int("HJ_PAIR_MIN_NODES", 0, 0, 1 << 30))) {
+      const size_t first_tri = s->num_spheres + s->num_quads;
+      for (size_t i = 0; i + 2 < N; i++) {
+        if (s->bvh[i].shape_index != HJ_BVH_INNER) continue;
+        const size_t l = i + 1, r = s->bvh[l].exit_index;
+        if (r >= N || r != l + 1) continue;
+        const uint32_t sl = s->bvh[l].shape_index, sr = s->bvh[r].shape_index;
+        if (sl == HJ_BVH_INNER || sr == HJ_BVH_INNER || sl < first_tri || sr < first_tri) continue;
+        if (s->bvh[r].exit_index != s->bvh[i].exit_index) continue;      // (a well-formed tree: the right child's exit is its parent's)
+        pair_of[i] = (uint32_t)(pairs.size() / 6);
+        for (uint32_t sh : {sl, sr}) {
+          const size_t t = sh - first_tri;
+          float4 a = isect[3 * t];
+          a.w = __builtin_bit_cast(float, sh);
+          pairs.push_back(a); pairs.push_back(isect[3 * t + 1]); pairs.push_back(isect[3 * t + 2]);
+        }
+        del[l] = del[r] = 1;                                              // no records for the two leaves
+      }
+    }
+    auto resolve = [&](size_t i) { while (i < N && del[i]) i++; return i; };   // first kept node of a subtree
+    std::vector<uint32_t> order, map(N, 0);
+    for (size_t i = 0; i < N; i++) if (!del[i]) order.push_back((uint32_t)i);
+    const size_t M = order.size();
+    const uint32_t hot = (uint32_t)std::min<size_t>(hj::kHotNodes, M);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return sa[a] > sa[b]; });
+    std::vector<char> is_hot(N, 0);
+    for (size_t k = 0; k < hot; k++) { map[order[k]] = (uint32_t)k; is_hot[order[k]] = 1; }
+    // (a treelet-blocked order - a node and its largest descendants per 128-byte line - was measured on the 1 M-triangle
+    // scene before: within 1 % at 4, 8 and 16 records per treelet)
+    uint32_t next = hot;
+    const int node_order = env_int("HJ_NODE_ORDER", -1, -1, 1);                      // -1: by tree size (with the pair nodes)
+    if (node_order == 0 || (node_order < 0 && pairs.empty())) {
+      for (size_t i = 0; i < N; i++) if (!del[i] && !is_hot[i]) map[i] = next++;   // small trees (cache-resident): pre-order
+    } else {
+      // Large trees: the children of a node side by side, a group of two or more starting on a 64-byte sector - the walk
+      // always goes from a child to its sibling (the child's exit), so the sibling's record comes with the child's; the
+      // group of the larger child (the likelier visit) follows directly.  Unused slots (padding) are never referenced.
+      // 1 M triangles: +2.4 %, 200 k: +1 %; cbox (forced): -0.6 %.
+      std::vector<uint32_t> stack, kids;
+      if (N && !is_hot[0]) map[0] = next++;
+      if (N) stack.push_back(0);
+      while (!stack.empty()) {
+        const uint32_t i = stack.back();
+        stack.pop_back();
+        const hj_bvh_node& nd = s->bvh[i];
+        if (nd.shape_index != HJ_BVH_INNER || pair_of[i] != 0xFFFFFFFFu) continue;
+        const size_t end = nd.exit_index < N ? resolve(nd.exit_index) : N;
+        kids.clear();
+        for (size_t c = resolve((size_t)i + 1); c < N && c != end;) {
+          kids.push_back((uint32_t)c);
+          const uint32_t e = s->bvh[c].exit_index;
+          c = e < N ? resolve(e) : N;
+        }
+        uint32_t cold = 0;
+        for (uint32_t c : kids) cold += is_hot[c] ? 0u : 1u;
+        if (cold >= 2 && (next & 1u)) next++;
+        for (uint32_t c : kids) if (!is_hot[c]) map[c] = next++;
+        std::stable_sort(kids.begin(), kids.end(), [&](uint32_t x, uint32_t y) { return sa[x] > sa[y]; });
+        for (size_t k = kids.size(); k-- > 0;) stack.push_back(kids[k]);
+      }
+    }
+    const size_t M_all = next;                                                       // records incl. padding
+    std::vector<float4> dev(2 * M_all, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (size_t i = 0; i < N; i++) {
+      if (del[i]) continue;
+      const hj_bvh_node& nd = s->bvh[i];
+      uint32_t a;
+      if (nd.shape_index != HJ_BVH_INNER) a = nd.shape_index;
+      else if (pair_of[i] != 0xFFFFFFFFu) a = hj::kInnerFlag | hj::kPairFlag | pair_of[i];
+      else {
+        const size_t l = resolve(i + 1);                                             // left child = next pre-order record
+        a = hj::kInnerFlag | (l < N ? map[l] : (uint32_t)M_all);
+      }
+      const size_t e = nd.exit_index < N ? resolve(nd.exit_index) : N;
+      const uint32_t b = e < N ? map[e] : (uint32_t)M_all;                           // >= the record count ends the walk
+      float4* rec = &dev[2 * (size_t)map[i]];
+      rec[0] = make_float4(nd.aabb_min[0], nd.aabb_min[1], nd.aabb_min[2], __builtin_bit_cast(float, a));
+      rec[1] = make_float4(nd.aabb_max[0], nd.aabb_max[1], nd.aabb_max[2], __builtin_bit_cast(float, b));
+    }
+    HJ_UP(upload(ctx, pairs.data(), pairs.size(), &d.tri_pair));
+    d.has_pairs = pairs.empty() ? 0u : 1u;
+    // Large trees (their nodes and triangles do not fit the caches): the path-state streams bypass the caches so that they
+    // do not evict scene data (1 M triangles +4.4 %; cache-resident scenes lose 0.5 ... 3 % with it).  HJ_STREAM_STATE = 0 / 1 forces.
+    {
+      const int nt_env = env_int("HJ_STREAM_STATE", -1, -1, 1);
+      d.stream_state = (nt_env == 1 || (nt_env < 0 && N >= (size_t)env_int("HJ_STREAM_MIN_NODES", 300000, 0, 1 << 30))) ? 1u : 0u;
+    }
+    d.num_nodes = (uint32_t)M_all;
+    d.root = N ? map[0] : 0u;
+    d.num_hot = hot;
+    // steps per round of the walk loop (the first one is the merged step that also runs the leaf tests) and free lanes at
+    // which a wave fetches new rays: without pair nodes 4 / 32 (6: -0.4 %, 8: -4 % on cbox); with them 7 / 24 on small trees
+    // (the rays of the rotated, child-ordered trees are shorter: 5 / 32, the optimum before those passes, is 3 % slower on
+    // cbox now; 6 or 8 steps, 20 or 28 lanes: -1 ... -2 %), 8 / 24 up to 600 000 records and 8 / 32 beyond (1 M triangles:
+    // 6 .. 10 steps the same, 24 lanes -1 %)
+    const bool small_tree = M < 50000;
+    d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", pairs.empty() ? 4 : (small_tree ? 7 : 8), 1, 1 << 20);   // >= 1, or the walk would never advance
+    d.refill_min = (uint32_t)env_int("HJ_REFILL_MIN", !pairs.empty() && M < 600000 ? 24 : (int)hj::kRefillMin, 1, 64);   // (20 k / 60 k / 200 k triangles: 24 lanes +2 / +3 / +1 %)
+    // The walk adds 32 * index to the low word of the array's address without a carry (kernels/hj_kernels.h): the
+    // array must not cross a 4 GiB boundary.  Allocate twice the size and start at the boundary if it would.
+    {
+      const size_t bytes = std::max<size_t>(dev.size() * sizeof(float4), 16) + 128;   // (slack: a whole 128-byte line may be read around the last record)
+      if (bytes >= (1ull << 32)) { release_scene(ctx); return set_error(ctx, HJ_ERR_UNSUPPORTED, "BVH of %zu records: the device node array is limited to 4 GiB", M); }
+      ctx->scene_bufs.emplace_back();
+      DevBuf& b = ctx->scene_bufs.back();
+      HJ_UP(dev_alloc(ctx, b, bytes));
+      uintptr_t start = reinterpret_cast<uintptr_t>(b.p);
+      if ((start >> 32) != ((start + bytes - 1) >> 32)) {
+        b.release();
+        HJ_UP(dev_alloc(ctx, b, 2 * bytes));
+        start = reinterpret_cast<uintptr_t>(b.p);
+        if ((start >> 32) != ((start + bytes - 1) >> 32)) start = ((start >> 32) + 1) << 32;
+      }
+      if (hipMemcpy(reinterpret_cast<void*>(start), dev.data(), dev.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess) {
+        release_scene(ctx);
+        return set_error(ctx, HJ_ERR_DEVICE, "node upload failed");
+      }
+      d.nodes = reinterpret_cast<const float4*>(start);
+    }
+  }
+  HJ_UP(upload(ctx, isect.data(), isect.size(), &d.tri_isect));
+  HJ_UP(upload(ctx, shade.data(), shade.size(), &d.tri_shade));
+  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->spheres), s->num_spheres, &d.spheres));
+  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->quads), 3 * s->num_quads, &d.quads));
+  HJ_UP(upload(ctx, s->triangles, s->num_triangles, &d.triangles));
+  HJ_UP(upload(ctx, s->vertices, s->num_vertices, &d.vertices));
+  HJ_UP(upload(ctx, s->materials, s->num_materials, &d.materials));
+  HJ_UP(upload(ctx, s->emitters, s->num_emitters, &d.emitters));
+  {
+    std::vector<float4> rec((size_t)hj::kEmitRecF4 * s->num_emitters, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (size_t i = 0; i < s->num_emitters; i++) {
+      float4* r = &rec[(size_t)hj::kEmitRecF4 * i];
+      const uint32_t shape = s->emitters[i].shape;
+      const hj_emissive& em = s->emissive[s->materials[shape] & HJ_MATERIAL_INDEX_MASK];
+      uint32_t kind;
+      if (shape < s->num_spheres) {
+        kind = 0;
+        const hj_sphere& sp = s->spheres[shape];
+        r[1] = make_float4(sp.center[0], sp.center[1], sp.center[2], 0.f);
+        r[0].z = sp.radius;
+      } else if (shape < s->num_spheres + s->num_quads) {
+        kind = 1;
+        const hj_quad& q = s->quads[shape - s->num_spheres];
+        r[1] = make_float4(q.origin[0], q.origin[1], q.origin[2], 0.f);
+        r[2] = make_float4(q.edge1[0], q.edge1[1], q.edge1[2], 0.f);
+        r[3] = make_float4(q.edge2[0], q.edge2[1], q.edge2[2], 0.f);
+      } else {
+        kind = 2;
+        const hj_triangle& t = s->triangles[shape - s->num_spheres - s->num_quads];
+        for (int k = 0; k < 3; k++) {
+          const hj_vertex& v = s->vertices[t.v[k]];
+          r[1 + k] = make_float4(v.pos[0], v.pos[1], v.pos[2], 0.f);
+          r[4 + k] = make_float4(v.normal[0], v.normal[1], v.normal[2], 0.f);
+        }
+      }
+      r[0].x = s->emitters[i].pdf;
+      r[0].y = __builtin_bit_cast(float, kind);
+      r[1].w = em.power[0]; r[2].w = em.power[1]; r[3].w = em.power[2];
+    }
+    HJ_UP(upload(ctx, rec.data(), rec.size(), &d.emit_rec));
+  }
+  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->diffuse), s->num_diffuse, &d.diffuse));
+  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->diffusecb), 2 * s->num_diffusecb, &d.diffusecb));
+  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->dielectric), s->num_dielectric, &d.dielectric));
+  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->emissive), s->num_emissive, &d.emissive));
+#undef HJ_UP
+  ctx->scene = d;
+  ctx->have_scene = true;
+  return HJ_OK;
+}
+
+}  // extern "C"

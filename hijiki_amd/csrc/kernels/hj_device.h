@@ -18,6 +18,8 @@ constexpr uint32_t kEmitRecF4 = 7;
                            // box scenes, 640: -1 %; the 1 M-triangle scene does not care)
 #endif
 constexpr uint32_t kHotNodes = HJ_HOT_NODES;
+constexpr uint32_t kRefillMin = 32;   // free lanes at which a wave of the persistent walk fetches new rays (hj_scene_upload: 24 on trees with
+                                      // pair nodes; sweep on the first fused kernel: 16 -> 1.39, 32..48 -> 1.43 Gpaths/s, 64 -> 1.24)
 constexpr uint32_t kInnerFlag = 0x80000000u;
 constexpr uint32_t kPairFlag = 0x40000000u;    // with kInnerFlag: an inner node whose two children are triangle leaves
 constexpr uint32_t kIndexMask = 0x3FFFFFFFu;

@@ -271,7 +271,6 @@ HJ_DEV bool traverse(const DeviceScene& sc, Ray r, RawHit& h) {
 //   finish(done, slot, h, any)   wave-convergent: called when some lanes are done; `done` lanes have a final result
 // A round of the loop: service phase (only when enough lanes are free) -> merged first step (leaf lanes fetch their shape
 // record, the others their node, in one trip) -> up to inner_burst - 1 plain box steps for the lanes not standing on a leaf.
-constexpr uint32_t kRefillMin = 32;   // sweep on the fused kernel: 16 -> 1.39, 32..48 -> 1.43 Gpaths/s, 64 -> 1.24
 
 #ifdef HJ_WALK_STATS
 // Diagnostic build only (tools/build_variant.sh stats -DHJ_WALK_STATS): wave-level occupancy of the walk's phases.
@@ -1445,7 +1444,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
 }
 
 // ---- split-kernel path (HJ_RENDER_SPLIT_KERNELS): the same stage functions, one launch per stage per bounce, for
-// per-stage timing and counters.  No regeneration: the pool holds every sample of the workgroup (hj_api.hip sizes
+// per-stage timing and counters.  No regeneration: the pool holds every sample of the workgroup (api/render.hip sizes
 // it so) and k_gen_camera starts them all.
 
 __global__ __launch_bounds__(kBlockThreads) void k_gen_camera(BatchState st, DeviceScene sc) {

@@ -9,7 +9,7 @@
 // in the construction of BVHs, octrees and k-d trees"), bounds by a bottom-up pass.  LARGE shapes (box area above
 // HJ_LBVH_BIG_PCT = 2 % of the area of the SCENE's box, e.g. the walls of the box around a mesh) are kept OUT of the Morton tree: sorted by centroid they
 // would sit deep inside it and blow the boxes of all their ancestors up to scene size; they go into a small SAH tree
-// that the host builds over them and over the CLUSTERS of the Morton tree (its subtrees of at most 64 leaves; hj_api.hip),
+// that the host builds over them and over the CLUSTERS of the Morton tree (its subtrees of at most 64 leaves; api/lbvh_build.hip),
 // so that only the lowest levels keep the Morton splits.  The image does not depend on the
 // topology except through epsilon-ties.
 //

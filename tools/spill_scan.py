@@ -4,7 +4,7 @@ register-allocated on its own), and the ones inside their hot loops.  A scratch 
 node loop of the packet stage - is a memory round trip per iteration; cold-stage edits move them around (the allocator is
 global per function), so run this after touching any stage.
 
-    python tools/spill_scan.py [extra hipcc flags]       # compiles hijiki_amd/csrc/hj_api.hip to gfx950 assembly in $TMPDIR
+    python tools/spill_scan.py [extra hipcc flags]       # compiles hijiki_amd/csrc/api/render.hip (the unit with the path kernels) to gfx950 assembly in $TMPDIR
 
 Per function: total scratch instructions; scratch instructions in loops of depth >= HOT (kernel: 2 = trace_persistent's
 for(;;), its box-step loop is depth 3; packet stage: 2 = the node loop inside the chunk loop); for the kernel also the older,
@@ -29,7 +29,7 @@ def compile_asm(extra=()):
     asm = os.path.join(tempfile.gettempdir(), "hj_spill_scan.s")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math",
            "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-function", "--cuda-device-only", "-S", *extra, "-o", asm,
-           os.path.join(root, "hijiki_amd/csrc/hj_api.hip")]
+           os.path.join(root, "hijiki_amd/csrc/api/render.hip")]
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     return open(asm).read().split("\n")
 
