@@ -34,8 +34,9 @@ if [ -f build/variants/var_stats.so ]; then
     c4) HJ_STATS_SPP=256 HJ_STATS_SIZE=2048 HJ_STATS_TRIS=1000000 timeout 300 python3 tools/walk_stats.py 2 --json $out/walk_stats.json > $out/walk_stats.txt 2>&1 ;;
   esac
 fi
-# the inputs first, in place (profiles/ of this copy of the tree), so that the un-profiled bench line below quotes THESE counters
+# the inputs first, in place (profiles/ of this copy of the tree) and TOGETHER with the CSVs they come from, so that the un-profiled
+# bench line below quotes THESE counters and tests/test_roofline_inputs.py still regenerates the newest inputs file from its passes
 python3 tools/roofline_inputs.py build $out $cfg > $out/roofline_inputs.json
-cp $out/roofline_inputs.json profiles/${tag}_${cfg}_roofline_inputs.json
+bash tools/collect_profiles.sh $tag $cfg > /dev/null
 timeout 600 python3 bench.py --config $cfg --steps 5 > $out/bench.json 2> $out/bench.err || echo "bench failed"
 head -6 $out/kernel_stats.csv; cat $out/pmc_pass*.csv | grep -i "k_path\|^kernel" ; cat $out/roofline_inputs.json; tail -1 $out/bench.json | cut -c1-400
