@@ -144,7 +144,7 @@ int hj_context_create(int device, hj_context** out) {
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail(e, "hipGetDeviceProperties");
   ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
-  // Tuning knobs (environment overrides exist only for sweeps; the defaults are the measured optima).
+  // Tuning knobs (environment overrides exist only for sweeps; the defaults are the measured optima: DESIGN.md 4, profiles/NOTES.md).
   ctx->num_wg = (uint32_t)ctx->num_cus * (uint32_t)env_int("HJ_WG_PER_CU", 8, 1, 32);   // 8 x 4 waves = the 32-wave CU limit
   // Small render calls (a rank's share of a frame on many GPUs) run 6 workgroups per CU: all of a kernel's workgroups are then
   // resident at once (7 x 4 waves fit a CU at 72 registers; with 8 per CU the last eighth of a batch's workgroups start when the

@@ -11,7 +11,7 @@ Result (P_STOP, Q_LEAF from profiles/r03_c2_walk_stats.txt: 13.1 box steps, 0.89
 per ray fall by 14 % with one exchange per round and by at most 19 - 22 % with an exchange after every step - rays that stay with
 their lane cannot fill a wave; together with the measured cost of a wave-step (half of it does not depend on the active lanes:
 profiles/r04_lane_limit_probe.txt) and of an LDS state round trip (profiles/r04_lds_roundtrip_probe.txt) nothing is left.
-DESIGN.md section 6, "Re-grouping rays through LDS".
+DESIGN.md section 6, "Re-grouping rays between waves through LDS"; profiles/NOTES.md.
 """
 import numpy as np
 rng = np.random.default_rng(1)
