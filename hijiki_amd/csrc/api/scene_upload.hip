@@ -171,13 +171,13 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
       }
     }
     mark("areas + collapse");
-    // Pair nodes (kernels/hj_kernels.h leaf_test): an inner node whose two children are triangle leaves keeps its
+    // Pair nodes (kernels/hj_intersect.h leaf_test): an inner node whose two children are triangle leaves keeps its
     // record, the two leaves lose theirs (nothing but the pair's own walk ever reaches them: the left one is the
     // node's first child, the right one the left one's exit) and their triangles go side by side into `pairs`.
     std::vector<uint32_t> pair_of(N, 0xFFFFFFFFu);
     std::vector<float4> pairs;
     pairs.reserve(N / 4 * 6 + 6);              // (a pair per three records at most; typically 0.43 per two leaves)
-    // A fifth fewer dependent fetch rounds per ray.  Before the walk's merged first step (hj_kernels.h) the longer leaf phase
+    // A fifth fewer dependent fetch rounds per ray.  Before the walk's merged first step (hj_walk.h) the longer leaf phase
     // - two tests while the rest of the wave waits - cost more than the rounds saved on cache-resident scenes (-3 % on the
     // 6 k-triangle box against +12 % at 1 M triangles); with the shape fetch riding along with the other lanes' node fetch
     // they pay everywhere: 6 k triangles +3 %, with the spheres +5 %, 60 k +7 %, 200 k +8 %.  HJ_PAIR_LEAVES = 0 / 1 forces;
@@ -289,7 +289,7 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     const bool small_tree = M < 50000;
     d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", pairs.empty() ? 4 : (small_tree ? 7 : 8), 1, 1 << 20);   // >= 1, or the walk would never advance
     d.refill_min = (uint32_t)env_int("HJ_REFILL_MIN", !pairs.empty() && M < 600000 ? 24 : (int)hj::kRefillMin, 1, 64);   // (20 k / 60 k / 200 k triangles: 24 lanes +2 / +3 / +1 %)
-    // The walk adds 32 * index to the low word of the array's address without a carry (kernels/hj_kernels.h): the
+    // The walk adds 32 * index to the low word of the array's address without a carry (kernels/hj_walk.h): the
     // array must not cross a 4 GiB boundary.  Allocate twice the size and start at the boundary if it would.
     {
       const size_t bytes = std::max<size_t>(dev.size() * sizeof(float4), 16) + 128;   // (slack: a whole 128-byte line may be read around the last record)

@@ -31,7 +31,7 @@ constexpr uint32_t kIndexMask = 0x3FFFFFFFu;
 // record" no longer holds, links are explicit:
 //   n0 = (aabb_min.xyz, A)   A = shape index for a leaf, 0x80000000 | left-child index for an inner node,
 //                            0xC0000000 | pair index for an inner node over two triangle leaves (those two leaves
-//                            have no records of their own: hj_kernels.h leaf_test)
+//                            have no records of their own: hj_intersect.h leaf_test)
 //   n1 = (aabb_max.xyz, B)   B = exit index (>= num_nodes ends the walk)
 // The walk starts at `root`.  Triangles are additionally pre-gathered per
 // triangle so that a leaf test is ONE dependent fetch instead of the
@@ -110,7 +110,7 @@ struct BatchState {
   uint32_t capacity;             // samples allocated
   uint32_t num_wg;               // grid size of every stage kernel
   uint32_t pool;                 // positions per workgroup, multiple of 64
-  uint32_t xcd_deal;             // sample groups dealt per XCD (hj_kernels.h: wg_group)
+  uint32_t xcd_deal;             // sample groups dealt per XCD (hj_stages.h: wg_group)
 };
 
 }  // namespace hj
