@@ -118,11 +118,14 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
   const dim3 grid_m((m + 255u) / 256u), grid_sub(((uint32_t)sub_total + 255u) / 256u);
   hipLaunchKernelGGL(hj::lbvh::k_hierarchy, grid_m, blk, 0, st, t, m);
   // ---- clusters of the Morton tree (HJ_LBVH_CLUSTER leaves at most; 0 = the whole tree is one cluster)
-  const uint32_t cmax_env = (uint32_t)env_int("HJ_LBVH_CLUSTER", 64, 0, 1 << 20);
+  // (clusters of up to 64 leaves are re-split by one thread each, k_emit_clusters_sah - rounds 2-3's default -, larger ones
+  // up to 512 by one wave each, k_emit_clusters_sah_wave)
+  const uint32_t cmax_env = (uint32_t)env_int("HJ_LBVH_CLUSTER", 512, 0, 1 << 20);
   const uint32_t cmax = cmax_env == 0 ? m : cmax_env;
   // inside the clusters: SAH re-split (one thread per cluster, which needs no boxes of the Morton tree's internal nodes) or the
   // Morton topology as it is (HJ_LBVH_SAH=0, or clusters larger than the kernel's arrays: bottom-up refit first)
-  const bool sah_clusters = cmax <= hj::lbvh::kClusterMax && env_int("HJ_LBVH_SAH", 1, 0, 1) != 0;
+  const bool sah_clusters = cmax <= hj::lbvh::kWaveClusterMax && env_int("HJ_LBVH_SAH", 1, 0, 1) != 0;
+  const bool sah_wave = sah_clusters && cmax > hj::lbvh::kClusterMax;
   if (!sah_clusters) hipLaunchKernelGGL(hj::lbvh::k_refit, grid_m, blk, 0, st, t, m, idx_mask);
   hj::lbvh::Clusters cl{};
   {
@@ -142,6 +145,23 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
   HJ_HIP(ctx, hipMemcpyAsync(&K, cl.count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HJ_HIP(ctx, hipStreamSynchronize(st));
   mark("hierarchy, refit, clusters");
+  // the wave-per-cluster re-split starts NOW, into a staging array, and runs while the host builds the top of the tree over
+  // the clusters' boxes; k_place_clusters moves the records to their places once those are known
+  // (on a stream of its own - a batch slot's, idle outside render calls -, so that the small copies the host needs for the top
+  // do not queue behind it)
+  hj_bvh_node* d_staged = nullptr;
+  struct Events { hipEvent_t a = nullptr, b = nullptr; ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } ev;
+  hipStream_t side = ctx->slots[0].stream;
+  if (sah_wave) {
+    HJ_DEVBUF(d_staged, hj_bvh_node, 2 * (size_t)m);
+    HJ_HIP(ctx, hipEventCreateWithFlags(&ev.a, hipEventDisableTiming));
+    HJ_HIP(ctx, hipEventCreateWithFlags(&ev.b, hipEventDisableTiming));
+    HJ_HIP(ctx, hipEventRecord(ev.a, st));
+    HJ_HIP(ctx, hipStreamWaitEvent(side, ev.a, 0));
+    hipLaunchKernelGGL(hj::lbvh::k_emit_clusters_sah_wave, dim3(K), dim3(64), 0, side, t, K, cl, idx_mask, d_staged,
+                       env_int("HJ_BVH_CHILD_ORDER", 3, 0, 9));
+    HJ_HIP(ctx, hipEventRecord(ev.b, side));
+  }
   // ---- the top of the tree on the host: binned SAH over the K clusters and the nbig large shapes
   struct Item { float lo[3], hi[3]; uint32_t shape; uint32_t cluster; uint32_t records; float weight; uint32_t first; };
   std::vector<Item> items(K + nbig);
@@ -441,7 +461,11 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
   mark("host SAH over the clusters");
   HJ_HIP(ctx, hipMemcpyAsync(const_cast<uint32_t*>(cl.base), cbase.data(), sizeof(uint32_t) * K, hipMemcpyHostToDevice, st));
   HJ_HIP(ctx, hipMemcpyAsync(const_cast<uint32_t*>(cl.exit), cexit.data(), sizeof(uint32_t) * K, hipMemcpyHostToDevice, st));
-  if (sah_clusters)
+  if (sah_wave) {
+    HJ_HIP(ctx, hipStreamWaitEvent(st, ev.b, 0));
+    hipLaunchKernelGGL(hj::lbvh::k_place_clusters, dim3(K), dim3(64), 0, st, K, cl, d_staged, d_out);
+  }
+  else if (sah_clusters)
     hipLaunchKernelGGL(hj::lbvh::k_emit_clusters_sah, dim3((K + hj::lbvh::kSahThreads - 1) / hj::lbvh::kSahThreads),
                        dim3(hj::lbvh::kSahThreads), 0, st, t, K, cl, idx_mask, d_out, env_int("HJ_BVH_CHILD_ORDER", 3, 0, 9));
   else

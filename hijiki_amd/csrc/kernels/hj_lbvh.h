@@ -450,6 +450,198 @@ __global__ __launch_bounds__(kSahThreads) void k_emit_clusters_sah(Tree t, uint3
   }
 }
 
+// The same re-split with ONE WAVE per cluster (round 4): the leaf boxes of a cluster of up to kWaveClusterMax leaves sit in
+// LDS, the 64 lanes stride over a range's leaves for its bounds and its 3 x 8 bins (LDS atomics on order-preserving ints:
+// independent of the order of arrival), lanes 0..20 price the 21 split candidates, a ballot partition (stable) re-orders the
+// range's ids.  Same bins, same cost, same tie-break (lowest axis, lowest bin) and same child order as k_emit_clusters_sah;
+// larger clusters mean fewer Morton borders inside the tree and fewer items for the host's SAH top (1 M triangles: ~3 k
+// clusters of up to 512 leaves instead of 25 k of up to 64).
+constexpr uint32_t kWaveClusterMax = 512;
+constexpr uint32_t kOpenExit = 0xFFFFFFFFu;
+struct SahRange { uint32_t lo, hi, pos, exit; };
+__global__ __launch_bounds__(64) void k_emit_clusters_sah_wave(Tree t, uint32_t K, Clusters c, unsigned long long idx_mask,
+                                                               hj_bvh_node* out, int child_order) {
+  __shared__ float s_box[6][kWaveClusterMax];
+  __shared__ uint16_t s_ids[kWaveClusterMax], s_tmp[kWaveClusterMax];
+  __shared__ int s_bin[3][8][7];                                     // per axis and bin: ordered(min xyz), ordered(max xyz), count
+  __shared__ SahRange s_stack[kWaveClusterMax];
+  const uint32_t k = blockIdx.x, lane = threadIdx.x;
+  if (k >= K) return;
+  const uint32_t first = __float_as_uint(c.lo[k].w), cnt = __float_as_uint(c.hi[k].w);
+  for (uint32_t i = lane; i < cnt; i += 64u) {
+    const uint32_t id = (uint32_t)(t.keys[first + i] & idx_mask);
+    const float4 a = t.leaf_lo[id], b = t.leaf_hi[id];
+    s_box[0][i] = a.x; s_box[1][i] = a.y; s_box[2][i] = a.z;
+    s_box[3][i] = b.x; s_box[4][i] = b.y; s_box[5][i] = b.z;
+    s_ids[i] = (uint16_t)i;
+  }
+  // `out` is a STAGING array: the cluster's records go to [2 * first, 2 * first + 2 * cnt - 1) with the exits of its right
+  // spine left open (kOpenExit) - the cluster's place in the tree is not known yet, the host builds the top of the tree while
+  // this kernel runs; k_place_clusters moves the records to their place afterwards.
+  if (lane == 0) s_stack[0] = SahRange{0u, cnt, 2u * first, kOpenExit};
+  __syncthreads();                                                   // (one wave: a fence for the LDS writes above)
+  uint32_t sp = 1;
+  auto wave_min = [](float v) { for (int o = 32; o > 0; o >>= 1) v = f_min(v, __shfl_xor(v, o)); return v; };
+  auto wave_max = [](float v) { for (int o = 32; o > 0; o >>= 1) v = f_max(v, __shfl_xor(v, o)); return v; };
+  auto shape_of = [&](uint32_t pos) { return (uint32_t)(t.keys[first + s_ids[pos]] & idx_mask); };
+  auto leaf_record = [&](uint32_t pos, uint32_t at, uint32_t exit) {     // (one lane)
+    const uint32_t li = s_ids[pos];
+    hj_bvh_node nd;
+    nd.aabb_min[0] = s_box[0][li]; nd.aabb_min[1] = s_box[1][li]; nd.aabb_min[2] = s_box[2][li];
+    nd.aabb_max[0] = s_box[3][li]; nd.aabb_max[1] = s_box[4][li]; nd.aabb_max[2] = s_box[5][li];
+    nd.shape_index = shape_of(pos); nd.exit_index = exit;
+    out[at] = nd;
+  };
+  while (sp != 0) {
+    sp--;
+    const SahRange r = s_stack[sp];                                  // (every lane reads the same entry: a broadcast)
+    const uint32_t m = r.hi - r.lo;
+    if (m == 1) {
+      if (lane == 0) leaf_record(r.lo, r.pos, r.exit);
+      continue;
+    }
+    // bounds of the range and of its centroids (sums lo + hi, as in the one-thread kernel)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = r.lo + lane; i < r.hi; i += 64u) {
+      const uint32_t li = s_ids[i];
+      for (int ax = 0; ax < 3; ax++) {
+        const float al = s_box[ax][li], bh = s_box[3 + ax][li], cc = al + bh;
+        lo[ax] = f_min(lo[ax], al); hi[ax] = f_max(hi[ax], bh);
+        clo[ax] = f_min(clo[ax], cc); chi[ax] = f_max(chi[ax], cc);
+      }
+    }
+    for (int ax = 0; ax < 3; ax++) { lo[ax] = wave_min(lo[ax]); hi[ax] = wave_max(hi[ax]); clo[ax] = wave_min(clo[ax]); chi[ax] = wave_max(chi[ax]); }
+    if (lane == 0) {
+      hj_bvh_node nd;
+      nd.aabb_min[0] = lo[0]; nd.aabb_min[1] = lo[1]; nd.aabb_min[2] = lo[2];
+      nd.aabb_max[0] = hi[0]; nd.aabb_max[1] = hi[1]; nd.aabb_max[2] = hi[2];
+      nd.shape_index = HJ_BVH_INNER; nd.exit_index = r.exit;
+      out[r.pos] = nd;
+    }
+    if (m == 2) {                                                    // two leaves: nothing to choose (equal counts keep their order)
+      if (lane == 0) { leaf_record(r.lo, r.pos + 1, r.pos + 2); leaf_record(r.lo + 1, r.pos + 2, r.exit); }
+      continue;
+    }
+    // bins
+    constexpr int B = 8;
+    for (uint32_t e = lane; e < 3u * B * 7u; e += 64u) {
+      const uint32_t f = e % 7u;
+      (&s_bin[0][0][0])[e] = f < 3u ? 0x7FFFFFFF : f < 6u ? (int)0x80000000 : 0;
+    }
+    __syncthreads();
+    float ext[3];
+    for (int ax = 0; ax < 3; ax++) ext[ax] = chi[ax] - clo[ax];
+    auto bin_of = [&](uint32_t li, int ax) {
+      int q = (int)(((s_box[ax][li] + s_box[3 + ax][li]) - clo[ax]) / ext[ax] * (float)B);
+      return q < 0 ? 0 : q >= B ? B - 1 : q;
+    };
+    for (uint32_t i = r.lo + lane; i < r.hi; i += 64u) {
+      const uint32_t li = s_ids[i];
+      for (int ax = 0; ax < 3; ax++) {
+        if (!(ext[ax] > 0.f)) continue;
+        const int q = bin_of(li, ax);
+        for (int d = 0; d < 3; d++) {
+          atomicMin(&s_bin[ax][q][d], ordered(s_box[d][li]));
+          atomicMax(&s_bin[ax][q][3 + d], ordered(s_box[3 + d][li]));
+        }
+        atomicAdd(&s_bin[ax][q][6], 1);
+      }
+    }
+    __syncthreads();
+    // the 21 candidates: lane j = 7 * axis + bin prices "bins 0..bin to the left": cost = area(L) * |L| + area(R) * |R|
+    float cost = INFINITY;
+    if (lane < 21u) {
+      const int ax = (int)lane / 7, q = (int)lane % 7;
+      if (ext[ax] > 0.f) {
+        float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t ln = 0, rn = 0;
+        for (int b = 0; b < B; b++) {
+          const uint32_t nb = (uint32_t)s_bin[ax][b][6];
+          if (nb == 0) continue;
+          float* tlo = b <= q ? llo : rlo;
+          float* thi = b <= q ? lhi : rhi;
+          for (int d = 0; d < 3; d++) { tlo[d] = f_min(tlo[d], unordered(s_bin[ax][b][d])); thi[d] = f_max(thi[d], unordered(s_bin[ax][b][3 + d])); }
+          if (b <= q) ln += nb; else rn += nb;
+        }
+        if (ln != 0 && rn != 0) {
+          const float dx = lhi[0] - llo[0], dy = lhi[1] - llo[1], dz = lhi[2] - llo[2];
+          const float ex = rhi[0] - rlo[0], ey = rhi[1] - rlo[1], ez = rhi[2] - rlo[2];
+          cost = (dx * dy + dy * dz + dz * dx) * (float)ln + (ex * ey + ey * ez + ez * ex) * (float)rn;
+        }
+      }
+    }
+    // the cheapest candidate, the lowest lane among equals (the one-thread kernel's loop order with its strict <)
+    float bc = cost;
+    uint32_t bj = lane;
+    for (int o = 32; o > 0; o >>= 1) {
+      const float oc = __shfl_xor(bc, o);
+      const uint32_t oj = (uint32_t)__shfl_xor((int)bj, o);
+      if (oc < bc || (oc == bc && oj < bj)) { bc = oc; bj = oj; }
+    }
+    uint32_t mid = r.lo + m / 2;                                     // all centroids equal: halves in order
+    if (bc < INFINITY) {
+      const int best_axis = (int)bj / 7, best_bin = (int)bj % 7;
+      // stable partition of the ids: left part to s_tmp[r.lo ...], right part behind it
+      uint32_t nleft = 0;
+      for (uint32_t i0 = r.lo; i0 < r.hi; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        const bool left = i < r.hi && bin_of(s_ids[i], best_axis) <= best_bin;
+        nleft += (uint32_t)__popcll(__ballot(left));
+      }
+      uint32_t wl = r.lo, wr = r.lo + nleft;
+      for (uint32_t i0 = r.lo; i0 < r.hi; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        const bool in = i < r.hi;
+        const uint32_t li = in ? s_ids[i] : 0u;
+        const bool left = in && bin_of(li, best_axis) <= best_bin, right = in && !left;
+        const unsigned long long ml = __ballot(left), mr = __ballot(right), below = (1ull << lane) - 1ull;
+        if (left) s_tmp[wl + (uint32_t)__popcll(ml & below)] = (uint16_t)li;
+        if (right) s_tmp[wr + (uint32_t)__popcll(mr & below)] = (uint16_t)li;
+        wl += (uint32_t)__popcll(ml); wr += (uint32_t)__popcll(mr);
+      }
+      __syncthreads();
+      if (nleft != 0 && nleft != m) {
+        mid = r.lo + nleft;
+        for (uint32_t i = r.lo + lane; i < r.hi; i += 64u) s_ids[i] = s_tmp[i];
+        __syncthreads();
+      }
+    }
+    if (child_order != 0 && r.hi - mid < mid - r.lo) {
+      // the side with fewer leaves first (host/scene.cpp order_children): the two blocks of the id list change places
+      const uint32_t nl = mid - r.lo, nr = r.hi - mid;
+      for (uint32_t i = r.lo + lane; i < r.hi; i += 64u) s_tmp[i] = s_ids[i];
+      __syncthreads();
+      for (uint32_t i = lane; i < m; i += 64u) s_ids[r.lo + i] = i < nr ? s_tmp[mid + i] : s_tmp[r.lo + (i - nr)];
+      __syncthreads();
+      mid = r.lo + nr;
+      (void)nl;
+    }
+    const uint32_t left_pos = r.pos + 1, right_pos = left_pos + 2 * (mid - r.lo) - 1;
+    if (lane == 0) {
+      s_stack[sp] = SahRange{mid, r.hi, right_pos, r.exit};          // a right child inherits its parent's exit
+      s_stack[sp + 1] = SahRange{r.lo, mid, left_pos, right_pos};    // exit of a left child = its sibling
+    }
+    sp += 2;
+    __syncthreads();
+  }
+}
+
+// Cluster k's staged records (k_emit_clusters_sah_wave) to their place: record j of the cluster -> out[base[k] + j], exits
+// inside the cluster shifted with it, the open exits of its right spine = exit[k].  One wave per cluster.
+__global__ __launch_bounds__(64) void k_place_clusters(uint32_t K, Clusters c, const hj_bvh_node* __restrict__ staged, hj_bvh_node* __restrict__ out) {
+  const uint32_t k = blockIdx.x;
+  if (k >= K) return;
+  const uint32_t first = __float_as_uint(c.lo[k].w), cnt = __float_as_uint(c.hi[k].w);
+  const uint32_t from = 2u * first, to = c.base[k], end = c.exit[k];
+  for (uint32_t j = threadIdx.x; j < 2u * cnt - 1u; j += 64u) {
+    hj_bvh_node nd = staged[from + j];
+    nd.exit_index = nd.exit_index == kOpenExit ? end : nd.exit_index - from + to;
+    out[to + j] = nd;
+  }
+}
+
 // One record of the reference's flattened array per tree node (internal nodes: threads [0, n-1), leaves: the rest).
 // The tree occupies records [base, base + 2n - 1) of `out`; `end_exit` is the exit of its right spine.
 __global__ __launch_bounds__(256) void k_emit(Tree t, uint32_t n, uint32_t base, uint32_t end_exit, unsigned long long idx_mask,

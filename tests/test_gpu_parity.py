@@ -357,6 +357,15 @@ def test_device_built_bvh_large_and_degenerate(gpu_renderer, oracle, monkeypatch
     _check_skip_link_tree(nodes, _shape_boxes(cs))
     assert _sah_cost(nodes) < 1.15 * host_cost, (_sah_cost(nodes), host_cost)
     assert _sah_cost(nodes) < 0.98 * _sah_cost(morton), (_sah_cost(nodes), _sah_cost(morton))   # leaf areas are common to both
+    assert (gpu_renderer.build_bvh(cs) == nodes).all()                    # deterministic (LDS atomics on ordered ints, ballot partition)
+    # both re-split kernels: clusters of up to 512 leaves by one WAVE each (the default), of up to 64 by one thread each
+    monkeypatch.setenv("HJ_LBVH_CLUSTER", "64")
+    small = gpu_renderer.build_bvh(cs)
+    _check_skip_link_tree(small, _shape_boxes(cs))
+    assert _sah_cost(nodes) < 1.02 * _sah_cost(small), (_sah_cost(nodes), _sah_cost(small))     # larger SAH domains are not worse
+    monkeypatch.setenv("HJ_LBVH_CLUSTER", "300")                          # (a cluster size that is no power of two)
+    _check_skip_link_tree(gpu_renderer.build_bvh(cs), _shape_boxes(cs))
+    monkeypatch.delenv("HJ_LBVH_CLUSTER")
     cs.set_bvh(nodes)
     W = H = 128
     blocks = host.make_blocks(W, H, 1, 3)
