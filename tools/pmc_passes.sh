@@ -2,7 +2,7 @@
 # pmc_passes.sh OUTDIR "C1 C2 C3" "C4 C5" ... : one rocprofv3 --pmc pass per counter group over a 64-spp C2 frame (perf_probe, 1 rep),
 # each under its own timeout; prints per-kernel sums.  Run from the repo root on the GPU box.
 export GPU_MAX_HW_QUEUES=8   # before rocprofv3 / python start: the tool library initialises HIP first, later settings are ignored
-out=$1; shift
+out=$1; shift; mkdir -p $out
 root=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 i=0
