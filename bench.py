@@ -302,21 +302,34 @@ def run_config(name, cfg, args, steps, warmup, hj, barrier):
     opts = device.default_opts()
     opts.flags = abi.RENDER_TIME_KERNELS      # HIP events around every kernel class, on the library's own streams
     sr.reserve(spp, opts)                     # set-up: the batch slots' device memory (86 GB at the defaults) is allocated here, not in a frame
-    for _ in range(warmup):
-        sr.render_frame(spp, args.seed, opts=opts, reduce=True)
+    # Frames back to back: the batch pipeline is not drained between two frames (hj_render_frame with HJ_RENDER_NO_DRAIN,
+    # ShardedRenderer.render_frames): frame k + 1's first batches run beside the path-depth tail of frame k's last ones, and
+    # frame k's reduce beside frame k + 1's rendering.  Every one of the K frames is rendered, reduced and complete inside the
+    # timed region.  --no-pipeline: one blocking frame after the other (rounds 1-3).
+    pipelined = not getattr(args, "no_pipeline", False)
+
+    def frames(n):
+        if n <= 0:
+            return None
+        if pipelined:
+            return sr.render_frames(n, spp, args.seed, opts=opts, reduce=True)
+        agg_ = None
+        for _ in range(n):
+            st = sr.render_frame(spp, args.seed, opts=opts, reduce=True)
+            agg_ = st if agg_ is None else {k: agg_[k] + v for k, v in st.items()}
+        return agg_
+
+    frames(warmup)
     barrier()
     t0 = time.perf_counter()
-    agg = None
-    for _ in range(steps):
-        st = sr.render_frame(spp, args.seed, opts=opts, reduce=True)
-        agg = st if agg is None else {k: agg[k] + v for k, v in st.items()}
+    agg = frames(steps)
     barrier()
     elapsed = hjdist.max_over_ranks(time.perf_counter() - t0, device=sr.local)     # the slowest rank's wall time
     if getattr(args, "dump_frame", None) and name == args.config and rank == 0:
         import numpy as np
         np.save(args.dump_frame, sr.fb.cpu().numpy())          # the reduced frame of the last timed step (tests compare it)
     sr.close()
-    return dict(cs=cs, W=W, H=H, spp=spp, agg=agg, elapsed=elapsed, steps=steps,
+    return dict(cs=cs, W=W, H=H, spp=spp, agg=agg, elapsed=elapsed, steps=steps, pipelined=pipelined,
                 standard=(W, H, spp) == (cfg["size"], cfg["size"], cfg["spp"]))
 
 
@@ -333,6 +346,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="only the headline configuration (the default c2 run on one GPU also times 3 frames each of c3 and c4)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="drain the batch pipeline after every frame (one blocking hj_render_frame per step, as in rounds 1-3)")
     ap.add_argument("--dump-frame", default=None, metavar="FILE.npy",
                     help="rank 0 saves the reduced RGBA32F accumulation buffer of the last timed frame (after the timed region)")
     ap.add_argument("--inproc", action="store_true",
@@ -389,6 +404,8 @@ def main():
             # how many ranks the collective of the timed frames really spanned (torch.distributed's nccl backend = RCCL)
             "rccl_ranks": dist.get_world_size() if world > 1 and dist.is_initialized() else 1,
             "rccl_backend": dist.get_backend() if world > 1 and dist.is_initialized() else None,
+            # steps overlap at their seams (the next frame's first batches beside this frame's last): all K frames lie inside the timed region
+            "frames_back_to_back": bool(res["pipelined"]),
         }
         oracle_counters = None
         if not args.no_cpu_baseline and world == 1:        # the CPU baseline is a one-GPU-run item (rank 0, N = 1 only)

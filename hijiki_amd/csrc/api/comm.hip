@@ -142,6 +142,7 @@ int hj_comm_reduce_framebuffers(hj_comm* c, int root) {
   // every context's frame must be complete: join asynchronous renders, then drain the streams
   for (int i = 0; i < n; i++) {
     hj_context* x = c->ctxs[(size_t)i];
+    if (x->pipe_active) return set_error(r, HJ_ERR_STATE, "context %d: frames submitted with HJ_RENDER_NO_DRAIN are in flight: hj_pipeline_wait first", i);
     const int rs = hj_sync(x, nullptr);
     if (rs != HJ_OK) return set_error(r, rs, "context %d: render failed: %s", i, get_error(x).c_str());
     if (hipSetDevice(x->device) != hipSuccess || sync_all(x) != HJ_OK)

@@ -205,6 +205,8 @@ void hj_context_destroy(hj_context* ctx) {
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
   }
   if (ctx->accum && ctx->accum_owned) (void)hipFree(ctx->accum);
+  for (hipEvent_t e : ctx->frame_events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->frame_event_pool) (void)hipEventDestroy(e);
   for (auto& ep : ctx->events) {
     (void)hipEventDestroy(ep.a);
     (void)hipEventDestroy(ep.b);
@@ -216,6 +218,7 @@ void hj_context_destroy(hj_context* ctx) {
 int hj_framebuffer_create(hj_context* ctx, uint32_t width, uint32_t height, void* external) {
   if (!ctx) return HJ_ERR_INVALID;
   HJ_NOT_BUSY(ctx);
+  HJ_NOT_PIPELINED(ctx);
   if (width == 0 || height == 0 || width > 65536 || height > 65536) return set_error(ctx, HJ_ERR_INVALID, "bad framebuffer size %ux%u", width, height);
   HJ_HIP(ctx, hipSetDevice(ctx->device));
   {
@@ -243,6 +246,7 @@ int hj_framebuffer_create(hj_context* ctx, uint32_t width, uint32_t height, void
 int hj_framebuffer_clear(hj_context* ctx) {
   if (!ctx) return HJ_ERR_INVALID;
   HJ_NOT_BUSY(ctx);
+  HJ_NOT_PIPELINED(ctx);
   if (!ctx->accum) return set_error(ctx, HJ_ERR_STATE, "no framebuffer");
   HJ_HIP(ctx, hipSetDevice(ctx->device));
   HJ_HIP(ctx, hipMemsetAsync(ctx->accum, 0, (size_t)ctx->width * ctx->height * sizeof(float4), ctx->stream));
@@ -252,9 +256,22 @@ int hj_framebuffer_clear(hj_context* ctx) {
 
 void* hj_framebuffer_device_ptr(hj_context* ctx) { return ctx ? ctx->accum : nullptr; }
 
+// Frames submitted from now on accumulate into `external` (same size as the framebuffer hj_framebuffer_create made or was
+// given); no synchronisation: frames already submitted (HJ_RENDER_NO_DRAIN) keep the buffer they were submitted with.
+int hj_framebuffer_bind(hj_context* ctx, void* external) {
+  if (!ctx) return HJ_ERR_INVALID;
+  HJ_NOT_BUSY(ctx);
+  if (!ctx->accum) return set_error(ctx, HJ_ERR_STATE, "no framebuffer: hj_framebuffer_create first (it fixes the size)");
+  if (!external || (reinterpret_cast<uintptr_t>(external) & 15u) != 0) return set_error(ctx, HJ_ERR_INVALID, "external framebuffer must be non-null and 16-byte aligned");
+  if (ctx->accum_owned) return set_error(ctx, HJ_ERR_STATE, "the context owns its framebuffer: create it with an external buffer to bind others");
+  ctx->accum = static_cast<float4*>(external);
+  return HJ_OK;
+}
+
 int hj_framebuffer_read(hj_context* ctx, float* host_rgba) {
   if (!ctx) return HJ_ERR_INVALID;
   HJ_NOT_BUSY(ctx);
+  HJ_NOT_PIPELINED(ctx);
   if (!ctx->accum) return set_error(ctx, HJ_ERR_STATE, "no framebuffer");
   if (!host_rgba) return set_error(ctx, HJ_ERR_INVALID, "null destination");
   HJ_HIP(ctx, hipSetDevice(ctx->device));

@@ -125,6 +125,16 @@ struct hj_context {
   int async_rc = HJ_OK;
   hj_render_stats async_stats{};
 
+  // Frames back to back WITHOUT draining the batch pipeline between them (HJ_RENDER_NO_DRAIN, hj_pipeline_wait): one event per
+  // frame submitted (recorded behind its last batch), the statistics accumulated since the last full drain, the slot rotation
+  // carried from frame to frame.
+  std::vector<hipEvent_t> frame_events;   // oldest first: frames submitted, not yet waited for
+  std::vector<hipEvent_t> frame_event_pool;
+  bool pipe_active = false;               // something submitted with HJ_RENDER_NO_DRAIN has not been drained yet
+  hj_render_stats pipe_stats{};
+  size_t pipe_k = 0;
+  std::chrono::steady_clock::time_point pipe_wall0;
+
   // hj_last_error: the worker thread writes `error` while the caller's thread may read it
   std::mutex err_mu;
 };
@@ -149,6 +159,13 @@ void drop_cached_comms(hj_context* ctx);             // api/comm.hip: the commun
   do {                                                                                                            \
     if ((ctx)->busy.load(std::memory_order_acquire))                                                              \
       return set_error(ctx, HJ_ERR_STATE, "%s: an asynchronous frame is in flight on this context: call hj_sync first", __func__); \
+  } while (0)
+
+// ... and while frames submitted with HJ_RENDER_NO_DRAIN are still in flight (hj_pipeline_wait(ctx, 0, ...) drains them).
+#define HJ_NOT_PIPELINED(ctx)                                                                                     \
+  do {                                                                                                            \
+    if ((ctx)->pipe_active)                                                                                       \
+      return set_error(ctx, HJ_ERR_STATE, "%s: frames submitted with HJ_RENDER_NO_DRAIN are in flight: call hj_pipeline_wait(ctx, 0, ...) first", __func__); \
   } while (0)
 
 #define HJ_HIP(ctx, call)                                                                         \

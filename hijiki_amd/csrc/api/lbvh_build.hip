@@ -14,6 +14,7 @@ extern "C" {
 int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* out_nodes, size_t capacity, size_t* out_num_nodes) {
   if (!ctx) return HJ_ERR_INVALID;
   HJ_NOT_BUSY(ctx);
+  HJ_NOT_PIPELINED(ctx);
   if (!s || !out_nodes) return set_error(ctx, HJ_ERR_INVALID, "null argument");
   const size_t n = s->num_spheres + s->num_quads + s->num_triangles;
   if (n < 2) return set_error(ctx, HJ_ERR_INVALID, "scene needs at least 2 shapes (reference panics: root would be a leaf, src/main.rs:230)");

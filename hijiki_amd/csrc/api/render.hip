@@ -342,6 +342,7 @@ struct RenderRun {
   uint64_t paths = 0;
   uint32_t batch = 0;
   uint32_t shrunk = 0;     // times run_submit lowered the pool or the batch after an allocation failed
+  bool no_drain = false;   // HJ_RENDER_NO_DRAIN: a frame of a back-to-back sequence (run_end does not wait)
   std::chrono::steady_clock::time_point wall0;
 };
 
@@ -353,11 +354,24 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
   int rc = check_opts(ctx, run.o);
   if (rc != HJ_OK) return rc;
   HJ_HIP(ctx, hipSetDevice(ctx->device));
-  run.st = stats ? stats : &run.local;
-  std::memset(run.st, 0, sizeof *run.st);
-  ctx->events_used = 0;
-  run.tm = Timer{ctx, (run.o.flags & HJ_RENDER_TIME_KERNELS) != 0};
   run.split = (run.o.flags & HJ_RENDER_SPLIT_KERNELS) != 0;
+  run.no_drain = (run.o.flags & HJ_RENDER_NO_DRAIN) != 0 && !run.split;
+  if (run.no_drain) {
+    // a frame of a back-to-back sequence: statistics and timing events accumulate in the context until hj_pipeline_wait(ctx, 0)
+    run.st = &ctx->pipe_stats;
+    if (!ctx->pipe_active) {
+      std::memset(run.st, 0, sizeof *run.st);
+      ctx->events_used = 0;
+      ctx->pipe_k = 0;
+      ctx->pipe_wall0 = std::chrono::steady_clock::now();
+    }
+    run.k = ctx->pipe_k;                     // (the slot rotation goes on where the frame before stopped)
+  } else {
+    run.st = stats ? stats : &run.local;
+    std::memset(run.st, 0, sizeof *run.st);
+    ctx->events_used = 0;
+  }
+  run.tm = Timer{ctx, (run.o.flags & HJ_RENDER_TIME_KERNELS) != 0};
   // Default batch: large batches amortise the latency-bound tail of a batch (measured: cbox+mirror+glass 700 ->
   // 960 Mpaths/s from 512 to 2048 blocks, +2-3 % more at 4096), but at least four batches should exist so that the three
   // slots can overlap (tools/batch_probe.py, rank 0's share of the cbox frame at 8 / 4 / 2 / 1 ranks: a quarter of the blocks
@@ -403,8 +417,10 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
       }
     }
   }
-  rc = sync_all(ctx);
-  if (rc != HJ_OK) return rc;
+  if (!(run.no_drain && ctx->pipe_active)) {   // (a continuing sequence: the slots are in use, run_submit waits for them one by one)
+    rc = sync_all(ctx);
+    if (rc != HJ_OK) return rc;
+  }
   ctx->blocks_total = total_blocks;
   ctx->blocks_done = ctx->blocks_reported = 0;
   run.wall0 = std::chrono::steady_clock::now();
@@ -467,7 +483,57 @@ int run_submit(hj_context* ctx, RenderRun& run, const hj_image_block* blocks, si
 }
 
 // Drains the slots (also after an error, so that nothing of this run is still in flight) and closes the statistics.
+// Kernel times of the events recorded since they were last reset, into *st_out (HJ_RENDER_TIME_KERNELS).
+void collect_timing(hj_context* ctx, hj_render_stats* st_out) {
+  // exclusive time of the dominant kernel: the union of the launches' intervals (launches of different batch slots
+  // overlap, so the sum of their durations exceeds the wall clock)
+  {
+    std::vector<std::pair<float, float>> iv;
+    for (size_t i = 0; i < ctx->events_used; i++) {
+      const int kind = ctx->events[i].kind;
+      if (kind != EV_PATH && kind != EV_CLOSEST && kind != EV_SHADE && kind != EV_SHADOW) continue;
+      float a = 0.f, b = 0.f;
+      if (hipEventElapsedTime(&a, ctx->events[0].a, ctx->events[i].a) != hipSuccess) continue;
+      if (hipEventElapsedTime(&b, ctx->events[0].a, ctx->events[i].b) != hipSuccess) continue;
+      iv.emplace_back(a, b);
+    }
+    std::sort(iv.begin(), iv.end());
+    float busy = 0.f, cur_a = 0.f, cur_b = -1.f;
+    for (auto& x : iv) {
+      if (cur_b < cur_a || x.first > cur_b) { if (cur_b > cur_a) busy += cur_b - cur_a; cur_a = x.first; cur_b = x.second; }
+      else cur_b = std::max(cur_b, x.second);
+    }
+    if (cur_b > cur_a) busy += cur_b - cur_a;
+    st_out->path_busy_ms = busy;
+  }
+  for (size_t i = 0; i < ctx->events_used; i++) {
+    float e = 0.f;
+    if (hipEventElapsedTime(&e, ctx->events[i].a, ctx->events[i].b) != hipSuccess) continue;
+    switch (ctx->events[i].kind) {
+      case EV_CLOSEST: st_out->trace_closest_ms += e; st_out->closest_launches++; break;
+      case EV_SHADOW: st_out->trace_shadow_ms += e; break;
+      case EV_SHADE: st_out->shade_ms += e; break;
+      case EV_RECON: st_out->reconstruct_ms += e; break;
+      case EV_PATH: st_out->path_ms += e; st_out->path_launches++; break;
+    }
+  }
+}
+
 int run_end(hj_context* ctx, RenderRun& run, int rc) {
+  if (run.no_drain && rc == HJ_OK) {
+    // a frame of a back-to-back sequence: nothing is waited for; one event behind the frame's last batch (its slot's stream
+    // waits for its reconstruction, and the reconstructions are chained in order: everything of the frame precedes it)
+    hipEvent_t ev = nullptr;
+    if (!ctx->frame_event_pool.empty()) { ev = ctx->frame_event_pool.back(); ctx->frame_event_pool.pop_back(); }
+    else HJ_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipStream_t last = run.k != ctx->pipe_k ? ctx->slots[(run.k - 1) % ctx->slots_eff].stream : ctx->stream;   // (no batch: nothing to wait for)
+    if (hipEventRecord(ev, last) != hipSuccess) { ctx->frame_event_pool.push_back(ev); return set_error(ctx, HJ_ERR_DEVICE, "hipEventRecord failed"); }
+    ctx->frame_events.push_back(ev);
+    ctx->pipe_active = true;
+    ctx->pipe_k = run.k;
+    run.st->paths += run.paths;
+    return HJ_OK;
+  }
   const std::string first_error = get_error(ctx);
   for (auto& sl : ctx->slots) {
     const int rc2 = harvest(ctx, sl, run.st);
@@ -487,39 +553,13 @@ int run_end(hj_context* ctx, RenderRun& run, int rc) {
   if (rc == HJ_OK) {
     hj_render_stats* st_out = run.st;
     st_out->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - run.wall0).count();
-    st_out->paths = run.paths;
-    // exclusive time of the dominant kernel: the union of the launches' intervals (launches of different batch slots
-    // overlap, so the sum of their durations exceeds the wall clock)
-    {
-      std::vector<std::pair<float, float>> iv;
-      for (size_t i = 0; i < ctx->events_used; i++) {
-        const int kind = ctx->events[i].kind;
-        if (kind != EV_PATH && kind != EV_CLOSEST && kind != EV_SHADE && kind != EV_SHADOW) continue;
-        float a = 0.f, b = 0.f;
-        if (hipEventElapsedTime(&a, ctx->events[0].a, ctx->events[i].a) != hipSuccess) continue;
-        if (hipEventElapsedTime(&b, ctx->events[0].a, ctx->events[i].b) != hipSuccess) continue;
-        iv.emplace_back(a, b);
-      }
-      std::sort(iv.begin(), iv.end());
-      float busy = 0.f, cur_a = 0.f, cur_b = -1.f;
-      for (auto& x : iv) {
-        if (cur_b < cur_a || x.first > cur_b) { if (cur_b > cur_a) busy += cur_b - cur_a; cur_a = x.first; cur_b = x.second; }
-        else cur_b = std::max(cur_b, x.second);
-      }
-      if (cur_b > cur_a) busy += cur_b - cur_a;
-      st_out->path_busy_ms = busy;
-    }
-    for (size_t i = 0; i < ctx->events_used; i++) {
-      float e = 0.f;
-      if (hipEventElapsedTime(&e, ctx->events[i].a, ctx->events[i].b) != hipSuccess) continue;
-      switch (ctx->events[i].kind) {
-        case EV_CLOSEST: st_out->trace_closest_ms += e; st_out->closest_launches++; break;
-        case EV_SHADOW: st_out->trace_shadow_ms += e; break;
-        case EV_SHADE: st_out->shade_ms += e; break;
-        case EV_RECON: st_out->reconstruct_ms += e; break;
-        case EV_PATH: st_out->path_ms += e; st_out->path_launches++; break;
-      }
-    }
+    st_out->paths = run.no_drain ? st_out->paths + run.paths : run.paths;
+    collect_timing(ctx, st_out);
+  }
+  if (run.no_drain) {                          // (an error inside a sequence: everything has been drained above)
+    for (hipEvent_t e : ctx->frame_events) ctx->frame_event_pool.push_back(e);
+    ctx->frame_events.clear();
+    ctx->pipe_active = false;
   }
   return rc;
 }
@@ -528,6 +568,7 @@ int run_end(hj_context* ctx, RenderRun& run, int rc) {
 int hj_reserve(hj_context* ctx, size_t total_blocks, const hj_render_opts* opts) {
   if (!ctx) return HJ_ERR_INVALID;
   HJ_NOT_BUSY(ctx);
+  HJ_NOT_PIPELINED(ctx);
   if (total_blocks == 0) return HJ_OK;
   RenderRun run;
   int rc = run_begin(ctx, run, opts, nullptr, total_blocks);        // (the call's batch size, pool and workgroup count)
@@ -551,6 +592,7 @@ int hj_render_blocks(hj_context* ctx, const hj_image_block* blocks, size_t n, co
                      hj_render_stats* stats) {
   if (!ctx) return HJ_ERR_INVALID;
   HJ_NOT_BUSY(ctx);
+  HJ_NOT_PIPELINED(ctx);
   if (n && !blocks) return set_error(ctx, HJ_ERR_INVALID, "null block list");
   RenderRun run;
   int rc = run_begin(ctx, run, opts, stats, n);
@@ -567,7 +609,47 @@ int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed, uint32_
                     uint32_t rank, uint32_t world, const hj_render_opts* opts, hj_render_stats* stats) {
   if (!ctx) return HJ_ERR_INVALID;
   HJ_NOT_BUSY(ctx);
+  if (!(opts && (opts->flags & HJ_RENDER_NO_DRAIN) && !(opts->flags & HJ_RENDER_SPLIT_KERNELS))) HJ_NOT_PIPELINED(ctx);
   return render_frame_impl(ctx, spp, master_seed, pass_begin, pass_end, rank, world, opts, stats);
+}
+
+// Waits until at most `keep` of the frames submitted with HJ_RENDER_NO_DRAIN are in flight; keep = 0: drains the pipeline
+// and closes the sequence's statistics (include/hijiki_hip.h).
+int hj_pipeline_wait(hj_context* ctx, uint32_t keep, hj_render_stats* totals) {
+  if (!ctx) return HJ_ERR_INVALID;
+  HJ_NOT_BUSY(ctx);
+  HJ_HIP(ctx, hipSetDevice(ctx->device));
+  while (ctx->frame_events.size() > keep) {
+    hipEvent_t ev = ctx->frame_events.front();
+    HJ_HIP(ctx, hipEventSynchronize(ev));
+    ctx->frame_events.erase(ctx->frame_events.begin());
+    ctx->frame_event_pool.push_back(ev);
+  }
+  if (keep != 0) return HJ_OK;
+  if (!ctx->pipe_active) {                    // nothing in flight: the totals of the last sequence again
+    if (totals) *totals = ctx->pipe_stats;
+    return HJ_OK;
+  }
+  int rc = HJ_OK;
+  for (auto& sl : ctx->slots) {
+    const int rc2 = harvest(ctx, sl, &ctx->pipe_stats);
+    if (rc == HJ_OK) rc = rc2;
+  }
+  {
+    const int rc2 = sync_all(ctx);
+    if (rc == HJ_OK) rc = rc2;
+  }
+  ctx->pipe_active = false;
+  if (rc == HJ_OK) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) rc = set_error(ctx, HJ_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
+  }
+  if (rc == HJ_OK) {
+    ctx->pipe_stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->pipe_wall0).count();
+    collect_timing(ctx, &ctx->pipe_stats);
+    if (totals) *totals = ctx->pipe_stats;
+  }
+  return rc;
 }
 namespace {
 int render_frame_impl(hj_context* ctx, uint32_t spp, uint64_t master_seed, uint32_t pass_begin, uint32_t pass_end,
@@ -634,6 +716,7 @@ int hj_render_frame_async(hj_context* ctx, uint32_t spp, uint64_t master_seed, u
                           uint32_t rank, uint32_t world, const hj_render_opts* opts) {
   if (!ctx) return HJ_ERR_INVALID;
   HJ_NOT_BUSY(ctx);
+  HJ_NOT_PIPELINED(ctx);
   hj_context::AsyncJob j{};
   j.spp = spp; j.master_seed = master_seed; j.pass_begin = pass_begin; j.pass_end = pass_end; j.rank = rank; j.world = world;
   if (opts) j.opts = *opts;
@@ -672,6 +755,7 @@ int hj_sync(hj_context* ctx, hj_render_stats* stats) {
 int hj_debug_trace(hj_context* ctx, const float* rays, size_t n, uint32_t use_bvh, uint32_t any_hit, float* hits) {
   if (!ctx) return HJ_ERR_INVALID;
   HJ_NOT_BUSY(ctx);
+  HJ_NOT_PIPELINED(ctx);
   if (!ctx->have_scene) return set_error(ctx, HJ_ERR_STATE, "trace before hj_scene_upload");
   if (n == 0) return HJ_OK;
   if (!rays || !hits) return set_error(ctx, HJ_ERR_INVALID, "null argument");
@@ -705,6 +789,7 @@ int hj_debug_trace(hj_context* ctx, const float* rays, size_t n, uint32_t use_bv
 int hj_debug_samples(hj_context* ctx, const hj_image_block* block, const hj_render_opts* opts, float* samples) {
   if (!ctx) return HJ_ERR_INVALID;
   HJ_NOT_BUSY(ctx);
+  HJ_NOT_PIPELINED(ctx);
   if (!ctx->have_scene) return set_error(ctx, HJ_ERR_STATE, "render before hj_scene_upload");
   if (!block || !samples) return set_error(ctx, HJ_ERR_INVALID, "null argument");
   if (block->dimension[0] == 0 || block->dimension[1] == 0 || block->dimension[0] > HJ_BLOCK_SIZE || block->dimension[1] > HJ_BLOCK_SIZE)

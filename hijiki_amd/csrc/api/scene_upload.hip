@@ -63,6 +63,7 @@ extern "C" {
 int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
   if (!ctx) return HJ_ERR_INVALID;
   HJ_NOT_BUSY(ctx);
+  HJ_NOT_PIPELINED(ctx);
   if (!s) return set_error(ctx, HJ_ERR_INVALID, "null scene");
   // HJ_UPLOAD_TIMING=1: wall time of the stages below on stderr
   const bool timing = env_int("HJ_UPLOAD_TIMING", 0, 0, 1) != 0;

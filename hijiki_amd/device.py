@@ -21,7 +21,8 @@ EXPORTS = ("hj_context_create", "hj_context_destroy", "hj_last_error", "hj_versi
            "hj_framebuffer_read", "hj_framebuffer_resolve", "hj_render_blocks", "hj_render_frame", "hj_block_seed",
            "hj_pass_offset", "hj_block_owner", "hj_debug_trace", "hj_debug_samples", "hj_reduce_framebuffers",
            "hj_build_bvh_device", "hj_render_frame_async", "hj_sync", "hj_set_progress_callback", "hj_device_count",
-           "hj_comm_create", "hj_comm_destroy", "hj_comm_reduce_framebuffers", "hj_reserve")
+           "hj_comm_create", "hj_comm_destroy", "hj_comm_reduce_framebuffers", "hj_reserve", "hj_framebuffer_bind",
+           "hj_pipeline_wait")
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
 
@@ -54,6 +55,8 @@ def lib():
         L.hj_render_frame.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.POINTER(abi.RenderOpts), C.POINTER(abi.RenderStats)]
         L.hj_reserve.argtypes = [vp, C.c_size_t, C.POINTER(abi.RenderOpts)]
+        L.hj_framebuffer_bind.argtypes = [vp, vp]
+        L.hj_pipeline_wait.argtypes = [vp, C.c_uint32, C.POINTER(abi.RenderStats)]
         L.hj_reduce_framebuffers.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
         L.hj_render_frame_async.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                             C.POINTER(abi.RenderOpts)]
@@ -183,6 +186,26 @@ class Renderer:
         self._check(lib().hj_render_frame(self._h, spp, master_seed, pass_begin, pass_end, rank, world,
                                           C.byref(opts) if opts is not None else None, C.byref(st)))
         return stats_dict(st)
+
+    def submit_frame(self, spp, master_seed, pass_begin=0, pass_end=None, rank=0, world=1, opts=None):
+        """hj_render_frame with HJ_RENDER_NO_DRAIN: returns when the frame's batches are enqueued; `pipeline_wait` joins.
+        The frame accumulates into the framebuffer bound at the time of the call (`bind_framebuffer`)."""
+        o = abi.RenderOpts()
+        C.memmove(C.byref(o), C.byref(opts if opts is not None else default_opts()), C.sizeof(abi.RenderOpts))
+        o.flags |= abi.RENDER_NO_DRAIN
+        pass_end = spp if pass_end is None else pass_end
+        self._check(lib().hj_render_frame(self._h, spp, master_seed, pass_begin, pass_end, rank, world, C.byref(o), None))
+
+    def bind_framebuffer(self, device_ptr):
+        """hj_framebuffer_bind: frames submitted from now on accumulate into this caller-owned buffer (no synchronisation)."""
+        self._check(lib().hj_framebuffer_bind(self._h, device_ptr))
+
+    def pipeline_wait(self, keep=0):
+        """hj_pipeline_wait: until at most `keep` submitted frames are in flight; keep = 0 drains and returns the statistics of
+        all frames since the last drain."""
+        st = abi.RenderStats()
+        self._check(lib().hj_pipeline_wait(self._h, keep, C.byref(st) if keep == 0 else None))
+        return stats_dict(st) if keep == 0 else None
 
     def reserve(self, total_blocks, opts=None):
         """hj_reserve: allocate now what a render call of `total_blocks` ImageBlocks will use (set-up, not rendering)."""

@@ -156,6 +156,7 @@ typedef struct hj_render_opts {
 #define HJ_RENDER_TIME_KERNELS 1u   /* bracket every kernel with HIP events on its launch stream (fills *_ms) */
 #define HJ_RENDER_SPLIT_KERNELS 2u  /* diagnostic: one launch per stage per bounce instead of the fused kernel */
 #define HJ_RENDER_STATIC_DEAL 4u    /* hj_render_frame, world > 1: keep all passes of a block on one rank          */
+#define HJ_RENDER_NO_DRAIN 8u       /* hj_render_frame: return when the frame's batches are ENQUEUED (hj_pipeline_wait) */
 
 /* Per-render statistics (device counters; all in units of events). */
 typedef struct hj_render_stats {
@@ -285,6 +286,26 @@ int hj_render_frame_async(hj_context* ctx, uint32_t spp, uint64_t master_seed,
                           uint32_t pass_begin, uint32_t pass_end, uint32_t rank, uint32_t world,
                           const hj_render_opts* opts);
 int hj_sync(hj_context* ctx, hj_render_stats* stats /* may be NULL */);
+
+/* Frames BACK TO BACK without draining the batch pipeline between them.  (Upstream the queue never drains either: render()
+ * submits one command buffer per block and never waits, src/main.rs:1341-1347; a blocking hj_render_frame ends with the
+ * path-depth tail of its last batches running alone - 3 ms of a 160 ms frame on one GPU, of a 20 ms share on eight.)
+ *   hj_render_frame(..., opts->flags | HJ_RENDER_NO_DRAIN, stats = NULL)
+ *       returns when the frame's batches are enqueued; it blocks only while all batch slots are still busy with EARLIER
+ *       batches (the natural back-pressure).  The frame accumulates into the framebuffer that is bound at the time of the
+ *       call; it must have been zeroed (or hold what the frame is to be added to) before the call.
+ *   hj_framebuffer_bind(ctx, device_ptr)
+ *       frames submitted from now on accumulate into this caller-owned W x H RGBA32F buffer (16-byte aligned; same size as the
+ *       one hj_framebuffer_create was given) - no synchronisation, frames already submitted keep their buffer: two buffers in
+ *       turn let frame k + 1 render while frame k is reduced / read.
+ *   hj_pipeline_wait(ctx, keep, totals)
+ *       waits until at most `keep` of the submitted frames are still in flight (oldest first).  keep = 0 drains everything
+ *       and returns in *totals (may be NULL) the statistics of ALL frames since the last drain (times: kernels of all of
+ *       them); with keep > 0 *totals is left alone.
+ * While frames are in flight the other entry points that touch the context's device state return HJ_ERR_STATE (as with an
+ * asynchronous frame), except hj_framebuffer_bind and hj_framebuffer_device_ptr.  Results are the blocking call's, bit for bit. */
+int hj_framebuffer_bind(hj_context* ctx, void* external_device_ptr);
+int hj_pipeline_wait(hj_context* ctx, uint32_t keep, hj_render_stats* totals /* may be NULL */);
 
 /* Replaces the window-title percentage the reference updates every `present_interval` blocks (src/main.rs:1335-1340):
  * `fn(user, blocks_done, blocks_total)` is called from the thread that drives the render whenever at least

@@ -1066,6 +1066,51 @@ def test_async_frame_state_and_statistics(cbox_small):
 
 
 @pytest.mark.gpu
+def test_frames_back_to_back_without_draining(cbox_small):
+    """hj_render_frame with HJ_RENDER_NO_DRAIN + hj_framebuffer_bind + hj_pipeline_wait: five frames (different seeds, two
+    external framebuffers in turn) submitted back to back - the batch pipeline is never drained between them - are the
+    blocking frames bit for bit, the statistics of the sequence are the sums, the entry points that need an idle context
+    answer HJ_ERR_STATE while frames are in flight, and a blocking frame works again after the drain."""
+    import torch
+    W, H, spp = 384, 256, 12
+    seeds = [3, 4, 5, 6, 7]
+    with device.Renderer(0) as r:
+        r.upload_scene(cbox_small)
+        bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0") for _ in range(2)]
+        r.create_framebuffer(W, H, external_device_ptr=bufs[0].data_ptr())
+        want, want_st = [], []
+        for s_ in seeds:
+            bufs[0].zero_(); torch.cuda.synchronize()
+            want_st.append(r.render_frame(spp, s_))
+            want.append(bufs[0].cpu().numpy().copy())
+        L = device.lib()
+        got = []
+        torch.cuda.synchronize()
+        for k, s_ in enumerate(seeds):
+            fb = bufs[k % 2]
+            fb.zero_(); torch.cuda.synchronize()
+            r.bind_framebuffer(fb.data_ptr())
+            r.submit_frame(spp, s_)
+            assert L.hj_framebuffer_clear(r._h) == abi.HJ_ERR_STATE and b"NO_DRAIN" in L.hj_last_error(r._h)
+            with pytest.raises(abi.HijikiError):
+                r.render_frame(spp, s_)                          # a blocking frame in the middle of a sequence: refused
+            if k >= 1:
+                assert r.pipeline_wait(keep=1) is None
+                got.append(bufs[(k - 1) % 2].cpu().numpy().copy())
+        st = r.pipeline_wait(keep=0)
+        got.append(bufs[(len(seeds) - 1) % 2].cpu().numpy().copy())
+        for k in range(len(seeds)):
+            assert (bits(got[k]) == bits(want[k])).all(), f"frame {k}"
+        for key in ("paths", "closest_rays", "shadow_rays", "hits", "unoccluded_shadow_rays", "batches"):
+            assert st[key] == sum(w[key] for w in want_st), key
+        assert r.pipeline_wait(keep=0)["paths"] == st["paths"]       # (nothing in flight: the last totals again)
+        r.bind_framebuffer(bufs[0].data_ptr())
+        bufs[0].zero_(); torch.cuda.synchronize()
+        r.render_frame(spp, seeds[0])
+        assert (bits(bufs[0].cpu().numpy()) == bits(want[0])).all()
+
+
+@pytest.mark.gpu
 def test_defaults_shrink_to_the_free_device_memory(cbox_small, monkeypatch):
     """A frame whose default pool and batches would take 21 GB of path state and samples, on a device that (HJ_MEM_LIMIT_MB: a test
     rig) has 3 GB free: the render call lowers the pool, then the batch, instead of failing with HJ_ERR_NOMEM, and the frame is the
