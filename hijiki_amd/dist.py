@@ -27,6 +27,29 @@ def owned_blocks(width, height, rank, world, pass_index=0):
     return [j for j in range(per) if L.hj_block_owner(width, height, pass_index, j, world) == rank]
 
 
+def _init_group(backend, rank, world, local):
+    """dist.init_process_group for this package's use + the first collective (set-up, not rendering)."""
+    import torch
+    import torch.distributed as dist
+    done = False
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        # the collective's kernels on a high-priority stream: they run beside the NEXT frame's persistent workgroups
+        # (render_frames) and should get the next free wave slots, as the reconstructions do
+        try:
+            pg = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, pg_options=pg)
+            done = True
+        except (AttributeError, TypeError):
+            done = False
+    if not done:
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    # RCCL builds its communicator (rings over xGMI) at the FIRST collective: do that here, as set-up, so that the first
+    # frame's reduce - inside a timed region when a caller asks for no warm-up - is an ordinary one
+    t = torch.zeros(1, device=f"cuda:{local}") if backend == "nccl" else torch.zeros(1)
+    dist.all_reduce(t)
+
+
 def init_process_group(backend=None):
     """Idempotent init from the torchrun environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
     import torch
@@ -37,19 +60,15 @@ def init_process_group(backend=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:   # HIJIKI_DIST_BACKEND=gloo lets several ranks share one GPU (test rigs); RCCL needs one GPU per rank
             backend = os.environ.get("HIJIKI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
-            torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
-        # RCCL builds its communicator (rings over xGMI) at the FIRST collective: do that here, as set-up, so that the first
-        # frame's reduce - inside a timed region when a caller asks for no warm-up - is an ordinary one
-        t = torch.zeros(1, device=f"cuda:{local}") if backend == "nccl" else torch.zeros(1)
-        dist.all_reduce(t)
+        _init_group(backend, rank, world, local)
     return rank, world, local
 
 
 def _active():
+    """Collectives run when there is more than one rank (HIJIKI_DIST_FORCE=1, a test rig: also with one, so that the RCCL calls
+    of the multi-GPU path execute on a one-GPU box)."""
     import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("HIJIKI_DIST_FORCE") == "1")
 
 
 def _through_host(t):

@@ -863,10 +863,18 @@ sys.path.insert(0, os.getcwd())
 from hijiki_amd import host, device, dist as hjdist
 os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[1],
                   HSA_ENABLE_IPC_MODE_LEGACY="0")
-torch.cuda.set_device(0)
-dist.init_process_group(backend="nccl", rank=0, world_size=1)
+os.environ["HIJIKI_DIST_FORCE"] = "1"                        # collectives also with one rank (hijiki_amd/dist.py)
+hjdist._init_group("nccl", 0, 1, 0)                          # bench.py's own init: high-priority stream option, first collective
+assert dist.get_backend() == "nccl"
 cs = host.Scene.synthetic(host.SYNTH_CBOX).compile()
 sr = hjdist.ShardedRenderer(cs, 256, 256)
+# bench.py's timed loop through RCCL: frames back to back, frame k reduced (ncclReduce on torch's stream) while frame k + 1 renders
+st = sr.render_frames(5, 8, 5, reduce=True)
+assert st["paths"] == 5 * 256 * 256 * 8
+hjdist.barrier(); assert hjdist.max_over_ranks(1.5, device=0) == 1.5
+pipelined = sr.fb.clone()
+sr.render_frame(8, 5, reduce=True)
+assert torch.equal(sr.fb.view(torch.int32), pipelined.view(torch.int32))
 sr.render_frame(8, 5, reduce=False)
 before = sr.fb.clone()
 dist.all_reduce(sr.fb, op=dist.ReduceOp.SUM)                 # RCCL on the buffer the C ABI rendered into
