@@ -381,6 +381,11 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
   static const size_t batch_cap = (size_t)env_int("HJ_BATCH_CAP", 8192, 64, 32768);
   run.batch = run.o.batch_blocks ? run.o.batch_blocks
                                  : (uint32_t)std::min<size_t>(batch_cap, std::max<size_t>(256, ((n + 3) / 4 + 63) / 64 * 64));
+  // Frames back to back (HJ_RENDER_NO_DRAIN): the slots overlap ACROSS frames, so a frame need not be cut into four batches for
+  // them - half a frame per batch, a whole small one (fewer, larger batches spend less of their time in tails): rank 0's share of
+  // the c2 frame at 8 / 4 ranks 21.2 -> 20.3 ms / 40.7 -> 40.2 ms (tools/frames_probe.py); the one-rank frame is at the cap already.
+  if (run.no_drain && !run.o.batch_blocks)
+    run.batch = (uint32_t)std::min<size_t>(batch_cap, std::max<size_t>(256, (std::max<size_t>((n + 1) / 2, std::min<size_t>(n, 4096)) + 63) / 64 * 64));
   run.batch = std::min<uint32_t>(run.batch, run.split ? 2048u : 32768u);   // (a sample index has 31 bits: 131 072 blocks at most)   // the split path keeps every sample of a batch in flight
   // Footprint: per batch slot 512 KB of samples per ImageBlock of the batch + num_wg x pool positions of
   // path state (184 B each, 216 B with tinted dielectrics).  DEFAULTS that do not fit the device's free memory (other
