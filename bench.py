@@ -40,7 +40,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before torch initialises HIP: see hijiki_amd/__init__.py
+# before torch initialises HIP (hijiki_amd/__init__.py): seven library streams (3 batch slots + their 3 high-priority
+# reconstruction streams + 1) want hardware queues of their own; with more than one rank torch's stream and RCCL's come on top
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "8")
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (about 6.3 TB/s achievable)
 
