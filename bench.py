@@ -303,7 +303,7 @@ def run_config(name, cfg, args, steps, warmup, hj, barrier):
     sr = hjdist.ShardedRenderer(cs, W, H, local_rank=local)
     opts = device.default_opts()
     opts.flags = abi.RENDER_TIME_KERNELS      # HIP events around every kernel class, on the library's own streams
-    sr.reserve(spp, opts)                     # set-up: the batch slots' device memory (86 GB at the defaults) is allocated here, not in a frame
+    sr.reserve(spp, opts)                     # set-up: the batch slots' device memory (50 GB at the defaults) is allocated here, not in a frame
     # Frames back to back: the batch pipeline is not drained between two frames (hj_render_frame with HJ_RENDER_NO_DRAIN,
     # ShardedRenderer.render_frames): frame k + 1's first batches run beside the path-depth tail of frame k's last ones, and
     # frame k's reduce beside frame k + 1's rendering.  Every one of the K frames is rendered, reduced and complete inside the

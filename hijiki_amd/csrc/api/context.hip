@@ -153,10 +153,13 @@ int hj_context_create(int device, hj_context** out) {
   ctx->num_wg_small = std::min(ctx->num_wg, (uint32_t)ctx->num_cus * (uint32_t)env_int("HJ_WG_SMALL", 6, 1, 32));
   ctx->num_wg_eff = ctx->num_wg;
   ctx->num_slots = (uint32_t)env_int("HJ_SLOTS", 3, 1, (int)kMaxSlots);
-  // positions per workgroup: 65536 = every sample of a workgroup's share of an 8192-block batch in flight at once (the walk
-  // phases of a round are long, their ramp-down costs once per round: c2 +6 %, c3 +4 % over 8192 positions with path
-  // regeneration; 32768: +4.5 %; 24.7 GB of path state per batch slot, lowered by run_begin when the device is short of memory)
-  ctx->pool = (uint32_t)env_int("HJ_POOL", 65536, 64, 1 << 20) / 64u * 64u;
+  // positions per workgroup: the more paths a workgroup has in flight, the longer the walk phases of its rounds and the less
+  // their ramp-down weighs.  One blocking frame after the other: 32768 is +4.5 % over 8192 on c2 / c3, 65536 (every sample
+  // of a workgroup's share of an 8192-block batch in flight at once: round 3's default, 24.7 GB of path state per slot) +6 %.
+  // Frames back to back: 16384 ... 65536 are the same within a per cent (c2 3433-3441 / 3404-3412 / 3391-3411, c3 2769 / 2773-2791 /
+  // 2779-2788, c4 1166-1171 / 1160-1172 / 1160 Mrays/s at 16384 / 32768 / 65536; 8192: -2.5 %): the tails that a large pool
+  // shortens are covered by the next frame there.  32768 = 12.4 GB per slot, 50 GB per context instead of 86.
+  ctx->pool = (uint32_t)env_int("HJ_POOL", 32768, 64, 1 << 20) / 64u * 64u;
   for (auto& sl : ctx->slots) {
     if ((e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     if ((e = hipHostMalloc((void**)&sl.h_counts, sizeof(uint32_t) * 6 * ctx->num_wg, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");

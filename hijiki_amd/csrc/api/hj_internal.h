@@ -99,8 +99,8 @@ struct hj_context {
   uint32_t num_wg = 2048;                // grid size of the path kernels of a large render call (= queue segments), and the most a call uses
   uint32_t num_wg_small = 1536;          // ... of a small one (run_begin)
   uint32_t num_wg_eff = 2048;            // ... of the current call
-  uint32_t pool = 65536;                 // path slots per workgroup of the fused kernel (HJ_POOL)
-  uint32_t pool_eff = 65536;             // ... as the current render call uses it (lowered when device memory is short)
+  uint32_t pool = 32768;                 // path slots per workgroup of the fused kernel (HJ_POOL)
+  uint32_t pool_eff = 32768;             // ... as the current render call uses it (lowered when device memory is short)
 
   // timing
   std::vector<EventPair> events;

@@ -227,11 +227,11 @@ int hj_framebuffer_resolve(hj_context* ctx, float* host_rgb /* W*H*3 */);
 /* Optional set-up step (no counterpart upstream: Renderer::new creates every resource it needs, src/main.rs:1167-1314):
  * allocates the batch slots - path state and sample buffers - that a render call of `total_blocks` ImageBlocks with
  * these options will use (for hj_render_frame: spp x blocks per pass / world), so that the first frame does not pay for
- * them (86 GB and 1.3 s for the benchmark's frames at the defaults).  A render call allocates whatever is missing.
+ * them (50 GB and 0.8 s for the benchmark's frames at the defaults).  A render call allocates whatever is missing.
  * Preconditions: a scene has been uploaded and a framebuffer created (HJ_ERR_STATE otherwise, as for a render call: the
- * sizes depend on both); no asynchronous frame in flight.  MEMORY: the defaults take up to 30 % of a 288 GB device (three
- * batch slots of 24.7 GB of path state + 4.3 GB of samples each, for calls of 32768 ImageBlocks and more; a call of n
- * blocks takes about n x 2.7 MB up to that).  Both hj_reserve and the render calls first fit their request to the free
+ * sizes depend on both); no asynchronous frame in flight.  MEMORY: the defaults take up to 17 % of a 288 GB device (three
+ * batch slots of 12.4 GB of path state + 4.3 GB of samples each, for calls of 32768 ImageBlocks and more; a call of n
+ * blocks takes about n x 2.7 MB up to that; HJ_POOL).  Both hj_reserve and the render calls first fit their request to the free
  * device memory (hipMemGetInfo) and, when an allocation fails all the same - another context or the host application took
  * the memory in between -, give back every slot, halve the positions per workgroup (down to 1024), then the batch (down to
  * 64 ImageBlocks), then run ONE batch slot instead of three, and try again: HJ_ERR_NOMEM is returned only when the smallest
