@@ -682,6 +682,23 @@ def test_pure_c_host_example(tmp_path):
     assert "8388608 paths" in r.stdout and os.path.getsize(out) > 512 * 512 * 12
 
 
+def test_pure_c_host_frames_back_to_back(tmp_path):
+    """examples/render_frames.c: a C99 host renders five frames back to back (HJ_RENDER_NO_DRAIN, hj_framebuffer_bind,
+    hj_pipeline_wait) into two hipMalloc'ed buffers and compares each, bit for bit, with a blocking call's frame."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "render_frames")
+    cmd = ["gcc", "-std=c99", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include"), "-I/opt/rocm/include",
+           os.path.join(root, "examples", "render_frames.c"), "-L" + os.path.join(root, "hijiki_amd", "lib"),
+           "-lhijiki_hip", "-lhijiki_host", "-Wl,-rpath," + os.path.join(root, "hijiki_amd", "lib"),
+           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-o", exe]
+    c = subprocess.run(cmd, capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "5 frames back to back: 7864320 paths" in r.stdout and "bit-identical" in r.stdout
+
+
 def test_edge_inputs(gpu_renderer, oracle):
     """Empty block list, 1x1 blocks, a scene without emitters, a camera that sees nothing."""
     r = gpu_renderer
