@@ -722,6 +722,8 @@ int hj_render_frame_async(hj_context* ctx, uint32_t spp, uint64_t master_seed, u
   if (!ctx) return HJ_ERR_INVALID;
   HJ_NOT_BUSY(ctx);
   HJ_NOT_PIPELINED(ctx);
+  if (opts && (opts->flags & HJ_RENDER_NO_DRAIN))
+    return set_error(ctx, HJ_ERR_INVALID, "HJ_RENDER_NO_DRAIN belongs to hj_render_frame (it returns at once by itself), not to the asynchronous form");
   hj_context::AsyncJob j{};
   j.spp = spp; j.master_seed = master_seed; j.pass_begin = pass_begin; j.pass_end = pass_end; j.rank = rank; j.world = world;
   if (opts) j.opts = *opts;
