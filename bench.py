@@ -327,11 +327,20 @@ def run_config(name, cfg, args, steps, warmup, hj, barrier):
     agg = frames(steps)
     barrier()
     elapsed = hjdist.max_over_ranks(time.perf_counter() - t0, device=sr.local)     # the slowest rank's wall time
+    # one BLOCKING frame after the timed region (not part of `value`): what a single frame takes from submission to the
+    # reduced result when nothing overlaps its end - the latency figure beside the back-to-back throughput
+    latency_ms = None
+    if pipelined:
+        barrier()
+        t1 = time.perf_counter()
+        sr.render_frame(spp, args.seed, opts=opts, reduce=True)
+        barrier()
+        latency_ms = hjdist.max_over_ranks(1e3 * (time.perf_counter() - t1), device=sr.local)
     if getattr(args, "dump_frame", None) and name == args.config and rank == 0:
         import numpy as np
         np.save(args.dump_frame, sr.fb.cpu().numpy())          # the reduced frame of the last timed step (tests compare it)
     sr.close()
-    return dict(cs=cs, W=W, H=H, spp=spp, agg=agg, elapsed=elapsed, steps=steps, pipelined=pipelined,
+    return dict(cs=cs, W=W, H=H, spp=spp, agg=agg, elapsed=elapsed, steps=steps, pipelined=pipelined, latency_ms=latency_ms,
                 standard=(W, H, spp) == (cfg["size"], cfg["size"], cfg["spp"]))
 
 
@@ -408,6 +417,7 @@ def main():
             "rccl_backend": dist.get_backend() if world > 1 and dist.is_initialized() else None,
             # steps overlap at their seams (the next frame's first batches beside this frame's last): all K frames lie inside the timed region
             "frames_back_to_back": bool(res["pipelined"]),
+            "blocking_frame_ms": None if res["latency_ms"] is None else round(res["latency_ms"], 3),   # one frame alone, after the timed region
         }
         oracle_counters = None
         if not args.no_cpu_baseline and world == 1:        # the CPU baseline is a one-GPU-run item (rank 0, N = 1 only)
