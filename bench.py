@@ -330,7 +330,7 @@ def run_config(name, cfg, args, steps, warmup, hj, barrier):
     # one BLOCKING frame after the timed region (not part of `value`): what a single frame takes from submission to the
     # reduced result when nothing overlaps its end - the latency figure beside the back-to-back throughput
     latency_ms = None
-    if pipelined:
+    if pipelined and not getattr(args, "no_latency_frame", False):
         barrier()
         t1 = time.perf_counter()
         sr.render_frame(spp, args.seed, opts=opts, reduce=True)
@@ -359,6 +359,8 @@ def main():
                     help="only the headline configuration (the default c2 run on one GPU also times 3 frames each of c3 and c4)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="drain the batch pipeline after every frame (one blocking hj_render_frame per step, as in rounds 1-3)")
+    ap.add_argument("--no-latency-frame", action="store_true",
+                    help="skip the one blocking frame after the timed region (`blocking_frame_ms`): profiling runs that count frames")
     ap.add_argument("--dump-frame", default=None, metavar="FILE.npy",
                     help="rank 0 saves the reduced RGBA32F accumulation buffer of the last timed frame (after the timed region)")
     ap.add_argument("--inproc", action="store_true",

@@ -11,7 +11,7 @@ export GPU_MAX_HW_QUEUES=8
 tag=$1; cfg=${2:-c2}
 root=$(pwd); out=$root/gpurun_out/${tag}_${cfg}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $out/stats.log 2>&1 || echo "stats pass failed"
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-latency-frame > $out/stats.log 2>&1 || echo "stats pass failed"
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv 2>/dev/null
 python3 $root/tools/roofline_inputs.py trace "$(find $out/stats -name "*kernel_trace.csv" | head -1)" 2 > $out/kernel_trace_summary.txt
 cat $out/kernel_trace_summary.txt
@@ -19,7 +19,7 @@ grep '^{' $out/stats.log > $out/bench_under_rocprof.json
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM SQ_INSTS_SALU" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 500 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/p$i -- python3 $root/bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > $out/p$i.log 2>&1 || echo "pmc pass $i ($grp) failed"
+  timeout 500 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/p$i -- python3 $root/bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-latency-frame > $out/p$i.log 2>&1 || echo "pmc pass $i ($grp) failed"
   f=$(find $out/p$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 $root/tools/roofline_inputs.py pmc "$f" > $out/pmc_pass$i.csv
   rm -rf $out/p$i

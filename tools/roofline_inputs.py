@@ -91,7 +91,7 @@ def cmd_build(d, cfg, prefix=""):
     c, launches = read_passes(files)
     paths = PATHS[cfg]
     out = {"config": cfg, "kernel": "k_path_wavefront", "paths_per_frame": paths, "launches_per_frame": launches,
-           "command": f"tools/profile_config.sh: rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py --config {cfg} --steps 1 --warmup 0 --no-cpu-baseline --no-secondary, one pass per group, GPU_MAX_HW_QUEUES=8",
+           "command": f"tools/profile_config.sh: rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py --config {cfg} --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-latency-frame, one pass per group, GPU_MAX_HW_QUEUES=8",
            "counters": {k: v for k, v in sorted(c.items())}}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:      # rocprofv3 reports both in KiB
         fetch, write = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
