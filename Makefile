@@ -9,14 +9,14 @@ CC ?= gcc
 ARCH ?= gfx950
 
 FP_STRICT = -ffp-contract=off -fno-fast-math
-HOST_SRC = hijiki_amd/csrc/host/scene.cpp hijiki_amd/csrc/host/synth.cpp hijiki_amd/csrc/host/blockgen.cpp \
+HOST_SRC = hijiki_amd/csrc/host/scene.cpp hijiki_amd/csrc/host/tree_opt.cpp hijiki_amd/csrc/host/synth.cpp hijiki_amd/csrc/host/blockgen.cpp \
            hijiki_amd/csrc/host/obj_loader.cpp hijiki_amd/csrc/host/image_io.cpp hijiki_amd/csrc/host/host_api.cpp
 HOST_HDR = hijiki_amd/csrc/host/scene.hpp hijiki_amd/csrc/host/blockgen.hpp include/hijiki_hip.h include/hijiki_host.h
 # libhijiki_hip.so: five translation units (hijiki_amd/csrc/api/hj_internal.h lists them); only render.hip and
 # lbvh_build.hip hold device code.  The register / scratch / LDS report of the path kernels: hijiki_amd/lib/resource_usage.txt.
 HIP_UNITS = context scene_upload render comm lbvh_build
-HIP_OBJ = $(HIP_UNITS:%=build/obj/%.o) build/obj/blockgen.o
-HIP_HDR = $(wildcard hijiki_amd/csrc/kernels/*.h) hijiki_amd/csrc/api/hj_internal.h include/hijiki_hip.h hijiki_amd/csrc/host/blockgen.hpp
+HIP_OBJ = $(HIP_UNITS:%=build/obj/%.o) build/obj/blockgen.o build/obj/light_grid.o
+HIP_HDR = $(wildcard hijiki_amd/csrc/kernels/*.h) hijiki_amd/csrc/api/hj_internal.h hijiki_amd/csrc/api/light_grid.hpp include/hijiki_hip.h hijiki_amd/csrc/host/blockgen.hpp
 HIP_FLAGS = --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC $(FP_STRICT) -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden \
             -Wall -Wno-unused-function $(HIP_EXTRA)
 
@@ -40,6 +40,10 @@ build/obj/%.o: hijiki_amd/csrc/api/%.hip $(HIP_HDR)
 	@mkdir -p build/obj
 	$(HIPCC) $(HIP_FLAGS) -c $< -o $@
 
+build/obj/light_grid.o: hijiki_amd/csrc/api/light_grid.cpp hijiki_amd/csrc/api/light_grid.hpp include/hijiki_hip.h
+	@mkdir -p build/obj
+	$(CXX) -std=c++17 -O2 -fPIC -pthread -Wall -Wextra $(FP_STRICT) -fvisibility=hidden -c $< -o $@
+
 build/obj/blockgen.o: hijiki_amd/csrc/host/blockgen.cpp hijiki_amd/csrc/host/blockgen.hpp include/hijiki_hip.h
 	@mkdir -p build/obj
 	$(CXX) -std=c++17 -O2 -fPIC $(FP_STRICT) -fvisibility=hidden -c $< -o $@
@@ -53,7 +57,7 @@ oracle/_build/libhj_oracle.so: oracle/hj_oracle.c include/hijiki_hip.h
 	@mkdir -p oracle/_build
 	$(CC) -std=c11 -O2 -fPIC -shared -Wall -Wextra $(FP_STRICT) -mfma -fvisibility=hidden -o $@ oracle/hj_oracle.c -lm -lpthread
 
-CLI_SRC = hijiki_amd/csrc/cli/main.cpp hijiki_amd/csrc/host/scene.cpp hijiki_amd/csrc/host/synth.cpp \
+CLI_SRC = hijiki_amd/csrc/cli/main.cpp hijiki_amd/csrc/host/scene.cpp hijiki_amd/csrc/host/tree_opt.cpp hijiki_amd/csrc/host/synth.cpp \
           hijiki_amd/csrc/host/obj_loader.cpp hijiki_amd/csrc/host/image_io.cpp
 hijiki_amd/bin/hijiki-hip: $(CLI_SRC) $(HOST_HDR) hijiki_amd/lib/libhijiki_hip.so
 	@mkdir -p hijiki_amd/bin

@@ -308,8 +308,11 @@ std::vector<BuildNode> build_bvh(const std::vector<Aabb>& boxes) {
     if (std::getenv("HJ_BVH_ROTATE_VERBOSE")) std::fprintf(stderr, "rotation pass %d: half-area gain %.4f\n", p, r.gain);
     if (r.gain <= 0) break;
   }
-  static const int child_order = [] { const char* e = std::getenv("HJ_BVH_CHILD_ORDER"); return e ? std::atoi(e) : 3; }();
-  if (child_order != 0) order_children(b.nodes, 0, child_order);
+  // HJ_BVH_REINSERT = passes of the insertion-based optimisation (tree_opt.cpp)
+  static const int reinsert_passes = [] { const char* e = std::getenv("HJ_BVH_REINSERT"); return e ? std::atoi(e) : 3; }();
+  if (reinsert_passes > 0) optimize_by_reinsertion(b.nodes, reinsert_passes);
+  static const int child_order = [] { const char* e = std::getenv("HJ_BVH_CHILD_ORDER"); return e ? std::atoi(e) : 4; }();
+  if (child_order != 0) order_children(b.nodes, 0, std::min(child_order, 3));
   return std::move(b.nodes);
 }
 
@@ -356,6 +359,16 @@ CompiledScene compile(const Scene& scene) {
 
   // BVH::build (src/main.rs:199) -> depth-first flatten with skip links (src/main.rs:203-231)
   std::vector<BuildNode> tree = build_bvh(boxes);
+  {
+    // HJ_BVH_CHILD_ORDER = 4: on top of "fewer shapes first", the order a sample of the renderer's own rays votes for
+    // (tree_opt.cpp); HJ_BVH_VOTE_PATHS = camera paths of the sample
+    static const int child_order = [] { const char* e = std::getenv("HJ_BVH_CHILD_ORDER"); return e ? std::atoi(e) : 4; }();
+    static const long vote_paths = [] { const char* e = std::getenv("HJ_BVH_VOTE_PATHS"); return e ? std::atol(e) : 0l; }();
+    if (child_order >= 4) {
+      const size_t paths = vote_paths > 0 ? (size_t)vote_paths : std::min<size_t>(200000, std::max<size_t>(60000, n / 2));
+      order_children_by_rays(tree, scene, paths);
+    }
+  }
   const uint32_t ns = (uint32_t)out.spheres.size(), nq = (uint32_t)out.quads.size();
   auto global_index = [&](int32_t obj) -> uint32_t {  // src/main.rs:232-243
     switch (scene.objects[obj].first.kind) {

@@ -77,6 +77,10 @@ struct BuildNode {
   Aabb left_box, right_box;       // child_l_aabb / child_r_aabb
 };
 std::vector<BuildNode> build_bvh(const std::vector<Aabb>& boxes);  // node 0 is the root
+// Optimisation passes over the finished tree (tree_opt.cpp): insertion-based optimisation of the surface-area cost, and the
+// order of every node's two children voted by a sample of the rays the renderer will trace through `scene`.
+double optimize_by_reinsertion(std::vector<BuildNode>& nodes, int passes);
+size_t order_children_by_rays(std::vector<BuildNode>& nodes, const Scene& scene, size_t num_paths);
 
 // Synthetic bench scenes.
 Scene make_synthetic(int kind, uint32_t mesh_triangles, uint32_t gen_seed);

@@ -530,7 +530,7 @@ def test_config4_million_triangles_bit_exact(gpu_renderer, oracle, mesh_1m):
     got, st = render(gpu_renderer, cs, W, H, blocks)
     assert_same(got, want, "1M mesh, SAH tree")
     assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"]
-    assert ctr["nodes"] / ctr["closest_calls"] > 50
+    assert ctr["nodes"] / ctr["closest_calls"] > 35          # a deep tree (48.8 node visits per closest-hit ray with round 5's tree passes, 53 before)
     sah = cs.bvh.copy()
     nodes = gpu_renderer.build_bvh(cs)
     assert len(nodes) == len(sah) and int(nodes[0, 7]) == len(nodes)
@@ -606,7 +606,7 @@ def test_large_mesh_and_large_frame(gpu_renderer, oracle):
     want, ctr, _ = oracle.render_blocks(cs, blocks, W, H)
     got, _ = render(gpu_renderer, cs, W, H, blocks)
     assert_same(got, want, "200k mesh")
-    assert ctr["nodes"] / ctr["closest_calls"] > 40
+    assert ctr["nodes"] / ctr["closest_calls"] > 30
     r = gpu_renderer
     cbox = host.Scene.synthetic(host.SYNTH_CBOX).compile()
     r.upload_scene(cbox)
