@@ -20,6 +20,7 @@ RENDER_TIME_KERNELS = 1
 RENDER_SPLIT_KERNELS = 2
 RENDER_STATIC_DEAL = 4
 RENDER_NO_DRAIN = 8
+RENDER_NO_LIGHT_GRID = 16
 
 f32, u32, u64 = C.c_float, C.c_uint32, C.c_uint64
 

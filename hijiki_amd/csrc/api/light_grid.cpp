@@ -1,0 +1,308 @@
+// Light-shaft visibility grid: which next-event shadow rays need no walk at all.
+//
+// The reference traces a shadow ray for every next-event sample (shader/render.glsl:117-126 -> scene.glsl:92-96, a full
+// closest-hit walk; "TODO: optimize" upstream) and only its boolean is used.  On a Cornell-box-shaped scene most of those
+// rays run from a wall to the light through empty space.  This grid proves that ahead of time, per (cell of a uniform grid
+// over the scene, emitter): bit e of a cell is set only if EVERY shadow ray the renderer can generate from a hit point in
+// that cell towards a sampled point of emitter e is unoccluded - whatever tree is walked, and including what float rounding
+// can do to the shape tests - so the shade stage adds such a sample's contribution at once and no ray is queued.  A cleared
+// bit costs nothing but the walk that would have run anyway.  Shaft culling in the sense of Haines & Wallace 1991.
+//
+// A bit is set when all of this holds (scale = extent of the scene incl. the camera; tol_p = 2e-6 scale bounds the distance
+// of a computed hit point from its shape's plane, tol_s = 2e-7 scale is "coplanar", m = 1e-4 max(1, scale) pads every box):
+//   1. every shape whose padded bounding box overlaps the padded cell is a triangle or quad, and all of them lie in ONE
+//      plane P (every vertex within tol_s): a hit point p in the cell lies on one of them, i.e. within tol_p of P;
+//   2. emitter e is a triangle or quad (plane Q) and all of it lies on one side of P at an angle: for every point y of its
+//      padded box, |dist(y, P)| - tol_p >= 0.25 |y - x| for every x of the padded cell.  A ray leaving P that steeply is more
+//      than tol_s away from P from t = 1e-4 on (tMin of a shadow ray is 2e-4, scene.glsl:85), so no shape coplanar with P
+//      - the one p lies on, its neighbours in the wall - can be hit; the same with the roles exchanged (0.1) at the emitter:
+//      shapes coplanar with Q, the emitter itself included, are met at t >= dist - 1e-5 > tMax = dist - 1e-4;
+//   3. no other shape's padded bounding box touches the convex hull of the padded cell and the padded box of the emitter
+//      (every segment p -> y lies in that hull).  The hull of two boxes is the intersection, over the three axes, of the
+//      extruded 2-D hulls of their projections (every facet normal of the hull is perpendicular to an axis), so a box is
+//      outside it as soon as one projection separates them: by the union rectangle or by one of the four lines through
+//      corresponding corners.  The test errs only towards "touches".
+// The leaves are enumerated through the uploaded skip-link array itself, with subtree bounds recomputed from the shapes
+// (the array's own boxes are not trusted: tests upload trees with wrong boxes): every leaf whose bounds touch the shaft is
+// looked at, in any well- or ill-formed array whose exits point forward.  Shapes the array does not hold cannot be hit.
+#include "light_grid.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace hjapi {
+
+namespace {
+
+struct Box { double lo[3], hi[3]; };
+inline Box empty_box() { return {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}}; }
+inline void grow(Box& b, const double p[3]) { for (int k = 0; k < 3; k++) { b.lo[k] = std::min(b.lo[k], p[k]); b.hi[k] = std::max(b.hi[k], p[k]); } }
+inline void join(Box& b, const Box& o) { for (int k = 0; k < 3; k++) { b.lo[k] = std::min(b.lo[k], o.lo[k]); b.hi[k] = std::max(b.hi[k], o.hi[k]); } }
+inline Box pad(Box b, double m) { for (int k = 0; k < 3; k++) { b.lo[k] -= m; b.hi[k] += m; } return b; }
+inline bool finite_box(const Box& b) { for (int k = 0; k < 3; k++) if (!(std::isfinite(b.lo[k]) && std::isfinite(b.hi[k]) && b.lo[k] <= b.hi[k])) return false; return true; }
+
+struct Plane { double n[3], d; bool ok; };        // n.x - d = signed distance, |n| = 1
+
+struct Geometry {
+  const hj_scene_desc* s;
+  size_t ns, nq, nt;
+  int vertices(size_t shape, double v[4][3]) const {          // 0 for a sphere
+    if (shape < ns) return 0;
+    if (shape < ns + nq) {
+      const hj_quad& q = s->quads[shape - ns];
+      for (int k = 0; k < 3; k++) {
+        v[0][k] = q.origin[k]; v[1][k] = (double)q.origin[k] + q.edge1[k]; v[2][k] = (double)q.origin[k] + q.edge2[k];
+        v[3][k] = (double)q.origin[k] + q.edge1[k] + q.edge2[k];
+      }
+      return 4;
+    }
+    const hj_triangle& t = s->triangles[shape - ns - nq];
+    for (int c = 0; c < 3; c++) for (int k = 0; k < 3; k++) v[c][k] = s->vertices[t.v[c]].pos[k];
+    return 3;
+  }
+  Box bounds(size_t shape) const {
+    Box b = empty_box();
+    if (shape < ns) {
+      const hj_sphere& sp = s->spheres[shape];
+      const double r = std::fabs((double)sp.radius);
+      for (int k = 0; k < 3; k++) { b.lo[k] = sp.center[k] - r; b.hi[k] = sp.center[k] + r; }
+      return b;
+    }
+    double v[4][3];
+    const int n = vertices(shape, v);
+    for (int c = 0; c < n; c++) grow(b, v[c]);
+    return b;
+  }
+  Plane plane(size_t shape) const {
+    Plane p{};
+    double v[4][3];
+    if (vertices(shape, v) < 3) return p;
+    const double a[3] = {v[1][0] - v[0][0], v[1][1] - v[0][1], v[1][2] - v[0][2]}, b[3] = {v[2][0] - v[0][0], v[2][1] - v[0][1], v[2][2] - v[0][2]};
+    double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    const double la = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), lb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+    if (!(l > 1e-9 * la * lb) || !std::isfinite(l) || l == 0.0) return p;        // (needle triangles have no usable plane)
+    for (int k = 0; k < 3; k++) p.n[k] = n[k] / l;
+    p.d = p.n[0] * v[0][0] + p.n[1] * v[0][1] + p.n[2] * v[0][2];
+    p.ok = true;
+    return p;
+  }
+  bool coplanar(size_t shape, const Plane& p, double tol) const {
+    double v[4][3];
+    const int n = vertices(shape, v);
+    if (n == 0) return false;
+    for (int c = 0; c < n; c++)
+      if (!(std::fabs(p.n[0] * v[c][0] + p.n[1] * v[c][1] + p.n[2] * v[c][2] - p.d) <= tol)) return false;
+    return true;
+  }
+};
+
+// The shaft between two boxes, as its projections along the three axes.
+struct Shaft {
+  Box a, b, u;                                   // the two boxes and their union
+  // per axis k (projection plane (i, j) = the other two axes): up to four supporting lines n.x <= c of the 2-D hull
+  struct Line { double ni, nj, c; };
+  Line lines[3][4];
+  int nlines[3];
+  Shaft(const Box& A, const Box& B) : a(A), b(B), u(A) {
+    join(u, B);
+    for (int k = 0; k < 3; k++) {
+      const int i = (k + 1) % 3, j = (k + 2) % 3;
+      nlines[k] = 0;
+      for (int ci = 0; ci < 2; ci++) for (int cj = 0; cj < 2; cj++) {
+        // the line through corner (ci, cj) of A's rectangle and the same corner of B's
+        const double ax = ci ? A.hi[i] : A.lo[i], ay = cj ? A.hi[j] : A.lo[j], bx = ci ? B.hi[i] : B.lo[i], by = cj ? B.hi[j] : B.lo[j];
+        double nx = -(by - ay), ny = bx - ax;                                  // a normal of the line
+        if (nx == 0.0 && ny == 0.0) continue;
+        // orient it away from both rectangles: every corner of A and B must satisfy n.x <= c (a supporting line), else skip
+        for (int flip = 0; flip < 2; flip++) {
+          const double sx = flip ? -nx : nx, sy = flip ? -ny : ny, c = sx * ax + sy * ay;
+          double worst = -INFINITY;
+          for (int di = 0; di < 2; di++) for (int dj = 0; dj < 2; dj++) {
+            worst = std::max(worst, sx * (di ? A.hi[i] : A.lo[i]) + sy * (dj ? A.hi[j] : A.lo[j]) - c);
+            worst = std::max(worst, sx * (di ? B.hi[i] : B.lo[i]) + sy * (dj ? B.hi[j] : B.lo[j]) - c);
+          }
+          const double slack = 1e-12 * (std::fabs(c) + std::fabs(sx) + std::fabs(sy));
+          if (worst <= slack) { lines[k][nlines[k]++] = {sx, sy, c + slack}; break; }
+        }
+      }
+    }
+  }
+  // true only if box q certainly does not touch the shaft
+  bool outside(const Box& q) const {
+    for (int k = 0; k < 3; k++) if (q.lo[k] > u.hi[k] || q.hi[k] < u.lo[k]) return true;
+    for (int k = 0; k < 3; k++) {
+      const int i = (k + 1) % 3, j = (k + 2) % 3;
+      for (int l = 0; l < nlines[k]; l++) {
+        const Line& L = lines[k][l];
+        // the corner of q that lies deepest inside the half-plane n.x <= c
+        const double best = L.ni * (L.ni > 0 ? q.lo[i] : q.hi[i]) + L.nj * (L.nj > 0 ? q.lo[j] : q.hi[j]);
+        if (best > L.c) return true;
+      }
+    }
+    return false;
+  }
+};
+
+}  // namespace
+
+bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
+  out = LightGrid{};
+  if (!s || res < 2 || res > 256 || s->num_emitters == 0 || s->num_bvh_nodes == 0) return false;
+  const Geometry g{s, s->num_spheres, s->num_quads, s->num_triangles};
+  const size_t shapes = g.ns + g.nq + g.nt, N = s->num_bvh_nodes;
+
+  // bounds of the scene (shapes) and the scale of the coordinates (incl. the camera: camera rays start there)
+  std::vector<Box> sb(shapes);
+  Box scene = empty_box();
+  for (size_t i = 0; i < shapes; i++) { sb[i] = g.bounds(i); join(scene, sb[i]); }
+  if (!finite_box(scene)) return false;
+  Box all = scene;
+  { const double c[3] = {s->camera.position[0], s->camera.position[1], s->camera.position[2]}; if (std::isfinite(c[0] + c[1] + c[2])) grow(all, c); }
+  double scale = 0, ext = 0;
+  for (int k = 0; k < 3; k++) { scale = std::max(scale, std::max(all.hi[k] - all.lo[k], std::max(std::fabs(all.lo[k]), std::fabs(all.hi[k])))); ext = std::max(ext, scene.hi[k] - scene.lo[k]); }
+  if (!(ext > 0)) return false;
+  const double tol_p = 2e-6 * scale, tol_s = 2e-7 * scale, m = 1e-4 * std::max(1.0, scale);
+  constexpr double kSinCell = 0.25, kSinEmitter = 0.1, kTMin = 2e-4, kEps = 1e-4;
+  // the two escape arguments of the header must hold with room to spare at this scale, or there is no grid
+  if (!((tol_p + tol_s) / kSinCell < 0.5 * kTMin && 2 * tol_s / kSinEmitter < 0.5 * kEps)) return false;
+
+  // subtree bounds from the shapes: sub[i] covers every leaf with an index in [i, exit(i))
+  std::vector<Box> sub(N);
+  for (size_t i = N; i-- > 0;) {
+    const hj_bvh_node& nd = s->bvh[i];
+    Box b = empty_box();
+    if (nd.shape_index != HJ_BVH_INNER) { if (nd.shape_index >= shapes) return false; b = sb[nd.shape_index]; }
+    const size_t e = std::min<size_t>(nd.exit_index, N);
+    if (e <= i) return false;
+    int chain = 0;
+    for (size_t j = i + 1; j < e; j = std::min<size_t>(s->bvh[j].exit_index, N)) {
+      join(b, sub[j]);
+      if (++chain > 8) return false;                       // not a tree this code wants to reason about
+    }
+    sub[i] = b;
+  }
+
+  // the grid over the padded scene bounds
+  const Box gb = pad(scene, 4 * m);
+  double cell[3];
+  for (int k = 0; k < 3; k++) cell[k] = (gb.hi[k] - gb.lo[k]) / res;
+  out.res = res;
+  for (int k = 0; k < 3; k++) { out.lo[k] = (float)gb.lo[k]; out.inv[k] = (float)(1.0 / cell[k]); }
+  // (the kernel computes the cell index in float from out.lo / out.inv: a cell's guarantee covers the padded cell, and the
+  // padding - m on every side, plus the shapes' own - is orders of magnitude above what that rounding can move a point)
+  const size_t ncell = (size_t)res * res * res;
+  out.bits.assign(ncell, 0);
+
+  // rasterise the shapes: per cell the first shape seen, and whether all of them share its plane
+  std::vector<uint32_t> first(ncell, 0xFFFFFFFFu);
+  std::vector<uint8_t> bad(ncell, 0);
+  std::vector<Plane> planes(shapes);
+  for (size_t i = 0; i < shapes; i++) planes[i] = g.plane(i);
+  auto cell_range = [&](const Box& b, int lo[3], int hi[3]) {
+    for (int k = 0; k < 3; k++) {
+      lo[k] = std::max(0, (int)std::floor((b.lo[k] - gb.lo[k]) / cell[k]));
+      hi[k] = std::min((int)res - 1, (int)std::floor((b.hi[k] - gb.lo[k]) / cell[k]));
+    }
+  };
+  for (size_t i = 0; i < shapes; i++) {
+    int lo[3], hi[3];
+    cell_range(pad(sb[i], 2 * m), lo, hi);               // (shape and cell both padded by m)
+    for (int z = lo[2]; z <= hi[2]; z++) for (int y = lo[1]; y <= hi[1]; y++) for (int x = lo[0]; x <= hi[0]; x++) {
+      const size_t c = ((size_t)z * res + y) * res + x;
+      if (bad[c]) continue;
+      if (first[c] == 0xFFFFFFFFu) { first[c] = (uint32_t)i; if (!planes[i].ok) bad[c] = 1; }
+      else if (!g.coplanar(i, planes[first[c]], tol_s)) bad[c] = 1;
+    }
+  }
+
+  // emitters (bit e for e < 8)
+  struct Em { size_t shape; Plane q; Box box; bool ok; };
+  std::vector<Em> ems;
+  for (size_t e = 0; e < std::min<size_t>(s->num_emitters, 8); e++) {
+    Em em{};
+    em.shape = s->emitters[e].shape;
+    em.ok = em.shape < shapes && planes[em.shape].ok;
+    if (em.ok) { em.q = planes[em.shape]; em.box = pad(sb[em.shape], m); }
+    ems.push_back(em);
+  }
+
+  std::vector<uint32_t> work;                              // cells that hold a planar surface
+  for (size_t c = 0; c < ncell; c++) { if (first[c] != 0xFFFFFFFFu) out.cells_surface++; if (first[c] != 0xFFFFFFFFu && !bad[c]) work.push_back((uint32_t)c); }
+  out.cells_planar = work.size();
+
+  std::atomic<size_t> next{0}, clear{0};
+  auto run = [&] {
+    for (;;) {
+      const size_t w = next.fetch_add(64);
+      if (w >= work.size()) break;
+      for (size_t wi = w; wi < std::min(work.size(), w + 64); wi++) {
+        const size_t c = work[wi];
+        const int x = (int)(c % res), y = (int)((c / res) % res), z = (int)(c / ((size_t)res * res));
+        Box cb;
+        const int xyz[3] = {x, y, z};
+        for (int k = 0; k < 3; k++) { cb.lo[k] = gb.lo[k] + xyz[k] * cell[k] - m; cb.hi[k] = gb.lo[k] + (xyz[k] + 1) * cell[k] + m; }
+        const Plane& P = planes[first[c]];
+        uint8_t bits = 0;
+        for (size_t e = 0; e < ems.size(); e++) {
+          const Em& em = ems[e];
+          if (!em.ok) continue;
+          // 2. angles: the emitter's padded box on one side of P, steeply; the padded cell on one side of Q, not grazing
+          double dmax = 0;                                 // the longest segment of the shaft
+          { double d2 = 0; for (int k = 0; k < 3; k++) { const double a = std::max(std::fabs(em.box.hi[k] - cb.lo[k]), std::fabs(cb.hi[k] - em.box.lo[k])); d2 += a * a; } dmax = std::sqrt(d2); }
+          auto side_dist = [&](const Plane& pl, const Box& b, double& lo_d, double& hi_d) {   // range of the signed distance over the box
+            lo_d = -pl.d; hi_d = -pl.d;
+            for (int k = 0; k < 3; k++) { lo_d += pl.n[k] * (pl.n[k] > 0 ? b.lo[k] : b.hi[k]); hi_d += pl.n[k] * (pl.n[k] > 0 ? b.hi[k] : b.lo[k]); }
+          };
+          double lo_d, hi_d;
+          side_dist(P, em.box, lo_d, hi_d);
+          const double near_p = lo_d > 0 ? lo_d : (hi_d < 0 ? -hi_d : 0.0);
+          if (!(near_p - tol_p >= kSinCell * dmax)) continue;
+          // (the hit point is within tol_p of P, so its distance to Q is what the part of the cell near P has: the cell's box is a superset)
+          side_dist(em.q, cb, lo_d, hi_d);
+          const double near_q = lo_d > 0 ? lo_d : (hi_d < 0 ? -hi_d : 0.0);
+          if (!(near_q - tol_s >= kSinEmitter * dmax)) continue;
+          // 3. the shaft holds nothing but shapes in P and shapes in Q
+          const Shaft sh(cb, em.box);
+          bool blocked = false;
+          for (size_t i = 0; i < N && !blocked;) {
+            const hj_bvh_node& nd = s->bvh[i];
+            if (sh.outside(pad(sub[i], m))) { i = std::min<size_t>(nd.exit_index, N); continue; }
+            if (nd.shape_index != HJ_BVH_INNER) {
+              const size_t shp = nd.shape_index;
+              if (!(g.coplanar(shp, P, tol_s) || g.coplanar(shp, em.q, tol_s))) blocked = true;
+            }
+            i++;
+          }
+          if (!blocked) { bits |= (uint8_t)(1u << e); clear.fetch_add(1, std::memory_order_relaxed); }
+        }
+        out.bits[c] = bits;
+      }
+    }
+  };
+  unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (work.size() < 512) nthreads = 1;
+  std::vector<std::thread> pool;
+  try { for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(run); } catch (const std::exception&) {}
+  run();
+  for (auto& t : pool) t.join();
+  out.pairs_clear = clear.load();
+  if (out.pairs_clear == 0) { out = LightGrid{}; return false; }
+  return true;
+}
+
+}  // namespace hjapi
+
+// Test entry (no GPU needed): the grid hj_scene_upload would build for `s`.  bits: res^3 bytes (may be null: sizes only).
+extern "C" __attribute__((visibility("default"))) int hj_debug_light_grid(const hj_scene_desc* s, uint32_t res, uint8_t* bits, float lo[3],
+                                                                           float inv[3], uint64_t stats[3]) {
+  hjapi::LightGrid g;
+  if (!hjapi::build_light_grid(s, res, g)) return 0;
+  if (bits) std::memcpy(bits, g.bits.data(), g.bits.size());
+  for (int k = 0; k < 3; k++) { if (lo) lo[k] = g.lo[k]; if (inv) inv[k] = g.inv[k]; }
+  if (stats) { stats[0] = g.cells_surface; stats[1] = g.cells_planar; stats[2] = g.pairs_clear; }
+  return (int)g.res;
+}

@@ -62,6 +62,7 @@ int ensure_batch(hj_context* ctx, hj_context::BatchSlot& sl, uint32_t num_blocks
       else st.ext[par] = nullptr;
     }
     HJ_ALLOC(sl.bufs, hit, float4, n)
+    HJ_ALLOC(sl.bufs, hit_tag, uint8_t, n)
     HJ_ALLOC(sl.bufs, q_hit, uint32_t, n * hj::kNumTags)
     HJ_ALLOC(sl.bufs, sh_o, float4, n)
     HJ_ALLOC(sl.bufs, sh_d, float4, n)
@@ -83,6 +84,15 @@ int ensure_batch(hj_context* ctx, hj_context::BatchSlot& sl, uint32_t num_blocks
   st.num_wg = G;
   if (rc != HJ_OK) release_slot(sl);
   return rc;
+}
+
+// The scene as a render call's kernels see it: the light-shaft grid (api/light_grid.cpp) answers "no shape of the TREE lies
+// between this cell and that emitter", so it is taken away from a linear-scan render (scene.glsl:134-158 tests every shape of
+// the arrays, in the tree or not) and from a call that asks for every shadow ray to be walked (HJ_RENDER_NO_LIGHT_GRID).
+hj::DeviceScene scene_for(const hj_context* ctx, const hj_render_opts& o) {
+  hj::DeviceScene sc = ctx->scene;
+  if (!o.use_bvh || (o.flags & HJ_RENDER_NO_LIGHT_GRID)) sc.light_grid = nullptr;
+  return sc;
 }
 
 enum { EV_CLOSEST = 0, EV_SHADOW = 1, EV_SHADE = 2, EV_RECON = 3, EV_PATH = 4, EV_KINDS = 5 };
@@ -241,11 +251,12 @@ int enqueue_batch_fused(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::
   // touching the code, to measure how the frame rate scales with occupancy.
   static const size_t lds_pad = (size_t)env_int("HJ_LDS_PAD_KB", 0, 0, 64) * 1024;
   const bool pairs = ctx->scene.has_pairs != 0, nt = ctx->scene.stream_state != 0;
-  if (!o.use_bvh) hipLaunchKernelGGL((hj::k_path_wavefront<false, false, false>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
-  else if (pairs && nt) hipLaunchKernelGGL((hj::k_path_wavefront<true, true, true>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
-  else if (pairs) hipLaunchKernelGGL((hj::k_path_wavefront<true, true, false>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
-  else if (nt) hipLaunchKernelGGL((hj::k_path_wavefront<true, false, true>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
-  else hipLaunchKernelGGL((hj::k_path_wavefront<true, false, false>), grid, blk, lds_pad, sl.stream, st, ctx->scene, o.max_bounces, o.rr_start);
+  const hj::DeviceScene scn = scene_for(ctx, o);
+  if (!o.use_bvh) hipLaunchKernelGGL((hj::k_path_wavefront<false, false, false>), grid, blk, lds_pad, sl.stream, st, scn, o.max_bounces, o.rr_start);
+  else if (pairs && nt) hipLaunchKernelGGL((hj::k_path_wavefront<true, true, true>), grid, blk, lds_pad, sl.stream, st, scn, o.max_bounces, o.rr_start);
+  else if (pairs) hipLaunchKernelGGL((hj::k_path_wavefront<true, true, false>), grid, blk, lds_pad, sl.stream, st, scn, o.max_bounces, o.rr_start);
+  else if (nt) hipLaunchKernelGGL((hj::k_path_wavefront<true, false, true>), grid, blk, lds_pad, sl.stream, st, scn, o.max_bounces, o.rr_start);
+  else hipLaunchKernelGGL((hj::k_path_wavefront<true, false, false>), grid, blk, lds_pad, sl.stream, st, scn, o.max_bounces, o.rr_start);
   tm.end(ev, sl.stream);
   if (reconstruct) {
     rc = enqueue_reconstruct(ctx, sl, other, st, nb, o, tm);
@@ -283,7 +294,7 @@ int render_batch_split(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::B
     else hipLaunchKernelGGL(hj::k_trace_closest<false>, grid, blk, 0, s, st, ctx->scene, parity);
     tm.end(ev, s);
     ev = tm.begin(EV_SHADE, s);
-    hipLaunchKernelGGL(hj::k_shade, grid, blk, 0, s, st, ctx->scene, parity, o.max_bounces, o.rr_start);
+    hipLaunchKernelGGL(hj::k_shade, grid, blk, 0, s, st, scene_for(ctx, o), parity, o.max_bounces, o.rr_start);
     tm.end(ev, s);
     ev = tm.begin(EV_SHADOW, s);
     if (bvh) hipLaunchKernelGGL(hj::k_trace_shadow<true>, grid, blk, 0, s, st, ctx->scene);
@@ -388,7 +399,7 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
     run.batch = (uint32_t)std::min<size_t>(batch_cap, std::max<size_t>(256, (std::max<size_t>((n + 1) / 2, std::min<size_t>(n, 4096)) + 63) / 64 * 64));
   run.batch = std::min<uint32_t>(run.batch, run.split ? 2048u : 32768u);   // (a sample index has 31 bits: 131 072 blocks at most)   // the split path keeps every sample of a batch in flight
   // Footprint: per batch slot 512 KB of samples per ImageBlock of the batch + num_wg x pool positions of
-  // path state (184 B each, 216 B with tinted dielectrics).  DEFAULTS that do not fit the device's free memory (other
+  // path state (185 B each, 217 B with tinted dielectrics).  DEFAULTS that do not fit the device's free memory (other
   // contexts on the GPU, the host application) shrink until they do: first the pool (down to 8192 positions), then the
   // batch; an explicit hj_render_opts::batch_blocks is taken as given and fails with HJ_ERR_NOMEM if it does not fit.
   static const size_t small_blocks = (size_t)env_int("HJ_WG_SMALL_BLOCKS", 12288, 0, 1 << 30);
@@ -410,7 +421,7 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
         const size_t slots_needed = std::max<size_t>(1, std::min<size_t>(ctx->num_slots, (n + batch - 1) / std::max<uint32_t>(batch, 1u)));
         const size_t per_wg = ((((size_t)batch * hj::kSlotsPerBlock + 63) / 64 + ctx->num_wg_eff - 1) / ctx->num_wg_eff) * 64;
         const size_t pool = std::min<size_t>(per_wg, pool_cap);
-        const size_t state = (size_t)ctx->num_wg_eff * pool * (ctx->scene.has_extinction ? 196u + 20u : 164u + 20u);
+        const size_t state = (size_t)ctx->num_wg_eff * pool * (ctx->scene.has_extinction ? 196u + 21u : 164u + 21u);
         return slots_needed * (state + (size_t)batch * hj::kSlotsPerBlock * 32u);
       };
       const size_t margin = (size_t)512 << 20;

@@ -1,6 +1,7 @@
 // hj_scene_upload: validation of the reference's scene arrays (src/main.rs:561-605) and their re-layout for the kernels
 // (kernels/hj_device.h: collapsed tree, pair nodes, hot-first node order, pre-gathered triangle and emitter records).
 #include "hj_internal.h"
+#include "light_grid.hpp"
 
 #pragma clang fp contract(off)
 
@@ -286,9 +287,10 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     // which a wave fetches new rays: without pair nodes 4 / 32 (6: -0.4 %, 8: -4 % on cbox); with them 7 / 24 on small trees
     // (the rays of the rotated, child-ordered trees are shorter: 5 / 32, the optimum before those passes, is 3 % slower on
     // cbox now; 6 or 8 steps, 20 or 28 lanes: -1 ... -2 %), 8 / 24 up to 600 000 records and 8 / 32 beyond (1 M triangles:
-    // 6 .. 10 steps the same, 24 lanes -1 %)
+    // 6 .. 10 steps the same, 24 lanes -1 %).  Round 5: with the light-shaft grid most of the short shadow rays are gone and the
+    // small trees want 6 steps (c2 +2.3 %, c3 +0.8 % against 7; 5: the same; 8: -1 %; refill at 16 / 32 lanes: -0 ... -2 %)
     const bool small_tree = M < 50000;
-    d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", pairs.empty() ? 4 : (small_tree ? 7 : 8), 1, 1 << 20);   // >= 1, or the walk would never advance
+    d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", pairs.empty() ? 4 : (small_tree ? 6 : 8), 1, 1 << 20);   // >= 1, or the walk would never advance
     d.refill_min = (uint32_t)env_int("HJ_REFILL_MIN", !pairs.empty() && M < 600000 ? 24 : (int)hj::kRefillMin, 1, 64);   // (20 k / 60 k / 200 k triangles: 24 lanes +2 / +3 / +1 %)
     // The walk adds 32 * index to the low word of the array's address without a carry (kernels/hj_walk.h): the
     // array must not cross a 4 GiB boundary.  Allocate twice the size and start at the boundary if it would.
@@ -359,6 +361,20 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
   HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->dielectric), s->num_dielectric, &d.dielectric));
   HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->emissive), s->num_emissive, &d.emissive));
   mark("other uploads");
+  // Light-shaft visibility grid (api/light_grid.cpp): which next-event shadow rays are unoccluded whatever happens.  HJ_LIGHT_GRID =
+  // cells per axis (default 64; 0: none).
+  {
+    const int res = env_int("HJ_LIGHT_GRID", 64, 0, 256);
+    LightGrid lg;
+    if (res >= 2 && build_light_grid(s, (uint32_t)res, lg)) {
+      HJ_UP(upload(ctx, lg.bits.data(), lg.bits.size(), &d.light_grid));
+      d.lg_res = lg.res;
+      for (int k = 0; k < 3; k++) { d.lg_lo[k] = lg.lo[k]; d.lg_inv[k] = lg.inv[k]; }
+      if (timing) std::fprintf(stderr, "hj_scene_upload: light grid %u^3: %zu cells hold a surface, %zu a planar one, %zu (cell, emitter) pairs proven free\n",
+                               lg.res, lg.cells_surface, lg.cells_planar, lg.pairs_clear);
+    }
+  }
+  mark("light-shaft grid");
 #undef HJ_UP
   ctx->scene = d;
   ctx->have_scene = true;

@@ -66,6 +66,11 @@ struct DeviceScene {
   uint32_t stream_state;        // large tree: path records and samples bypass the caches (non-temporal accesses)
   hj_camera camera;
   float tan_half_fov;           // (float)tan(radians(fov/2)) evaluated in double on the host
+  // Light-shaft visibility grid (api/light_grid.cpp): bit e of cell (x, y, z) says that EVERY next-event shadow ray from a hit
+  // point in that cell to emitter e is unoccluded - the shade stage then adds the sample at once instead of queueing a ray.
+  const uint8_t* light_grid;    // lg_res^3 bytes, x fastest; null: no grid
+  uint32_t lg_res;
+  float lg_lo[3], lg_inv[3];    // cell index along axis k = (int)((p[k] - lg_lo[k]) * lg_inv[k])
 };
 
 // One wavefront batch = the samples of up to 4096 ImageBlocks.  Two index spaces:
@@ -93,6 +98,8 @@ struct BatchState {
   float4* ext[2];       // current extinction (only touched if scene.has_extinction)
   // per position of the current round
   float4* hit;          // (t, objectID bits, u, v) of the raw hit
+  uint8_t* hit_tag;     // material tag of the hit (0xFF: miss), written by the first pass of the hit compaction for its second
+                        // pass: 1 byte per ray instead of the 16-byte record + the material word a second time
   uint32_t* q_hit;      // [kNumTags][num_wg][pool] positions of the hits, binned by material tag, in queue order
   // NEE shadow rays produced by shade, walked in the next round (self-contained: the path may be over by then)
   float4* sh_o;         // origin.xyz

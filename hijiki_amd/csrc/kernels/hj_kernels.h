@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
   uint32_t total_closest = 0, total_shadow = 0, total_hits = 0, total_unocc = 0;   // (thread 0's copies are published)
   if (groups_left != 0) {
     uint32_t k_next = 0;                     // next group of this workgroup's sample sequence
-    if (threadIdx.x == 0) { sh.n_ray[0] = 0; sh.n_ray[1] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; sh.cam_first = 0xFFFFFFFFu; sh.cam_k0 = 0; sh.n_cam_dead = 0; }
+    if (threadIdx.x == 0) { sh.n_ray[0] = 0; sh.n_ray[1] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; sh.n_direct = 0; sh.cam_first = 0xFFFFFFFFu; sh.cam_k0 = 0; sh.n_cam_dead = 0; }
     if (USE_BVH) load_hot_nodes(sc, sh);
     uint32_t waves = blockDim.x >> 6;
     wg_sync(waves);
@@ -100,11 +100,14 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
         groups_left -= ngen;
       }
       const uint32_t n = IMPLICIT ? n0 + 64u * ngen : n0 + uni(sh.n_gen), ns = uni(sh.n_shadow);
+      // next-event samples of the previous round's shade that the light-shaft grid answered (intersectScene(shadowRay) == false
+      // without a walk): shadow rays of the statistics all the same
+      { const uint32_t nd = uni(sh.n_direct); total_shadow += nd; total_unocc += nd; }
       if (n + ns == 0) {
         if (groups_left == 0) break;
         // every sample of the new groups lay outside its block: next groups.  The other parity's path count is the one the
         // round before last left behind (only a round that reaches the reset below clears it): it must not be found again.
-        if (threadIdx.x == 0) sh.n_ray[parity ^ 1u] = 0;
+        if (threadIdx.x == 0) { sh.n_ray[parity ^ 1u] = 0; sh.n_direct = 0; }   // (n_direct: counted above, by thread 0, whose totals are the ones published)
         wg_sync(waves);
         continue;
       }
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
 #endif
       wg_sync(waves);                        // everyone has read the counts before they are reset
       if (threadIdx.x == 0) {
-        sh.head = 0; sh.head_cam = 0; sh.n_ray[parity ^ 1u] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0;
+        sh.head = 0; sh.head_cam = 0; sh.n_ray[parity ^ 1u] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; sh.n_direct = 0;
         sh.cam_first = (IMPLICIT && ngen != 0) ? n0 : 0xFFFFFFFFu; sh.cam_k0 = k0; sh.n_cam_dead = 0;
       }
       if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(BatchState st, DeviceSc
                                                          uint32_t max_bounces, uint32_t rr_start) {
   __shared__ WgShared sh;
   const uint32_t g = blockIdx.x;
-  if (threadIdx.x == 0) { sh.n_ray[parity ^ 1u] = 0; sh.n_shadow = 0; sh.cam_first = 0xFFFFFFFFu; sh.cam_k0 = 0; }   // (every camera path has records here)
+  if (threadIdx.x == 0) { sh.n_ray[parity ^ 1u] = 0; sh.n_shadow = 0; sh.n_direct = 0; sh.cam_first = 0xFFFFFFFFu; sh.cam_k0 = 0; }   // (every camera path has records here)
   if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = st.cnt_hit[g * kNumTags + threadIdx.x];
   __syncthreads();
   stage_shade<false>(st, sc, g, parity, max_bounces, rr_start, sh, blockDim.x >> 6);
@@ -254,7 +257,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(BatchState st, DeviceSc
   if (threadIdx.x == 0) {
     st.cnt_ray[parity ^ 1u][g] = sh.n_ray[parity ^ 1u];
     st.cnt_shadow[g] = sh.n_shadow;
-    st.acc_shadow[g] += sh.n_shadow;
+    st.acc_shadow[g] += sh.n_shadow + sh.n_direct;
+    st.acc_unoccluded[g] += sh.n_direct;
   }
 }
 

@@ -50,14 +50,15 @@ struct SRec { v3 p, n; float pdf; };
 HJ_DEV v3 ld3(const float* p) { return V(p[0], p[1], p[2]); }
 
 // reference shader/scene.glsl:44-89 + shapes/*: sample*.  Always 3 draws.
-HJ_DEV v3 sample_emitter(const DeviceScene& sc, v3 ref, uint32_t& rng, v3& sh_dir, float& sh_tmax) {
+// `e` = the emitter that was sampled.
+HJ_DEV v3 sample_emitter(const DeviceScene& sc, v3 ref, uint32_t& rng, v3& sh_dir, float& sh_tmax, uint32_t& e) {
   float xi = rng_float(rng);
+  e = 0;
   if (sc.num_emitters == 0) {   // reference reads emitters[0] out of bounds; defined here as "no light"
     rng_uint(rng); rng_uint(rng);
     sh_dir = V(0, 0, 0); sh_tmax = 0.0f;
     return V(0, 0, 0);
   }
-  uint32_t e = 0;
   for (uint32_t i = 0; i < sc.num_emitters; i++) {
     xi -= __uint_as_float(__float_as_uint(sc.emit_rec[kEmitRecF4 * i].x));   // emitters[i].pdf
     if (xi < 0.0f) { e = i; break; }
@@ -100,6 +101,17 @@ HJ_DEV v3 sample_emitter(const DeviceScene& sc, v3 ref, uint32_t& rng, v3& sh_di
   if (cosT < 0.0f) return V(0, 0, 0);
   const float pdf = (((em_pdf * sr.pdf) * dist) * dist) / cosT;
   return divs(power, pdf);
+}
+
+// Light-shaft visibility grid (api/light_grid.cpp): true when the grid PROVES that the shadow ray from hit point p to the sampled
+// point of emitter e is unoccluded (whatever tree is walked): no ray needs to be traced for this sample.
+HJ_DEV bool shadow_ray_proven_free(const DeviceScene& sc, v3 p, uint32_t e) {
+  if (sc.light_grid == nullptr || e >= 8u) return false;
+  const float fx = (p.x - sc.lg_lo[0]) * sc.lg_inv[0], fy = (p.y - sc.lg_lo[1]) * sc.lg_inv[1], fz = (p.z - sc.lg_lo[2]) * sc.lg_inv[2];
+  const float r = (float)sc.lg_res;
+  if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < r && fy < r && fz < r)) return false;   // (NaN: false)
+  const uint32_t cell = ((uint32_t)fz * sc.lg_res + (uint32_t)fy) * sc.lg_res + (uint32_t)fx;
+  return ((sc.light_grid[cell] >> e) & 1u) != 0u;
 }
 
 // reference shader/materials/diffusecb.glsl:6-13

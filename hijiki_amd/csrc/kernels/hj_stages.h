@@ -27,6 +27,7 @@ struct WgShared {                 // LDS of a path workgroup (16.5 KB)
   uint32_t n_gen;                 // new camera paths the current top-up has appended behind them
   uint32_t n_shadow;              // shadow records
   uint32_t n_unocc;               // statistics: unoccluded shadow rays of this round
+  uint32_t n_direct;              // next-event samples of this round's shade that the light-shaft grid proved unoccluded: added at once, no ray
   // IMPLICIT camera paths of the current round (kernels with the packet stage): positions [cam_first, n) of the closest-hit
   // queue are the samples of groups cam_k0, cam_k0 + 1, ... of the workgroup's sequence, 64 positions per group, lane = sample:
   // nothing of them is in the path arrays, every stage rebuilds what it needs from the sample index (camera_ray)
@@ -262,6 +263,9 @@ HJ_DEV void stage_camera_packets(const BatchState& st, const DeviceScene& sc, ui
   const uint32_t nn = sc.num_nodes, nhot = sc.num_hot;
   constexpr uint32_t kAwake = 0xFFFFFFFFu, kNever = 0xFFFFFFFEu;
   uint32_t dead = 0;                         // wave-uniform: positions without a sample
+#ifdef HJ_WALK_STATS
+  unsigned long long pk_steps = 0, pk_lanes = 0, pk_cold = 0;   // (wave-uniform) node steps of the packets, live lanes in them, steps on nodes outside the LDS copy
+#endif
   for (;;) {
     const uint32_t c = lds_fetch_chunk(&sh.head_cam);
     if (c >= 64u * chunks) break;
@@ -300,6 +304,9 @@ HJ_DEV void stage_camera_packets(const BatchState& st, const DeviceScene& sc, ui
       const uint32_t a = __float_as_uint(n0.w), ex = __float_as_uint(n1.w);
       if (wake == cur) wake = kAwake;
       const bool live = wake == kAwake;
+#ifdef HJ_WALK_STATS
+      pk_steps += 1; pk_lanes += (unsigned long long)__popcll(__ballot(live)); pk_cold += cur >= nhot ? 1u : 0u;
+#endif
       uint32_t nxt = ex;
       if ((a & kInnerFlag) == 0u) {          // a leaf: its shape is tested by every lane that got here (scene.glsl:105-119)
         if (live) {
@@ -343,6 +350,11 @@ HJ_DEV void stage_camera_packets(const BatchState& st, const DeviceScene& sc, ui
     stp<NT>(st.hit, pos, make_float4(h.t, __int_as_float(h.id), h.u, h.v));
   }
   if (lane == 0 && dead != 0) atomicAdd(&sh.n_cam_dead, dead);
+#ifdef HJ_WALK_STATS
+  // [8] wave-steps of the camera packets, [9] live lanes in them (beside [1], [2] of the merged walk); their cold steps are scalar
+  // loads, not lane fetches: counted per wave in g_round_stats[30]
+  if (lane == 0 && pk_steps != 0) { atomicAdd(&g_walk_stats[8], pk_steps); atomicAdd(&g_walk_stats[9], pk_lanes); atomicAdd(&g_round_stats[30], pk_cold); }
+#endif
 }
 
 // Ordered compaction of the hits of this workgroup's n closest-hit rays by material tag (divergent-BSDF sort): every
@@ -375,6 +387,15 @@ HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uin
 #pragma unroll
     for (uint32_t j = 0; j < R; j++) tag[j] = id[j] >= 0 ? sc.materials[id[j]] >> HJ_MATERIAL_TAG_SHIFT : 0xFFu;
   };
+  // second pass: the tags the first pass left in hit_tag (a byte per ray: 64 B per row instead of 1 KB + the material gather)
+  uint8_t* __restrict__ htag = st.hit_tag + g * st.pool;
+  auto tags4_again = [&](uint32_t row, uint32_t tag[R]) {
+#pragma unroll
+    for (uint32_t j = 0; j < R; j++) {
+      const uint32_t i = (row + j) * 64u + lane;
+      tag[j] = (row + j < r1 && i < n) ? (uint32_t)htag[i] : 0xFFu;
+    }
+  };
   uint32_t cnt[kNumTags];
 #pragma unroll
   for (uint32_t k = 0; k < kNumTags; k++) cnt[k] = 0;
@@ -383,9 +404,12 @@ HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uin
     uint32_t tag[R];
     tags4(row, tag);
 #pragma unroll
-    for (uint32_t j = 0; j < R; j++)
+    for (uint32_t j = 0; j < R; j++) {
+      const uint32_t i = (row + j) * 64u + lane;
+      if (row + j < r1 && i < n) htag[i] = (uint8_t)tag[j];
 #pragma unroll
       for (uint32_t k = 0; k < kNumTags; k++) cnt[k] += (uint32_t)__popcll(__ballot(tag[j] == k));
+    }
   }
   if (lane == 0) {
 #pragma unroll
@@ -401,7 +425,7 @@ HJ_DEV void compact_hits_by_tag(const BatchState& st, const DeviceScene& sc, uin
 #pragma unroll 1
   for (uint32_t row = r0; row < r1; row += R) {
     uint32_t tag[R];
-    tags4(row, tag);
+    tags4_again(row, tag);
 #pragma unroll
     for (uint32_t j = 0; j < R; j++) {
       const uint32_t i = (row + j) * 64u + lane;
@@ -439,7 +463,7 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
     for (uint32_t base = wave * 64u; base < n; base += waves * 64u) {
     const uint32_t i = base + lane;
     const bool valid = i < n;
-    bool alive = false, want_shadow = false;
+    bool alive = false, want_shadow = false, add_now = false;
     v3 T = V(0, 0, 0), wo = V(0, 0, 0), ext = V(0, 0, 0), sdir = V(0, 0, 0), scol = V(0, 0, 0);
     float stmax = 0.f;
     Its its; its.p = V(0, 0, 0);
@@ -500,12 +524,16 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
         case HJ_MAT_DIFFUSE:
         case HJ_MAT_DIFFUSECBOARD: {
           const v3 color = (tag == HJ_MAT_DIFFUSE) ? xyz(sc.diffuse[midx]) : checkerboard(sc, midx, its.u, its.v);
-          const v3 imp = sample_emitter(sc, its.p, rng, sdir, stmax);                      // render.glsl:117-126
+          uint32_t em = 0;
+          const v3 imp = sample_emitter(sc, its.p, rng, sdir, stmax, em);                  // render.glsl:117-126
           if (len3(imp) > kEps && dot3(sdir, its.n) > 0.0f) {
             const float cs = dot3(its.n, sdir);
             const v3 f = (color * cs) * kInvPi;                                            // material.glsl:18-30
             scol = (T * f) * imp;
-            want_shadow = true;
+            // intersectScene(shadowRay) is known to be false for this cell and emitter (api/light_grid.cpp): the sample is
+            // added here, where render.glsl:122-124 adds it, instead of after a walk in the next round
+            add_now = shadow_ray_proven_free(sc, its.p, em);
+            want_shadow = !add_now;
           }
           const v3 l = rand_cos_hemisphere(rng);                                           // material.glsl:37-46
           wo = (its.ft * l.x + its.fb * l.y) + its.n * l.z;
@@ -565,6 +593,17 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
       stp<NT>(st.ray_d[np], pos, make_float4(wo.x, wo.y, wo.z, __uint_as_float(rng)));
       stp<NT>(st.thr[np], pos, make_float4(T.x, T.y, T.z, __uint_as_float(flags_out)));
       if (sc.has_extinction) stp<NT>(st.ext[np], pos, make_float4(ext.x, ext.y, ext.z, 0.f));
+    }
+    {
+      const unsigned long long direct = __ballot(add_now);
+      if (direct != 0) {
+        if (add_now) {
+          float4 sv = ldp<NT>(st.smp_rgb, smp);
+          sv.x += scol.x; sv.y += scol.y; sv.z += scol.z;
+          stp<NT>(st.smp_rgb, smp, sv);
+        }
+        if (lane == 0) atomicAdd(&sh.n_direct, (uint32_t)__popcll(direct));
+      }
     }
     const uint32_t qs = lds_push(&sh.n_shadow, want_shadow);
     if (want_shadow) {

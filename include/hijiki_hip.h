@@ -157,6 +157,7 @@ typedef struct hj_render_opts {
 #define HJ_RENDER_SPLIT_KERNELS 2u  /* diagnostic: one launch per stage per bounce instead of the fused kernel */
 #define HJ_RENDER_STATIC_DEAL 4u    /* hj_render_frame, world > 1: keep all passes of a block on one rank          */
 #define HJ_RENDER_NO_DRAIN 8u       /* hj_render_frame: return when the frame's batches are ENQUEUED (hj_pipeline_wait) */
+#define HJ_RENDER_NO_LIGHT_GRID 16u /* walk every shadow ray, also those the light-shaft grid proves unoccluded (same image) */
 
 /* Per-render statistics (device counters; all in units of events). */
 typedef struct hj_render_stats {

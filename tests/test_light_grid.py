@@ -1,0 +1,177 @@
+"""The light-shaft visibility grid (hijiki_amd/csrc/api/light_grid.cpp) against the ORACLE, on the CPU.
+
+The grid claims, per (cell, emitter): every next-event shadow ray from a hit point in this cell to a sampled point of this
+emitter is unoccluded - so the shade stage may add the sample without tracing the ray (same image, fewer rays).  Here the
+claim is attacked with shadow rays built exactly as shader/scene.glsl:66-88 builds them (origin = a point of a planar shape,
+moved off its plane by what float rounding can do to a computed hit point; target = a point of the emitter incl. its corners and
+edges; tMin = 2 eps, tMax = distance - eps) and traced by the oracle's closest-hit walk: not one of them may hit anything.
+hj_debug_light_grid is pure host code: no GPU is needed.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import scenes
+from hijiki_amd import abi, device, host
+
+RES = 64
+
+
+def build_grid(cs, res=RES):
+    L = C.CDLL(device.HIP_LIB_PATH)
+    L.hj_debug_light_grid.argtypes = [C.POINTER(abi.SceneDesc), C.c_uint32, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                      C.POINTER(C.c_uint64)]
+    bits = np.zeros(res ** 3, np.uint8)
+    lo, inv, st = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_uint64 * 3)()
+    got = L.hj_debug_light_grid(C.byref(cs.desc), res, bits.ctypes.data, lo, inv, st)
+    return got, bits, np.array(list(lo), np.float32), np.array(list(inv), np.float32), [int(x) for x in st]
+
+
+def scene_arrays(cs):
+    d = cs.desc
+    tri = np.ctypeslib.as_array(d.triangles, shape=(d.num_triangles,)).view(np.uint32).reshape(-1, 3) if d.num_triangles else np.zeros((0, 3), np.uint32)
+    vert = np.ctypeslib.as_array(d.vertices, shape=(d.num_vertices,)).view(np.float32).reshape(-1, 8) if d.num_vertices else np.zeros((0, 8), np.float32)
+    quad = np.ctypeslib.as_array(d.quads, shape=(d.num_quads,)).view(np.float32).reshape(-1, 12) if d.num_quads else np.zeros((0, 12), np.float32)
+    em = np.ctypeslib.as_array(d.emitters, shape=(d.num_emitters,)).view(np.uint32).reshape(-1, 4)[:, 0].astype(np.int64) if d.num_emitters else np.zeros(0, np.int64)
+    return tri, vert[:, 0:3], quad, em, int(d.num_spheres), int(d.num_quads)
+
+
+def planar_points(cs, rng, n):
+    """n points on triangles (picked by area: the walls of a box are a dozen of thousands of triangles) and n / 4 on quads, with
+    the shape's unit normal."""
+    tri, pos, quad, _, ns, nq = scene_arrays(cs)
+    pts, nrm = [], []
+    if len(tri):
+        area = np.linalg.norm(np.cross(pos[tri[:, 1]] - pos[tri[:, 0]], pos[tri[:, 2]] - pos[tri[:, 0]]), axis=1).astype(np.float64)
+        t = tri[rng.choice(len(tri), n, p=area / area.sum())] if area.sum() > 0 else tri[rng.integers(0, len(tri), n)]
+        a, b, c = pos[t[:, 0]], pos[t[:, 1]], pos[t[:, 2]]
+        u, v = rng.uniform(size=(2, n))
+        f = u + v > 1
+        u, v = np.where(f, 1 - u, u), np.where(f, 1 - v, v)
+        pts.append(a + (b - a) * u[:, None] + (c - a) * v[:, None])
+        nrm.append(np.cross(b - a, c - a))
+    if len(quad):
+        q = quad[rng.integers(0, len(quad), max(1, n // 4))]
+        o, e1, e2 = q[:, 0:3], q[:, 4:7], q[:, 8:11]
+        u, v = rng.uniform(size=(2, len(q)))
+        pts.append(o + e1 * u[:, None] + e2 * v[:, None])
+        nrm.append(np.cross(e1, e2))
+    p, m = np.concatenate(pts), np.concatenate(nrm)
+    ln = np.linalg.norm(m, axis=1)
+    keep = ln > 0
+    return p[keep], m[keep] / ln[keep, None]
+
+
+def emitter_points(cs, e_shape, rng, n):
+    """Points of emitter shape `e_shape` (a triangle or quad): random ones, its corners, points on its edges."""
+    tri, pos, quad, _, ns, nq = scene_arrays(cs)
+    if e_shape < ns:
+        return None
+    if e_shape < ns + nq:
+        q = quad[e_shape - ns]
+        o, e1, e2 = q[0:3], q[4:7], q[8:11]
+        u, v = rng.uniform(size=(2, n))
+    else:
+        t = tri[e_shape - ns - nq]
+        o, e1, e2 = pos[t[0]], pos[t[1]] - pos[t[0]], pos[t[2]] - pos[t[0]]
+        u, v = rng.uniform(size=(2, n))
+        f = u + v > 1
+        u, v = np.where(f, 1 - v, u), v            # the reference's randBarycentric: (1 - v, v) when u + v > 1 (rand.glsl:45-48)
+    k = n // 8
+    u[:k], v[:k] = rng.integers(0, 2, k), 0.0      # corners and edges
+    v[k:2 * k] = 0.0
+    if e_shape >= ns + nq:
+        u[:k] = np.minimum(u[:k], 1 - v[:k])
+    return (o + e1 * u[:, None] + e2 * v[:, None]).astype(np.float32)
+
+
+def attack(cs, oracle, rng, n=60000, res=RES):
+    """Number of shadow rays tried from cells whose bit is set, and how many the oracle found occluded (must be 0)."""
+    got, bits, lo, inv, st = build_grid(cs, res)
+    if got == 0:
+        return 0, 0, st
+    _, _, _, em, _, _ = scene_arrays(cs)
+    p, nrm = planar_points(cs, rng, n)
+    # a computed hit point is not exactly on its shape: move it by up to +-1e-5 along the normal (the grid allows 2e-6 x scale)
+    p = (p + nrm * rng.uniform(-1e-5, 1e-5, (len(p), 1))).astype(np.float32)
+    f = (p - lo) * inv
+    inr = ((f >= 0) & (f < res)).all(1)
+    ci = np.clip(f.astype(np.int64), 0, res - 1)
+    cell = (ci[:, 2] * res + ci[:, 1]) * res + ci[:, 0]
+    tried = bad = 0
+    for e, shape in enumerate(em[:8]):
+        sel = inr & (((bits[cell] >> e) & 1) != 0)
+        if not sel.any():
+            continue
+        y = emitter_points(cs, int(shape), rng, int(sel.sum()))
+        assert y is not None, "a bit is set for a sphere emitter"
+        o = p[sel]
+        d = y - o
+        dist = np.sqrt((d.astype(np.float32) ** 2).sum(1, dtype=np.float32)).astype(np.float32)
+        d = (d / dist[:, None]).astype(np.float32)
+        rays = np.zeros((len(o), 8), np.float32)
+        rays[:, 0:3], rays[:, 3:6], rays[:, 6], rays[:, 7] = o, d, np.float32(2e-4), dist - np.float32(1e-4)     # scene.glsl:85
+        ids, _, _, _ = oracle.intersect(cs, rays, use_bvh=True)
+        tried += len(rays)
+        bad += int((ids >= 0).sum())
+    return tried, bad, st
+
+
+def test_cbox_most_wall_cells_are_proven_and_no_proven_ray_is_occluded(oracle, cbox):
+    rng = np.random.default_rng(1)
+    tried, bad, st = attack(cbox, oracle, rng, n=200000)
+    surface, planar, clear = st
+    assert planar > 0.6 * surface and clear > 0.5 * 2 * planar        # two emitter triangles; measured: 0.79, 0.66
+    assert tried > 50000 and bad == 0
+
+
+def test_spheres_mesh_and_rich_scenes(oracle, cbox_spheres):
+    rng = np.random.default_rng(2)
+    for cs in (cbox_spheres, host.Scene.synthetic(host.SYNTH_CBOX_MESH, mesh_triangles=20000).compile(), scenes.rich_scene()):
+        tried, bad, st = attack(cs, oracle, rng)
+        assert bad == 0, (tried, bad, st)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_scenes(oracle, seed):
+    rng = np.random.default_rng(10 + seed)
+    tried, bad, st = attack(scenes.random_scene(seed), oracle, rng, n=40000)
+    assert bad == 0, (tried, bad, st)
+
+
+def test_an_occluder_between_floor_and_light_clears_the_cells_below_it():
+    """A diffuse quad floating under a quad light: floor cells in its shadow and penumbra must not be proven; floor cells far
+    from it are; cells on the occluder's lit side are."""
+    s = host.Scene()
+    s.set_camera((0, 1, 4), (0, 0, 0, 1), 40.0)
+    white, lamp = s.add_diffuse((0.7, 0.7, 0.7)), s.add_emissive((10, 10, 10))
+    s.add_quad((-2, 0, 2), (4, 0, 0), (0, 0, -4), white)                       # floor y = 0
+    s.add_quad((-0.25, 2, -0.25), (0.5, 0, 0), (0, 0, 0.5), lamp)              # light y = 2
+    s.add_quad((-0.5, 1, 0.5), (1, 0, 0), (0, 0, -1), white)                   # occluder y = 1, above the floor's centre
+    cs = s.compile()
+    got, bits, lo, inv, st = build_grid(cs)
+    assert got == RES
+
+    def bit(p):
+        f = ((np.array(p, np.float32) - lo) * inv).astype(int)
+        return int(bits[(f[2] * RES + f[1]) * RES + f[0]]) & 1
+
+    assert bit((0.0, 0.0, 0.0)) == 0 and bit((0.3, 0.0, -0.3)) == 0 and bit((0.7, 0.0, 0.0)) == 0     # umbra, penumbra
+    assert bit((1.8, 0.0, 1.8)) == 1 and bit((-1.7, 0.0, 0.4)) == 1                                   # far from the occluder
+    assert bit((0.0, 1.0, 0.0)) == 1                                                                   # on top of the occluder
+
+
+def test_no_grid_without_planar_emitters_or_at_huge_scale():
+    s = host.Scene()
+    s.set_camera((0, 0, 5), (0, 0, 0, 1), 40.0)
+    white, lamp = s.add_diffuse((0.7, 0.7, 0.7)), s.add_emissive((5, 5, 5))
+    s.add_quad((-2, -1, 2), (4, 0, 0), (0, 0, -4), white)
+    s.add_sphere((0, 1, 0), 0.3, lamp)                                         # a sphere light: nothing can be proven
+    assert build_grid(s.compile())[0] == 0
+    s = host.Scene()
+    s.set_camera((0, 1e4, 4e4), (0, 0, 0, 1), 40.0)
+    white, lamp = s.add_diffuse((0.7, 0.7, 0.7)), s.add_emissive((5, 5, 5))
+    s.add_quad((-2e4, 0, 2e4), (4e4, 0, 0), (0, 0, -4e4), white)               # coordinates where eps = 1e-4 is below float resolution
+    s.add_quad((-2e3, 2e4, -2e3), (4e3, 0, 0), (0, 0, 4e3), lamp)
+    assert build_grid(s.compile())[0] == 0

@@ -34,6 +34,8 @@ rays = st["closest_rays"] + st["shadow_rays"]
 steps = o[1] + o[8]
 print(f"rays {rays/1e6:.1f} M; outer iterations {o[0]/1e6:.2f} M, active lanes at their start {o[7]/max(1,o[0]):.1f}")
 print(f"box wave-steps {steps/1e6:.2f} M with {(o[2]+o[9])/max(1,steps):.1f} lanes  ({(o[2]+o[9])/rays:.1f} lane-steps per ray, {o[14]/rays:.2f} of them on nodes outside the LDS copy; {steps/max(1,o[0]):.2f} wave-steps per outer iteration)")
+print(f"  of these, merged walk (continuing + shadow rays): {o[1]/1e6:.2f} M wave-steps with {o[2]/max(1,o[1]):.1f} lanes; camera packets (scalar-cache walk, "
+      f"one node per wave-step): {o[8]/1e6:.2f} M wave-steps with {o[9]/max(1,o[8]):.1f} live lanes = {o[9]/max(1,st['paths']):.1f} lane-steps per camera ray")
 print(f"leaf phases {o[3]/1e6:.2f} M with {o[4]/max(1,o[3]):.1f} lanes  ({o[4]/rays:.2f} leaf stops and {o[15]/rays:.2f} shape records per ray; in {100*o[3]/max(1,o[0]):.0f} % of outer iterations)")
 tot = max(1, o[13])
 print(f"wave cycles in the walk: service {100*o[10]/tot:.1f} %, box steps {100*o[11]/tot:.1f} %, leaf tests {100*o[12]/tot:.1f} %; per outer iteration {o[13]/max(1,o[0]):.0f} cycles; per box wave-step {o[11]/max(1,steps):.0f}; per leaf phase {o[12]/max(1,o[3]):.0f}; per refill {o[10]/max(1,o[5]):.0f}")
@@ -63,4 +65,7 @@ if js:
                "lanes_per_leaf_phase": o[4] / max(1, o[3]), "active_lanes": o[7] / max(1, o[0]),
                "cycle_share": {"service": o[10] / tot, "box": o[11] / tot, "leaf": o[12] / tot},
                "stage_share": {n: v / stage_tot for n, v in zip(("top_up", "walk", "compaction", "shade", "bookkeeping"), stage)},
+               "merged_box_wave_steps": o[1], "merged_box_lane_steps": o[2], "packet_wave_steps": o[8], "packet_lane_steps": o[9],
+               "packet_cold_wave_steps": rs[30], "leaf_phases": o[3], "outer_iterations": o[0],
+               "build": "the shipped kernel (camera packets on) compiled with -DHJ_WALK_STATS: counters and clock reads added, nothing else changed",
                "rounds": hist}, open(js, "w"), indent=1)
