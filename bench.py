@@ -45,6 +45,11 @@ if ROOT not in sys.path:
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "8")
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (about 6.3 TB/s achievable)
+# the other roofs the walk's bytes meet (same guide): every CU streaming ds_read_b128 (section LDS, "Aggregate with every CU
+# streaming"), rows gathered from an XCD's L2 (section "Indexed rows: gather into LDS": 16.8-18.8 TB/s), and the VALU lanes
+# (256 CUs x 64 lanes per clock; the clock the chip holds comes out of GRBM_GUI_ACTIVE, section "DVFS give-back")
+LDS_PEAK_GBS = 150000.0
+L2_GATHER_PEAK_GBS = 17800.0
 
 CONFIGS = {
     "c2": dict(kind="cbox", short="cbox", tris=0, size=1024, spp=512,
@@ -95,6 +100,16 @@ def coalesced_read_bytes(st):
     first_hits = P * (Hh / C) if C else 0.0
     return (C - P) * (2 * 16) + C * (2 * 16) + Hh * 16 + max(0.0, Hh - first_hits) * (3 * 16) + S * (3 * 16) \
         + P * (2 * 16 * (20 * 20) / (16 * 16))
+
+
+def valu_probe(config):
+    """Newest profiles/rNN_<config>_valu_probe.json: a same-box A/B of the shipped kernel against a build with extra VALU
+    instructions in every box step (tools/valu_probe.sh)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{config}_valu_probe.json")))
+    try:
+        return json.load(open(files[-1])) if files else None
+    except (OSError, ValueError):
+        return None
 
 
 def roofline_inputs(config):
@@ -151,6 +166,52 @@ def reference_bytes_per_path(c):
     walk = 32 * (c["nodes"] + c["shadow_nodes"]) + 108 * (c["tri_tests"] + c["shadow_tri_tests"]) \
         + 16 * (c["sphere_tests"] + c["shadow_sphere_tests"]) + 48 * (c["quad_tests"] + c["shadow_quad_tests"])
     return round((walk + 128 * c["hits"] + 144 * c["nee_evals"]) / P + 128, 1)
+
+
+def survey_8d_counters(config):
+    """The oracle's work counters of the WHOLE frame of `config` (tests/golden/full_size_<config>.json: data written by
+    tests/golden/make_full_size.py in the build container; c5 has its 8-pass prefix).  None when the fixture is missing."""
+    name = {"c5": "c5p"}.get(config, config)
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", f"full_size_{name}.json")) as f:
+            return json.load(f)["counters"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def roofs_block(inputs, agg, busy_s, traffic_gbs):
+    """The roofs the kernel's bytes and instructions actually meet, each as achieved / peak / frac (VERDICT r4 #2b).  Per-ray
+    figures come from the walk statistics of the profiled kernel (profiles/: `walk`), scaled by THIS run's ray count and
+    exclusive kernel time; the VALU fractions come from the PMC counters alone (instructions and lane-instructions over
+    GRBM_GUI_ACTIVE cycles: no clock assumed)."""
+    if not inputs:
+        return None
+    rays = agg["closest_rays"] + agg["shadow_rays"]
+    w = inputs.get("walk") or {}
+    c = inputs.get("counters") or {}
+    lim = inputs.get("limiter") or {}
+    out = {"hbm": None if traffic_gbs is None else {"achieved": traffic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                     "frac": round(traffic_gbs / HBM_PEAK_GBS, 4), "what": "PMC traffic (FETCH_SIZE corrected + WRITE_SIZE)"}}
+    if w.get("box_lane_steps_per_ray") is not None and busy_s > 0:
+        hot = max(0.0, w["box_lane_steps_per_ray"] - w.get("cold_node_steps_per_ray", 0.0))
+        lds = 32.0 * hot * rays / busy_s / 1e9
+        out["lds"] = {"achieved": round(lds, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBS, 4),
+                      "what": f"32 B x {hot:.2f} box steps per ray on the LDS copy of the 512 hottest nodes"}
+        gather = 32.0 * w.get("cold_node_steps_per_ray", 0.0) + 48.0 * w.get("triangle_records_per_ray", 0.0)
+        l2 = gather * rays / busy_s / 1e9
+        out["l2_gather"] = {"achieved": round(l2, 1), "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s", "frac": round(l2 / L2_GATHER_PEAK_GBS, 4),
+                            "what": f"{gather:.0f} B per ray of node and shape records gathered through the L2 (hit rate {lim.get('l2_hit_rate')})"}
+    if c.get("SQ_THREAD_CYCLES_VALU") and c.get("GRBM_GUI_ACTIVE") and inputs.get("paths_per_frame"):
+        lane_ops = c["SQ_THREAD_CYCLES_VALU"] * agg["paths"] / inputs["paths_per_frame"]          # scaled to this run's frames
+        clock = None
+        if inputs.get("pmc_kernel_seconds"):
+            clock = c["GRBM_GUI_ACTIVE"] / 8.0 / inputs["pmc_kernel_seconds"]
+        frac = c["SQ_THREAD_CYCLES_VALU"] / (256.0 * 64.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
+        out["valu_lanes"] = {"achieved": round(lane_ops / busy_s / 1e12, 2) if busy_s > 0 else None,
+                             "peak": None if clock is None else round(256 * 64 * clock / 1e12, 2), "unit": "T lane-instructions/s",
+                             "frac": round(frac, 4), "effective_clock_ghz": None if clock is None else round(clock / 1e9, 3),
+                             "what": "SQ_THREAD_CYCLES_VALU over 256 CUs x 64 lanes x GRBM_GUI_ACTIVE / 8 (= VALU issue share x lane fill)"}
+    return out
 
 
 def main_inproc(args, cfg):
@@ -245,8 +306,20 @@ def roofline_block(config, agg, elapsed, steps, world, standard, oracle_counters
     paths = max(1, agg["paths"])
     compulsory = 128.0 + scene_bytes / paths
     traffic_per_path = None if traffic_per_launch is None else traffic_per_launch * launches / paths
-    limited_by, shares = limited_by_counters(lim, None if traffic is None else traffic / HBM_PEAK_GBS)
+    probe = valu_probe(config) if inputs else None
+    limited_by, shares = limited_by_counters(lim, None if traffic is None else traffic / HBM_PEAK_GBS, probe)
+    # SURVEY 8(d) literally: B_path of the REFERENCE algorithm (oracle counters of the whole frame) x paths/s over the HBM peak.
+    # Above 1 on every configuration: those bytes are node and triangle fetches that the LDS copy, the scalar cache and the
+    # L1 / L2 serve - HBM is not this kernel's roof (`roofs` has the ones the bytes do meet).
+    sc_ = oracle_counters or survey_8d_counters(config)
+    b8d = None if sc_ is None else reference_bytes_per_path(sc_)
+    frac_8d = None if b8d is None else round(b8d * agg["paths"] * world / elapsed / 1e9 / HBM_PEAK_GBS, 4)
     return {
+        "frac_survey_8d": frac_8d,
+        "survey_8d_note": "SURVEY 8(d)'s algorithmic bytes per path (reference_algorithm_bytes_per_path) x paths/s / 8 TB/s; above 1 = served "
+                          "by LDS / scalar cache / L1 / L2, not by HBM",
+        "roofs": roofs_block(inputs, agg, busy_ms * 1e-3, traffic),
+        "valu_probe": probe,
         # `bound` names the roof `frac` is measured against (the contract's vocabulary: this path has no MFMA work, its
         # roof is HBM); `limited_by` names what the counters say actually binds the kernel today.
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -269,7 +342,7 @@ def roofline_block(config, agg, elapsed, steps, world, standard, oracle_counters
         "exclusive_ms_per_launch": round(excl_ms, 4),
         "overlapped_ms_per_launch": round(agg["path_ms"] / launches, 4),
         "achieved_wall": round(alg * world / elapsed / 1e9, 1),
-        "reference_algorithm_bytes_per_path": None if oracle_counters is None else reference_bytes_per_path(oracle_counters),
+        "reference_algorithm_bytes_per_path": b8d,
         "limiter": lim or None,
         "note": "`achieved` / `frac` = HBM UTILISATION: bytes of the implemented wavefront algorithm (path/hit/shadow records and "
                 "samples - queue traffic SURVEY 8(d) calls implementation overhead; scene data only where it is neither LDS- nor "
@@ -278,17 +351,24 @@ def roofline_block(config, agg, elapsed, steps, world, standard, oracle_counters
                 "the replayed counters (`limited_by_shares`; DESIGN.md 6, profiles/)"}
 
 
-def limited_by_counters(lim, hbm_frac):
-    """What binds the kernel, from the counters: "hbm" when the measured traffic is above 0.6 of the peak, "valu" when
-    the VALU issue slots are (the walk issues them at partial lane fill), else "latency" (waves waiting on dependent
-    fetches: `waiting_share_of_wave_cycles`).  None without counters."""
+def limited_by_counters(lim, hbm_frac, probe=None):
+    """What binds the kernel.  "hbm" when the measured traffic is above 0.6 of the peak.  "valu" needs more than busy issue
+    slots: the slots are 0.6-0.7 busy on the box scenes, yet extra VALU instructions in every box step cost next to nothing
+    (profiles/NOTES.md), so "valu" is only said when a probe run of the shipped kernel (`probe`: tools/valu_probe.sh,
+    profiles/rNN_<config>_valu_probe.json) shows a slope of at least 0.3 % of frame time per 1 % more VALU instructions; without
+    a probe the issue share alone decides at 0.85.  Otherwise "latency": waves waiting on dependent fetches at partial lane
+    fill (`waiting`).  None without counters."""
     if not lim:
         return None, None
+    slope = None if not probe else probe.get("slope_time_pct_per_valu_pct")
     shares = {"hbm": None if hbm_frac is None else round(hbm_frac, 4), "valu": lim.get("valu_issue_frac"),
-              "waiting": lim.get("waiting_share_of_wave_cycles")}
-    cand = {k: v for k, v in shares.items() if k != "waiting" and v is not None}
-    top = max(cand, key=cand.get) if cand else None
-    return (top if top is not None and cand[top] >= 0.6 else "latency"), shares
+              "waiting": lim.get("waiting_share_of_wave_cycles"), "valu_probe_slope": slope}
+    if hbm_frac is not None and hbm_frac >= 0.6:
+        return "hbm", shares
+    valu = lim.get("valu_issue_frac")
+    if valu is not None and ((slope is not None and slope >= 0.3 and valu >= 0.6) or (slope is None and valu >= 0.85)):
+        return "valu", shares
+    return "latency", shares
 
 
 def run_config(name, cfg, args, steps, warmup, hj, barrier):
@@ -420,6 +500,7 @@ def main():
             # steps overlap at their seams (the next frame's first batches beside this frame's last): all K frames lie inside the timed region
             "frames_back_to_back": bool(res["pipelined"]),
             "blocking_frame_ms": None if res["latency_ms"] is None else round(res["latency_ms"], 3),   # one frame alone, after the timed region
+            "value_blocking": None if not res["latency_ms"] else round(W * H * spp / (res["latency_ms"] * 1e-3) / 1e6, 3),   # Mrays/s of that frame
         }
         oracle_counters = None
         if not args.no_cpu_baseline and world == 1:        # the CPU baseline is a one-GPU-run item (rank 0, N = 1 only)
@@ -443,6 +524,8 @@ def main():
                     "workload": f"{name}: {c2['name'].format(W=r['W'], H=r['H'], spp=r['spp'])}, BVH, block 128, seed {args.seed}",
                     "value": round(p2 / r["elapsed"] / 1e6, 3), "unit": "Mrays/s", "steps": r["steps"], "warmup": 1,
                     "ms_per_step": round(1e3 * r["elapsed"] / r["steps"], 3),
+                    "blocking_frame_ms": None if r["latency_ms"] is None else round(r["latency_ms"], 3),
+                    "value_blocking": None if not r["latency_ms"] else round(r["W"] * r["H"] * r["spp"] / (r["latency_ms"] * 1e-3) / 1e6, 3),
                     "rays_per_path": round((r["agg"]["closest_rays"] + r["agg"]["shadow_rays"]) / max(1, r["agg"]["paths"]), 3),
                     "roofline": roofline_block(name, r["agg"], r["elapsed"], r["steps"], world, True)}
         print(json.dumps(out), flush=True)

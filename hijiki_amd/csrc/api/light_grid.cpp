@@ -145,6 +145,20 @@ struct Shaft {
     }
     return false;
   }
+  // the same for a ball (a sphere shape with its padding): outside as soon as it lies beyond the union box along an axis or
+  // beyond one supporting line of a projection by more than its radius (a disc outside a half-plane of the 2-D hull)
+  bool outside_ball(const double c[3], double r) const {
+    for (int k = 0; k < 3; k++) if (c[k] - r > u.hi[k] || c[k] + r < u.lo[k]) return true;
+    for (int k = 0; k < 3; k++) {
+      const int i = (k + 1) % 3, j = (k + 2) % 3;
+      for (int l = 0; l < nlines[k]; l++) {
+        const Line& L = lines[k][l];
+        const double len = std::sqrt(L.ni * L.ni + L.nj * L.nj);
+        if (L.ni * c[i] + L.nj * c[j] - L.c > r * len * (1.0 + 1e-12)) return true;
+      }
+    }
+    return false;
+  }
 };
 
 }  // namespace
@@ -273,7 +287,11 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
             if (sh.outside(pad(sub[i], m))) { i = std::min<size_t>(nd.exit_index, N); continue; }
             if (nd.shape_index != HJ_BVH_INNER) {
               const size_t shp = nd.shape_index;
-              if (!(g.coplanar(shp, P, tol_s) || g.coplanar(shp, em.q, tol_s))) blocked = true;
+              if (shp < g.ns) {                              // a sphere: its ball, not its box, has to touch the shaft
+                const hj_sphere& sp = s->spheres[shp];
+                const double c[3] = {sp.center[0], sp.center[1], sp.center[2]};
+                if (!sh.outside_ball(c, std::fabs((double)sp.radius) + m)) blocked = true;
+              } else if (!(g.coplanar(shp, P, tol_s) || g.coplanar(shp, em.q, tol_s))) blocked = true;
             }
             i++;
           }

@@ -280,6 +280,10 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
       const int nt_env = env_int("HJ_STREAM_STATE", -1, -1, 1);
       d.stream_state = (nt_env == 1 || (nt_env < 0 && N >= (size_t)env_int("HJ_STREAM_MIN_NODES", 300000, 0, 1 << 30))) ? 1u : 0u;
     }
+    {   // camera packets of 8 x 8 pixels instead of 64 x 1 on the same large trees.  HJ_GROUP_TILE = 0 / 1 forces.
+      const int gt_env = env_int("HJ_GROUP_TILE", -1, -1, 1);
+      d.group_tile = (gt_env == 1 || (gt_env < 0 && N >= (size_t)env_int("HJ_STREAM_MIN_NODES", 300000, 0, 1 << 30))) ? 1u : 0u;
+    }
     d.num_nodes = (uint32_t)M_all;
     d.root = N ? map[0] : 0u;
     d.num_hot = hot;

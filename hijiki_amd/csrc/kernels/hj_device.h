@@ -64,6 +64,7 @@ struct DeviceScene {
   uint32_t has_extinction;      // any dielectric with non-zero extinction
   uint32_t has_pairs;           // the node array holds pair nodes (tri_pair)
   uint32_t stream_state;        // large tree: path records and samples bypass the caches (non-temporal accesses)
+  uint32_t group_tile;          // large tree: a 64-sample group is an 8 x 8 pixel tile of its block instead of 64 pixels of a row (hj_stages.h)
   hj_camera camera;
   float tan_half_fov;           // (float)tan(radians(fov/2)) evaluated in double on the host
   // Light-shaft visibility grid (api/light_grid.cpp): bit e of cell (x, y, z) says that EVERY next-event shadow ray from a hit

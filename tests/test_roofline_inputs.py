@@ -48,9 +48,12 @@ def test_roofline_block_never_quotes_more_than_the_counters_saw():
            "unoccluded_shadow_rays": int(1.2 * P), "path_launches": 8, "path_busy_ms": 960.0, "path_ms": 2800.0}
     r = bench.roofline_block("c4", agg, 0.99, 1, 1, True)
     assert r["bound"] == "hbm" and r["replayed_from_profile"] is True
-    sh = r["limited_by_shares"]                              # `limited_by` follows from the counters, not from a literal
-    top = max(("hbm", "valu"), key=lambda k: sh[k])
-    assert r["limited_by"] == (top if sh[top] >= 0.6 else "latency")
+    sh = r["limited_by_shares"]                              # `limited_by` follows from counters + probe, not from a literal
+    assert r["limited_by"] == bench.limited_by_counters(r["limiter"], sh["hbm"], r["valu_probe"])[0]
+    assert r["frac_survey_8d"] is None or r["frac_survey_8d"] > 0
+    roofs = r["roofs"]
+    assert roofs["hbm"]["frac"] == sh["hbm"] and 0 < roofs["lds"]["frac"] < 1 and 0 < roofs["l2_gather"]["frac"] < 1
+    assert abs(roofs["valu_lanes"]["frac"] - r["valu_issue_frac"] * r["lane_fill"]) < 0.02
     assert r["compulsory_bytes_per_path"] >= 128 and r["overhead_ratio"] > 1
     assert abs(r["overhead_ratio"] - r["traffic_bytes_per_path"] / r["compulsory_bytes_per_path"]) < 0.01
     assert r["traffic"] is not None and r["achieved"] <= r["traffic"] * 1.001
@@ -62,6 +65,22 @@ def test_limited_by_follows_the_counters():
     sys.path.insert(0, ROOT)
     import bench
     assert bench.limited_by_counters({}, None) == (None, None)
-    assert bench.limited_by_counters({"valu_issue_frac": 0.66, "waiting_share_of_wave_cycles": 0.67}, 0.39)[0] == "valu"
+    busy = {"valu_issue_frac": 0.66, "waiting_share_of_wave_cycles": 0.67}
+    # busy issue slots alone do not make a kernel VALU-bound: the probe of the shipped kernel has to agree
+    assert bench.limited_by_counters(busy, 0.39)[0] == "latency"
+    assert bench.limited_by_counters(busy, 0.39, {"slope_time_pct_per_valu_pct": 0.02})[0] == "latency"
+    assert bench.limited_by_counters(busy, 0.39, {"slope_time_pct_per_valu_pct": 0.45})[0] == "valu"
+    assert bench.limited_by_counters({"valu_issue_frac": 0.9}, 0.2)[0] == "valu"
     assert bench.limited_by_counters({"valu_issue_frac": 0.55, "waiting_share_of_wave_cycles": 0.64}, 0.42)[0] == "latency"
     assert bench.limited_by_counters({"valu_issue_frac": 0.30}, 0.81)[0] == "hbm"
+
+
+def test_survey_8d_fraction_uses_the_full_frame_oracle_counters():
+    """SURVEY 8(d)'s B_path from the oracle counters of the whole frame (tests/golden/full_size_*.json): thousands of bytes per
+    path on every configuration - far more than HBM could deliver at the measured rates, which is the point of the field."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for cfg in ("c2", "c3", "c4", "c5"):
+        c = bench.survey_8d_counters(cfg)
+        assert c is not None and c["paths"] > 0
+        assert 3000 < bench.reference_bytes_per_path(c) < 20000

@@ -50,6 +50,7 @@ def cmd_pmc(path):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.Counter()
     names = []
+    seen = set()
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         c = r["Counter_Name"]
@@ -57,10 +58,16 @@ def cmd_pmc(path):
             names.append(c)
         agg[k][c] += float(r["Counter_Value"])
         cnt[(k, c)] += 1
+        # the dispatch's own duration (counter passes serialise the launches): once per dispatch, as a pseudo-counter in ns
+        if r.get("Start_Timestamp") and r.get("End_Timestamp") and (k, r.get("Dispatch_Id")) not in seen:
+            seen.add((k, r.get("Dispatch_Id")))
+            agg[k]["PASS_KERNEL_NS"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    if seen:
+        names.append("PASS_KERNEL_NS")
     w = csv.writer(sys.stdout, lineterminator="\n")             # kernel names hold commas ("k<true, false>"): quoted
     w.writerow(["kernel", "launches"] + names)
     for k in sorted(agg):
-        w.writerow([k, max(cnt[(k, c)] for c in names)] + [f"{agg[k][c]:.0f}" for c in names])
+        w.writerow([k, max(cnt[(k, c)] for c in names if c != "PASS_KERNEL_NS")] + [f"{agg[k][c]:.0f}" for c in names])
 
 
 def read_passes(files):
@@ -81,6 +88,10 @@ def read_passes(files):
                 row = [",".join(row[:extra + 1])] + row[extra + 1:]
                 launches = max(launches, int(row[1]))
                 for k, v in zip(header[2:], row[2:]):
+                    if k == "PASS_KERNEL_NS":                     # per pass: keep the one of the pass that holds GRBM_GUI_ACTIVE
+                        if "GRBM_GUI_ACTIVE" in header:
+                            c["GRBM_PASS_KERNEL_NS"] = float(v)
+                        continue
                     c[k] = float(v)
     return c, launches
 
@@ -99,6 +110,9 @@ def cmd_build(d, cfg, prefix=""):
         out["write_bytes_per_path"] = write / paths
         out["hbm_bytes_per_path_raw"] = (fetch + write) / paths
         out["hbm_bytes_per_path"] = (2 * fetch + write) / paths
+    if c.get("GRBM_PASS_KERNEL_NS"):        # kernel time of the pass that counted GRBM_GUI_ACTIVE: the clock the chip held = cycles / 8 / time
+        out["pmc_kernel_seconds"] = c["GRBM_PASS_KERNEL_NS"] * 1e-9
+        out["effective_clock_ghz"] = round(c["GRBM_GUI_ACTIVE"] / 8.0 / c["GRBM_PASS_KERNEL_NS"], 3)
     lim = {}
     if c.get("SQ_INSTS_VALU"):
         lim["valu_lanes_per_instruction"] = round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"], 2)
