@@ -70,8 +70,10 @@ def implemented_bytes(st):
     (DESIGN.md section 4 lists every term).  Path records are far larger than any cache (pool x 2048 workgroups x
     ~200 B), so every one of these accesses is compulsory traffic; scene data (0.6 MB on cbox: LDS/L1/L2-resident)
     is NOT counted here."""
-    P, C, S = st["paths"], st["closest_rays"], st["shadow_rays"]
-    Hh, U = st["hits"], st["unoccluded_shadow_rays"]
+    P, C = st["paths"], st["closest_rays"]
+    D = st.get("shadow_rays_proven_free", 0)          # next-event samples the light-shaft grid answered: one sample update, no records
+    S = st["shadow_rays"] - D                         # shadow rays that were queued and walked
+    Hh, U = st["hits"], st["unoccluded_shadow_rays"] - D
     A = C - P                      # continuing paths written by shade (every closest ray that is not a camera ray)
     first_hits = P * (Hh / C) if C else 0.0
     b = 0.0
@@ -79,7 +81,7 @@ def implemented_bytes(st):
     b += P * (2 * 16)              # packet stage: sample init (smp_rgb, smp_nd)
     b += A * (2 * 16)              # walk: fetch ray_o, ray_d of a continuing path
     b += C * 16                    # walk / packet stage: the hit record
-    b += C * (2 * 16)              # compaction: two passes over the hit records
+    b += C * (16 + 1 + 1)          # compaction: first pass reads the hit records and leaves a tag byte per ray for the second
     b += Hh * (4 + 4)              # hit queue: write + read of the position
     b += Hh * 16                   # shade: the hit record
     b += max(0.0, Hh - first_hits) * (3 * 16)   # shade: ray_o, ray_d, thr of a continuing path that hit
@@ -87,6 +89,7 @@ def implemented_bytes(st):
     b += S * (3 * 16)              # shade: shadow record (origin, direction + tMax, contribution + sample)
     b += S * (3 * 16)              # walk: fetch shadow origin, direction, contribution + sample index (carried in registers)
     b += U * (2 * 16)              # unoccluded: read-modify-write of the sample
+    b += D * (2 * 16)              # proven free: the same update, from the shade stage
     b += first_hits * 16           # first-hit normal + depth
     b += P * (2 * 16 * (20 * 20) / (16 * 16))   # reconstruction: both sample layers, 20x20 staged per 16x16 tile
     return b
@@ -96,9 +99,10 @@ def coalesced_read_bytes(st):
     """The part of implemented_bytes() that is READ as wide coalesced 16-byte-per-lane streams (records in queue order):
     rocprofv3's FETCH_SIZE counts these at half their size on gfx950 (MI355X_MICROARCH.md, section HBM), while it counts
     the 64-byte sectors of 16/32/48-byte gathers exactly (profiles/r02_fetch_size_calibration.txt)."""
-    P, C, S, Hh = st["paths"], st["closest_rays"], st["shadow_rays"], st["hits"]
+    P, C, Hh = st["paths"], st["closest_rays"], st["hits"]
+    S = st["shadow_rays"] - st.get("shadow_rays_proven_free", 0)
     first_hits = P * (Hh / C) if C else 0.0
-    return (C - P) * (2 * 16) + C * (2 * 16) + Hh * 16 + max(0.0, Hh - first_hits) * (3 * 16) + S * (3 * 16) \
+    return (C - P) * (2 * 16) + C * (16 + 1) + Hh * 16 + max(0.0, Hh - first_hits) * (3 * 16) + S * (3 * 16) \
         + P * (2 * 16 * (20 * 20) / (16 * 16))
 
 

@@ -111,7 +111,8 @@ class RenderStats(C.Structure):
                 ("bounce_rounds", u64), ("trace_closest_ms", C.c_double), ("trace_shadow_ms", C.c_double),
                 ("shade_ms", C.c_double), ("reconstruct_ms", C.c_double), ("total_ms", C.c_double),
                 ("closest_launches", u64), ("path_ms", C.c_double), ("path_launches", u64),
-                ("hits", u64), ("unoccluded_shadow_rays", u64), ("path_busy_ms", C.c_double)]
+                ("hits", u64), ("unoccluded_shadow_rays", u64), ("path_busy_ms", C.c_double),
+                ("shadow_rays_proven_free", u64)]
 
 
 # byte sizes of SURVEY.md Appendix A

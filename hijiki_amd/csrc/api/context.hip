@@ -162,7 +162,7 @@ int hj_context_create(int device, hj_context** out) {
   ctx->pool = (uint32_t)env_int("HJ_POOL", 32768, 64, 1 << 20) / 64u * 64u;
   for (auto& sl : ctx->slots) {
     if ((e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
-    if ((e = hipHostMalloc((void**)&sl.h_counts, sizeof(uint32_t) * 6 * ctx->num_wg, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
+    if ((e = hipHostMalloc((void**)&sl.h_counts, sizeof(uint32_t) * 7 * ctx->num_wg, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
     for (hipEvent_t* ev : {&sl.ev_count[0], &sl.ev_count[1], &sl.ev_recon, &sl.ev_done, &sl.ev_path})
       if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   }

@@ -85,7 +85,7 @@ struct hj_context {
     hipEvent_t ev_path = nullptr;         // this slot's path kernel has finished (the reconstruction stream waits for it)
     hj_image_block* h_blocks = nullptr;   // pinned staging of the block list
     uint32_t h_blocks_cap = 0;
-    uint32_t* h_counts = nullptr;         // pinned read-back: 2 (split-path ray counts) + 4 (statistics) arrays of num_wg words
+    uint32_t* h_counts = nullptr;         // pinned read-back: 2 (split-path ray counts) + 5 (statistics) arrays of num_wg words
     hipEvent_t ev_count[2] = {nullptr, nullptr};
     hipEvent_t ev_recon = nullptr;        // this slot's reconstruction has run (orders framebuffer updates)
     hipEvent_t ev_done = nullptr;         // batch complete, statistics copied back

@@ -71,7 +71,7 @@ int ensure_batch(hj_context* ctx, hj_context::BatchSlot& sl, uint32_t num_blocks
     HJ_ALLOC(sl.bufs, cnt_ray[1], uint32_t, Gmax)
     HJ_ALLOC(sl.bufs, cnt_hit, uint32_t, (size_t)Gmax * hj::kNumTags)
     HJ_ALLOC(sl.bufs, cnt_shadow, uint32_t, Gmax)
-    HJ_ALLOC(sl.bufs, acc_closest, uint32_t, (size_t)4 * Gmax)  // closest | shadow | hits | unoccluded, one read-back
+    HJ_ALLOC(sl.bufs, acc_closest, uint32_t, (size_t)5 * Gmax)  // closest | shadow | hits | unoccluded | proven free, one read-back
     if (rc == HJ_OK) sl.alloc_positions = n;
   }
 #undef HJ_ALLOC
@@ -79,6 +79,7 @@ int ensure_batch(hj_context* ctx, hj_context::BatchSlot& sl, uint32_t num_blocks
     st.acc_shadow = st.acc_closest + G;
     st.acc_hits = st.acc_closest + 2 * (size_t)G;
     st.acc_unoccluded = st.acc_closest + 3 * (size_t)G;
+    st.acc_direct = st.acc_closest + 4 * (size_t)G;
     st.pool = pool;
   }
   st.num_wg = G;
@@ -208,6 +209,7 @@ int harvest(hj_context* ctx, hj_context::BatchSlot& sl, hj_render_stats* stats, 
       stats->shadow_rays += h_acc[G + i];
       stats->hits += h_acc[2 * (size_t)G + i];
       stats->unoccluded_shadow_rays += h_acc[3 * (size_t)G + i];
+      stats->shadow_rays_proven_free += h_acc[4 * (size_t)G + i];
     }
     stats->batches += 1;
   }
@@ -231,7 +233,7 @@ int stage_blocks(hj_context* ctx, hj_context::BatchSlot& sl, const hj_image_bloc
 int finish_batch(hj_context* ctx, hj_context::BatchSlot& sl, const hj::BatchState& st) {
   const uint32_t G = st.num_wg;
   uint32_t* h_acc = sl.h_counts + (size_t)2 * G;
-  HJ_HIP(ctx, hipMemcpyAsync(h_acc, st.acc_closest, sizeof(uint32_t) * 4 * G, hipMemcpyDeviceToHost, sl.stream));
+  HJ_HIP(ctx, hipMemcpyAsync(h_acc, st.acc_closest, sizeof(uint32_t) * 5 * G, hipMemcpyDeviceToHost, sl.stream));
   HJ_HIP(ctx, hipEventRecord(sl.ev_done, sl.stream));
   sl.pending = true;
   sl.nb_in_flight = st.num_blocks;

@@ -113,6 +113,7 @@ struct BatchState {
   uint32_t* acc_shadow;   // [num_wg] shadow rays
   uint32_t* acc_hits;     // [num_wg] closest-hit rays that hit something
   uint32_t* acc_unoccluded;   // [num_wg] shadow rays that reached their light
+  uint32_t* acc_direct;       // [num_wg] of those: next-event samples the light-shaft grid answered (no ray was traced)
   const hj_image_block* blocks;  // the batch's ImageBlocks
   uint32_t num_blocks;
   uint32_t capacity;             // samples allocated

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
   // Camera paths without records: kernels that have the packet stage (BVH walk over a tree with pair nodes, stages called)
   constexpr bool IMPLICIT = HJ_CAMERA_PACKETS && HJ_SHADE_CALL >= 2 && USE_BVH && PAIRS;
   uint32_t groups_left = wg_num_groups(st, g);
-  uint32_t total_closest = 0, total_shadow = 0, total_hits = 0, total_unocc = 0;   // (thread 0's copies are published)
+  uint32_t total_closest = 0, total_shadow = 0, total_hits = 0, total_unocc = 0, total_direct = 0;   // (thread 0's copies are published)
   if (groups_left != 0) {
     uint32_t k_next = 0;                     // next group of this workgroup's sample sequence
     if (threadIdx.x == 0) { sh.n_ray[0] = 0; sh.n_ray[1] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; sh.n_direct = 0; sh.cam_first = 0xFFFFFFFFu; sh.cam_k0 = 0; sh.n_cam_dead = 0; }
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
       const uint32_t n = IMPLICIT ? n0 + 64u * ngen : n0 + uni(sh.n_gen), ns = uni(sh.n_shadow);
       // next-event samples of the previous round's shade that the light-shaft grid answered (intersectScene(shadowRay) == false
       // without a walk): shadow rays of the statistics all the same
-      { const uint32_t nd = uni(sh.n_direct); total_shadow += nd; total_unocc += nd; }
+      { const uint32_t nd = uni(sh.n_direct); total_shadow += nd; total_unocc += nd; total_direct += nd; }
       if (n + ns == 0) {
         if (groups_left == 0) break;
         // every sample of the new groups lay outside its block: next groups.  The other parity's path count is the one the
@@ -187,6 +187,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
     st.acc_shadow[g] = total_shadow;
     st.acc_hits[g] = total_hits;
     st.acc_unoccluded[g] = total_unocc;
+    st.acc_direct[g] = total_direct;
   }
 }
 
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_gen_camera(BatchState st, Dev
     st.acc_shadow[g] = 0;
     st.acc_hits[g] = 0;
     st.acc_unoccluded[g] = 0;
+    st.acc_direct[g] = 0;
   }
 }
 
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(BatchState st, DeviceSc
     st.cnt_shadow[g] = sh.n_shadow;
     st.acc_shadow[g] += sh.n_shadow + sh.n_direct;
     st.acc_unoccluded[g] += sh.n_direct;
+    st.acc_direct[g] += sh.n_direct;
   }
 }
 

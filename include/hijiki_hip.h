@@ -177,6 +177,7 @@ typedef struct hj_render_stats {
   uint64_t hits;             /* closest-hit rays that hit a shape                   */
   uint64_t unoccluded_shadow_rays; /* shadow rays that reached their light           */
   double   path_busy_ms;     /* union of the path kernels' intervals = their exclusive GPU time (if timed) */
+  uint64_t shadow_rays_proven_free; /* of shadow_rays (and of unoccluded_shadow_rays): answered by the light-shaft grid, no walk */
 } hj_render_stats;
 
 typedef struct hj_context hj_context;
