@@ -29,6 +29,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <thread>
@@ -45,6 +48,27 @@ inline Box pad(Box b, double m) { for (int k = 0; k < 3; k++) { b.lo[k] -= m; b.
 inline bool finite_box(const Box& b) { for (int k = 0; k < 3; k++) if (!(std::isfinite(b.lo[k]) && std::isfinite(b.hi[k]) && b.lo[k] <= b.hi[k])) return false; return true; }
 
 struct Plane { double n[3], d; bool ok; };        // n.x - d = signed distance, |n| = 1
+
+// Bounds as the scene's own floats (min / max of float coordinates are exact): half the memory of the double boxes in the two
+// passes over a million shapes and two million nodes.
+struct BoxF { float lo[3], hi[3]; };
+inline BoxF empty_boxf() { return {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}}; }
+inline void joinf(BoxF& b, const BoxF& o) { for (int k = 0; k < 3; k++) { b.lo[k] = std::min(b.lo[k], o.lo[k]); b.hi[k] = std::max(b.hi[k], o.hi[k]); } }
+inline Box widen(const BoxF& b) { Box r; for (int k = 0; k < 3; k++) { r.lo[k] = b.lo[k]; r.hi[k] = b.hi[k]; } return r; }
+
+// fn(begin, end) over [0, n) in contiguous pieces on up to 16 threads (one piece per thread; small n: the caller's thread)
+template <class Fn>
+void parallel_pieces(size_t n, size_t min_per_thread, Fn fn) {
+  unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, n / std::max<size_t>(1, min_per_thread)));
+  if (nt <= 1) { fn((size_t)0, n, 0u); return; }
+  std::vector<std::thread> pool;
+  unsigned started = 1;
+  try { for (unsigned t = 1; t < nt; t++) { pool.emplace_back(fn, n * t / nt, n * (t + 1) / nt, t); started++; } } catch (const std::exception&) {}
+  fn((size_t)0, n / nt, 0u);
+  for (unsigned t = started; t < nt; t++) fn(n * t / nt, n * (t + 1) / nt, t);     // (threads that could not be started)
+  for (auto& th : pool) th.join();
+}
 
 struct Geometry {
   const hj_scene_desc* s;
@@ -74,6 +98,25 @@ struct Geometry {
     double v[4][3];
     const int n = vertices(shape, v);
     for (int c = 0; c < n; c++) grow(b, v[c]);
+    return b;
+  }
+  BoxF boundsf(size_t shape) const {            // exact: a sphere's centre +- |radius| rounded OUTWARD, vertices as they are
+    BoxF b = empty_boxf();
+    if (shape < ns) {
+      const hj_sphere& sp = s->spheres[shape];
+      const double r = std::fabs((double)sp.radius);
+      for (int k = 0; k < 3; k++) {
+        b.lo[k] = std::nextafter((float)(sp.center[k] - r), -INFINITY);
+        b.hi[k] = std::nextafter((float)(sp.center[k] + r), INFINITY);
+      }
+      return b;
+    }
+    double v[4][3];
+    const int n = vertices(shape, v);
+    for (int c = 0; c < n; c++) for (int k = 0; k < 3; k++) {
+      b.lo[k] = std::min(b.lo[k], std::nextafter((float)v[c][k], -INFINITY));      // (quad corners are sums: outward by one ulp)
+      b.hi[k] = std::max(b.hi[k], std::nextafter((float)v[c][k], INFINITY));
+    }
     return b;
   }
   Plane plane(size_t shape) const {
@@ -168,38 +211,100 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
   if (!s || res < 2 || res > 256 || s->num_emitters == 0 || s->num_bvh_nodes == 0) return false;
   const Geometry g{s, s->num_spheres, s->num_quads, s->num_triangles};
   const size_t shapes = g.ns + g.nq + g.nt, N = s->num_bvh_nodes;
+  const bool timing = std::getenv("HJ_LIGHT_GRID_TIMING") != nullptr;       // wall time of the stages on stderr
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "light grid: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
 
   // bounds of the scene (shapes) and the scale of the coordinates (incl. the camera: camera rays start there)
-  std::vector<Box> sb(shapes);
+  std::vector<BoxF> sb(shapes);
   Box scene = empty_box();
-  for (size_t i = 0; i < shapes; i++) { sb[i] = g.bounds(i); join(scene, sb[i]); }
+  {
+    std::vector<BoxF> part(16, empty_boxf());
+    parallel_pieces(shapes, 65536, [&](size_t a, size_t b, unsigned t) {
+      BoxF acc = empty_boxf();
+      for (size_t i = a; i < b; i++) { sb[i] = g.boundsf(i); joinf(acc, sb[i]); }
+      part[t] = acc;
+    });
+    for (const BoxF& b : part) { const Box w = widen(b); join(scene, w); }
+  }
   if (!finite_box(scene)) return false;
   Box all = scene;
   { const double c[3] = {s->camera.position[0], s->camera.position[1], s->camera.position[2]}; if (std::isfinite(c[0] + c[1] + c[2])) grow(all, c); }
   double scale = 0, ext = 0;
   for (int k = 0; k < 3; k++) { scale = std::max(scale, std::max(all.hi[k] - all.lo[k], std::max(std::fabs(all.lo[k]), std::fabs(all.hi[k])))); ext = std::max(ext, scene.hi[k] - scene.lo[k]); }
   if (!(ext > 0)) return false;
+  mark("shape bounds");
   const double tol_p = 2e-6 * scale, tol_s = 2e-7 * scale, m = 1e-4 * std::max(1.0, scale);
   constexpr double kSinCell = 0.25, kSinEmitter = 0.1, kTMin = 2e-4, kEps = 1e-4;
   // the two escape arguments of the header must hold with room to spare at this scale, or there is no grid
   if (!((tol_p + tol_s) / kSinCell < 0.5 * kTMin && 2 * tol_s / kSinEmitter < 0.5 * kEps)) return false;
 
-  // subtree bounds from the shapes: sub[i] covers every leaf with an index in [i, exit(i))
-  std::vector<Box> sub(N);
-  for (size_t i = N; i-- > 0;) {
-    const hj_bvh_node& nd = s->bvh[i];
-    Box b = empty_box();
-    if (nd.shape_index != HJ_BVH_INNER) { if (nd.shape_index >= shapes) return false; b = sb[nd.shape_index]; }
-    const size_t e = std::min<size_t>(nd.exit_index, N);
-    if (e <= i) return false;
-    int chain = 0;
-    for (size_t j = i + 1; j < e; j = std::min<size_t>(s->bvh[j].exit_index, N)) {
-      join(b, sub[j]);
-      if (++chain > 8) return false;                       // not a tree this code wants to reason about
+  // subtree bounds from the shapes: sub[i] covers every leaf with an index in [i, exit(i)).  One reverse pass; on large
+  // arrays the pass is cut at the top of the tree: the ranges [a, exit(a)) of a frontier of nodes are disjoint blocks of the
+  // array, each done by its own thread, then the few nodes above the frontier.  A node whose exit leaves its block - no
+  // tree - ends the attempt (no grid).
+  std::vector<BoxF> sub(N);
+  std::atomic<bool> malformed{false};
+  auto reverse_pass = [&](size_t lo_i, size_t hi_i, const std::vector<uint8_t>* skip) {     // nodes [lo_i, hi_i), highest first
+    for (size_t i = hi_i; i-- > lo_i;) {
+      if (skip && (*skip)[i]) continue;
+      const hj_bvh_node& nd = s->bvh[i];
+      BoxF b = empty_boxf();
+      if (nd.shape_index != HJ_BVH_INNER) { if (nd.shape_index >= shapes) { malformed = true; return; } b = sb[nd.shape_index]; }
+      const size_t e = std::min<size_t>(nd.exit_index, N);
+      if (e <= i || (!skip && e > hi_i)) { malformed = true; return; }
+      int chain = 0;
+      for (size_t j = i + 1; j < e; j = std::min<size_t>(s->bvh[j].exit_index, N)) {
+        joinf(b, sub[j]);
+        if (++chain > 8) { malformed = true; return; }      // not a tree this code wants to reason about
+      }
+      sub[i] = b;
     }
-    sub[i] = b;
+  };
+  if (N < 200000) {
+    reverse_pass(0, N, nullptr);
+  } else {
+    // frontier: open the node with the largest range until there are enough blocks
+    std::vector<size_t> frontier{0};
+    std::vector<uint8_t> done(N, 0);            // 1: inside a block (its thread computed it); 0: above the frontier
+    while (frontier.size() < 64) {
+      size_t best = 0, best_len = 0;
+      for (size_t f = 0; f < frontier.size(); f++) {
+        const size_t a = frontier[f], len = std::min<size_t>(s->bvh[a].exit_index, N) - a;
+        if (s->bvh[a].shape_index == HJ_BVH_INNER && len > best_len) { best = f; best_len = len; }
+      }
+      if (best_len < 4096) break;
+      const size_t a = frontier[best], e = std::min<size_t>(s->bvh[a].exit_index, N);
+      frontier.erase(frontier.begin() + (long)best);
+      int chain = 0;
+      for (size_t j = a + 1; j < e; j = std::min<size_t>(s->bvh[j].exit_index, N)) {
+        if (std::min<size_t>(s->bvh[j].exit_index, N) <= j || ++chain > 8) return false;
+        frontier.push_back(j);
+      }
+    }
+    std::atomic<size_t> next_block{0};
+    parallel_pieces(frontier.size(), 1, [&](size_t, size_t, unsigned) {
+      for (;;) {
+        const size_t f = next_block.fetch_add(1);
+        if (f >= frontier.size()) break;
+        const size_t a = frontier[f], e = std::min<size_t>(s->bvh[a].exit_index, N);
+        if (e <= a) { malformed = true; break; }
+        reverse_pass(a, e, nullptr);
+      }
+    });
+    if (malformed) return false;
+    for (size_t a : frontier) for (size_t i = a, e = std::min<size_t>(s->bvh[a].exit_index, N); i < e; i++) done[i] = 1;
+    // whatever is left (the opened nodes, and anything a strange array keeps outside every block), highest first
+    reverse_pass(0, N, &done);
   }
+  if (malformed) return false;
 
+  mark("subtree bounds");
   // the grid over the padded scene bounds
   const Box gb = pad(scene, 4 * m);
   double cell[3];
@@ -211,36 +316,57 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
   const size_t ncell = (size_t)res * res * res;
   out.bits.assign(ncell, 0);
 
-  // rasterise the shapes: per cell the first shape seen, and whether all of them share its plane
+  // rasterise the shapes: per cell the first shape seen (in shape order), and whether all of them share its plane.  The cell
+  // range of every shape first (parallel over shapes), then every thread owns a slab of z layers and takes, in shape order,
+  // the shapes that reach into it: the same grid whatever the thread count.
   std::vector<uint32_t> first(ncell, 0xFFFFFFFFu);
   std::vector<uint8_t> bad(ncell, 0);
-  std::vector<Plane> planes(shapes);
-  for (size_t i = 0; i < shapes; i++) planes[i] = g.plane(i);
   auto cell_range = [&](const Box& b, int lo[3], int hi[3]) {
     for (int k = 0; k < 3; k++) {
       lo[k] = std::max(0, (int)std::floor((b.lo[k] - gb.lo[k]) / cell[k]));
       hi[k] = std::min((int)res - 1, (int)std::floor((b.hi[k] - gb.lo[k]) / cell[k]));
     }
   };
-  for (size_t i = 0; i < shapes; i++) {
-    int lo[3], hi[3];
-    cell_range(pad(sb[i], 2 * m), lo, hi);               // (shape and cell both padded by m)
-    for (int z = lo[2]; z <= hi[2]; z++) for (int y = lo[1]; y <= hi[1]; y++) for (int x = lo[0]; x <= hi[0]; x++) {
-      const size_t c = ((size_t)z * res + y) * res + x;
-      if (bad[c]) continue;
-      if (first[c] == 0xFFFFFFFFu) { first[c] = (uint32_t)i; if (!planes[i].ok) bad[c] = 1; }
-      else if (!g.coplanar(i, planes[first[c]], tol_s)) bad[c] = 1;
+  struct Range { uint8_t lo[3], hi[3]; };
+  std::vector<Range> range(shapes);
+  parallel_pieces(shapes, 65536, [&](size_t a, size_t b, unsigned) {
+    for (size_t i = a; i < b; i++) {
+      int lo[3], hi[3];
+      cell_range(pad(widen(sb[i]), 2 * m), lo, hi);             // (shape and cell both padded by m)
+      for (int k = 0; k < 3; k++) { range[i].lo[k] = (uint8_t)lo[k]; range[i].hi[k] = (uint8_t)std::max(hi[k], 0); if (hi[k] < lo[k]) { range[i].lo[2] = 255; range[i].hi[2] = 0; } }
     }
-  }
-
+  });
+  parallel_pieces(res, 1, [&](size_t z0, size_t z1, unsigned) {
+    uint32_t cached = 0xFFFFFFFFu;               // the plane of the cell's first shape, kept while consecutive cells share it
+    Plane cp{};
+    for (size_t i = 0; i < shapes; i++) {
+      const Range& r = range[i];
+      if (r.lo[2] > r.hi[2] || r.hi[2] < z0 || r.lo[2] >= z1) continue;
+      Plane pi{};
+      bool have_pi = false;
+      for (size_t z = std::max<size_t>(r.lo[2], z0); z <= r.hi[2] && z < z1; z++) for (int y = r.lo[1]; y <= r.hi[1]; y++) for (int x = r.lo[0]; x <= r.hi[0]; x++) {
+        const size_t c = (z * res + (size_t)y) * res + (size_t)x;
+        if (bad[c]) continue;
+        if (first[c] == 0xFFFFFFFFu) {
+          first[c] = (uint32_t)i;
+          if (!have_pi) { pi = g.plane(i); have_pi = true; }
+          if (!pi.ok) bad[c] = 1;
+        } else {
+          if (cached != first[c]) { cached = first[c]; cp = g.plane(cached); }
+          if (!g.coplanar(i, cp, tol_s)) bad[c] = 1;
+        }
+      }
+    }
+  });
+  mark("planes + rasterisation");
   // emitters (bit e for e < 8)
   struct Em { size_t shape; Plane q; Box box; bool ok; };
   std::vector<Em> ems;
   for (size_t e = 0; e < std::min<size_t>(s->num_emitters, 8); e++) {
     Em em{};
     em.shape = s->emitters[e].shape;
-    em.ok = em.shape < shapes && planes[em.shape].ok;
-    if (em.ok) { em.q = planes[em.shape]; em.box = pad(sb[em.shape], m); }
+    em.ok = em.shape < shapes;
+    if (em.ok) { em.q = g.plane(em.shape); em.ok = em.q.ok; em.box = pad(widen(sb[em.shape]), m); }
     ems.push_back(em);
   }
 
@@ -259,7 +385,7 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
         Box cb;
         const int xyz[3] = {x, y, z};
         for (int k = 0; k < 3; k++) { cb.lo[k] = gb.lo[k] + xyz[k] * cell[k] - m; cb.hi[k] = gb.lo[k] + (xyz[k] + 1) * cell[k] + m; }
-        const Plane& P = planes[first[c]];
+        const Plane P = g.plane(first[c]);
         uint8_t bits = 0;
         for (size_t e = 0; e < ems.size(); e++) {
           const Em& em = ems[e];
@@ -284,7 +410,7 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
           bool blocked = false;
           for (size_t i = 0; i < N && !blocked;) {
             const hj_bvh_node& nd = s->bvh[i];
-            if (sh.outside(pad(sub[i], m))) { i = std::min<size_t>(nd.exit_index, N); continue; }
+            if (sh.outside(pad(widen(sub[i]), m))) { i = std::min<size_t>(nd.exit_index, N); continue; }
             if (nd.shape_index != HJ_BVH_INNER) {
               const size_t shp = nd.shape_index;
               if (shp < g.ns) {                              // a sphere: its ball, not its box, has to touch the shaft
@@ -307,6 +433,7 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
   try { for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(run); } catch (const std::exception&) {}
   run();
   for (auto& t : pool) t.join();
+  mark("shafts");
   out.pairs_clear = clear.load();
   if (out.pairs_clear == 0) { out = LightGrid{}; return false; }
   return true;

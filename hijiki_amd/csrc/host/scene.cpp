@@ -309,8 +309,11 @@ std::vector<BuildNode> build_bvh(const std::vector<Aabb>& boxes) {
     if (r.gain <= 0) break;
   }
   // HJ_BVH_REINSERT = passes of the insertion-based optimisation (tree_opt.cpp)
-  static const int reinsert_passes = [] { const char* e = std::getenv("HJ_BVH_REINSERT"); return e ? std::atoi(e) : 3; }();
-  if (reinsert_passes > 0) optimize_by_reinsertion(b.nodes, reinsert_passes);
+  // (default: 3 passes up to 400 000 nodes; beyond that a pass over 1/16 of the nodes costs 1.5 s per 2 M nodes and no longer
+  // lowers the node visits measurably, a pass over all of them +2 % frame rate for half a minute - tools/tree_probe.py)
+  static const int reinsert_passes = [] { const char* e = std::getenv("HJ_BVH_REINSERT"); return e ? std::atoi(e) : -1; }();
+  const int passes = reinsert_passes >= 0 ? reinsert_passes : (b.nodes.size() <= 400000 ? 3 : 0);
+  if (passes > 0) optimize_by_reinsertion(b.nodes, passes);
   static const int child_order = [] { const char* e = std::getenv("HJ_BVH_CHILD_ORDER"); return e ? std::atoi(e) : 4; }();
   if (child_order != 0) order_children(b.nodes, 0, std::min(child_order, 3));
   return std::move(b.nodes);
