@@ -2,6 +2,7 @@
 // (kernels/hj_device.h: collapsed tree, pair nodes, hot-first node order, pre-gathered triangle and emitter records).
 #include "hj_internal.h"
 #include "light_grid.hpp"
+#include "scene_relayout.hpp"
 
 #pragma clang fp contract(off)
 
@@ -57,6 +58,30 @@ int validate_scene(hj_context* ctx, const hj_scene_desc* s) {
   return HJ_OK;
 }
 
+// What depends on the tree's size once its records exist (host and device re-layout alike): N = nodes of the uploaded array,
+// M = device records without padding.
+void finish_tree_settings(hj::DeviceScene& d, size_t N, size_t M, bool has_pairs) {
+  // Large trees (their nodes and triangles do not fit the caches): the path-state streams bypass the caches so that they
+  // do not evict scene data (1 M triangles +4.4 %; cache-resident scenes lose 0.5 ... 3 % with it).  HJ_STREAM_STATE = 0 / 1 forces.
+  {
+    const int nt_env = env_int("HJ_STREAM_STATE", -1, -1, 1);
+    d.stream_state = (nt_env == 1 || (nt_env < 0 && N >= (size_t)env_int("HJ_STREAM_MIN_NODES", 300000, 0, 1 << 30))) ? 1u : 0u;
+  }
+  {   // camera packets of 8 x 8 pixels instead of 64 x 1 on the same large trees.  HJ_GROUP_TILE = 0 / 1 forces.
+    const int gt_env = env_int("HJ_GROUP_TILE", -1, -1, 1);
+    d.group_tile = (gt_env == 1 || (gt_env < 0 && N >= (size_t)env_int("HJ_STREAM_MIN_NODES", 300000, 0, 1 << 30))) ? 1u : 0u;
+  }
+  // steps per round of the walk loop (the first one is the merged step that also runs the leaf tests) and free lanes at
+  // which a wave fetches new rays: without pair nodes 4 / 32 (6: -0.4 %, 8: -4 % on cbox); with them 7 / 24 on small trees
+  // (the rays of the rotated, child-ordered trees are shorter: 5 / 32, the optimum before those passes, is 3 % slower on
+  // cbox now; 6 or 8 steps, 20 or 28 lanes: -1 ... -2 %), 8 / 24 up to 600 000 records and 8 / 32 beyond (1 M triangles:
+  // 6 .. 10 steps the same, 24 lanes -1 %).  Round 5: with the light-shaft grid most of the short shadow rays are gone and the
+  // small trees want 6 steps (c2 +2.3 %, c3 +0.8 % against 7; 5: the same; 8: -1 %; refill at 16 / 32 lanes: -0 ... -2 %)
+  const bool small_tree = M < 50000;
+  d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", !has_pairs ? 4 : (small_tree ? 6 : 8), 1, 1 << 20);   // >= 1, or the walk would never advance
+  d.refill_min = (uint32_t)env_int("HJ_REFILL_MIN", has_pairs && M < 600000 ? 24 : (int)hj::kRefillMin, 1, 64);   // (20 k / 60 k / 200 k triangles: 24 lanes +2 / +3 / +1 %)
+}
+
 }  // namespace
 
 extern "C" {
@@ -96,6 +121,39 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     if (s->dielectric[i].extinction[0] != 0.f || s->dielectric[i].extinction[1] != 0.f || s->dielectric[i].extinction[2] != 0.f)
       d.has_extinction = 1;
 
+#define HJ_UP(expr) do { rc = (expr); if (rc != HJ_OK) { release_scene(ctx); return rc; } } while (0)
+  // Large trees: the whole re-layout below runs on the device (api/scene_relayout.hip: the arrays go up as they are, a dozen
+  // kernels derive the kernels' records) - 0.19 s of host work at 1 M triangles otherwise.  HJ_UPLOAD_DEVICE = 0 / 1 forces;
+  // default: from HJ_UPLOAD_DEVICE_MIN (100 000) nodes on.  An array that is not a tree takes the host path.
+  bool on_device = false;
+  {
+    const int env = env_int("HJ_UPLOAD_DEVICE", -1, -1, 1);
+    const bool want = env == 1 || (env < 0 && s->num_bvh_nodes >= (size_t)env_int("HJ_UPLOAD_DEVICE_MIN", 100000, 0, 1 << 30));
+    if (want && s->num_bvh_nodes >= 3) {
+      const size_t mark_bufs = ctx->scene_bufs.size();
+      HJ_UP(upload(ctx, s->triangles, s->num_triangles, &d.triangles));
+      HJ_UP(upload(ctx, s->vertices, s->num_vertices, &d.vertices));
+      mark("triangle + vertex upload");
+      const int pair_env = env_int("HJ_PAIR_LEAVES", -1, -1, 1);
+      const bool pairs_on = pair_env == 1 || (pair_env < 0 && s->num_bvh_nodes >= (size_t)env_int("HJ_PAIR_MIN_NODES", 0, 0, 1 << 30));
+      RelayoutOut ro;
+      rc = relayout_on_device(ctx, s, d.triangles, d.vertices, pairs_on, env_int("HJ_NODE_ORDER", -1, -1, 1),
+                              (float)env_int("HJ_COLLAPSE_PCT", 50, 0, 1000) / 100.0f, timing, ro);
+      if (rc == HJ_OK) {
+        on_device = true;
+        d.nodes = ro.nodes; d.tri_isect = ro.tri_isect; d.tri_shade = ro.tri_shade; d.tri_pair = ro.tri_pair;
+        d.num_nodes = ro.num_nodes; d.root = ro.root; d.num_hot = ro.num_hot; d.has_pairs = ro.num_pairs ? 1u : 0u;
+        finish_tree_settings(d, s->num_bvh_nodes, ro.kept, ro.num_pairs != 0);
+      } else if (rc == HJ_ERR_UNSUPPORTED) {
+        while (ctx->scene_bufs.size() > mark_bufs) { ctx->scene_bufs.back().release(); ctx->scene_bufs.pop_back(); }
+        d.triangles = nullptr; d.vertices = nullptr;
+      } else {
+        release_scene(ctx);
+        return rc;
+      }
+    }
+  }
+  if (!on_device) {
   // pre-gathered triangle records (see kernels/hj_device.h)
   std::vector<float4> isect, shade;
   try {
@@ -134,7 +192,6 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
   static_assert(sizeof(hj_bvh_node) == 2 * sizeof(float4), "node = 2 x float4");
   static_assert(sizeof(hj_quad) == 3 * sizeof(float4) && sizeof(hj_sphere) == sizeof(float4), "shape records");
   static_assert(sizeof(hj_diffuse_cb) == 2 * sizeof(float4), "checkerboard record");
-#define HJ_UP(expr) do { rc = (expr); if (rc != HJ_OK) { release_scene(ctx); return rc; } } while (0)
   // device node array (kernels/hj_device.h): redundant inner nodes dropped, hottest (largest surface area) nodes
   // first, explicit left/exit links.
   {
@@ -274,28 +331,10 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     mark("device records");
     HJ_UP(upload(ctx, pairs.data(), pairs.size(), &d.tri_pair));
     d.has_pairs = pairs.empty() ? 0u : 1u;
-    // Large trees (their nodes and triangles do not fit the caches): the path-state streams bypass the caches so that they
-    // do not evict scene data (1 M triangles +4.4 %; cache-resident scenes lose 0.5 ... 3 % with it).  HJ_STREAM_STATE = 0 / 1 forces.
-    {
-      const int nt_env = env_int("HJ_STREAM_STATE", -1, -1, 1);
-      d.stream_state = (nt_env == 1 || (nt_env < 0 && N >= (size_t)env_int("HJ_STREAM_MIN_NODES", 300000, 0, 1 << 30))) ? 1u : 0u;
-    }
-    {   // camera packets of 8 x 8 pixels instead of 64 x 1 on the same large trees.  HJ_GROUP_TILE = 0 / 1 forces.
-      const int gt_env = env_int("HJ_GROUP_TILE", -1, -1, 1);
-      d.group_tile = (gt_env == 1 || (gt_env < 0 && N >= (size_t)env_int("HJ_STREAM_MIN_NODES", 300000, 0, 1 << 30))) ? 1u : 0u;
-    }
     d.num_nodes = (uint32_t)M_all;
     d.root = N ? map[0] : 0u;
     d.num_hot = hot;
-    // steps per round of the walk loop (the first one is the merged step that also runs the leaf tests) and free lanes at
-    // which a wave fetches new rays: without pair nodes 4 / 32 (6: -0.4 %, 8: -4 % on cbox); with them 7 / 24 on small trees
-    // (the rays of the rotated, child-ordered trees are shorter: 5 / 32, the optimum before those passes, is 3 % slower on
-    // cbox now; 6 or 8 steps, 20 or 28 lanes: -1 ... -2 %), 8 / 24 up to 600 000 records and 8 / 32 beyond (1 M triangles:
-    // 6 .. 10 steps the same, 24 lanes -1 %).  Round 5: with the light-shaft grid most of the short shadow rays are gone and the
-    // small trees want 6 steps (c2 +2.3 %, c3 +0.8 % against 7; 5: the same; 8: -1 %; refill at 16 / 32 lanes: -0 ... -2 %)
-    const bool small_tree = M < 50000;
-    d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", pairs.empty() ? 4 : (small_tree ? 6 : 8), 1, 1 << 20);   // >= 1, or the walk would never advance
-    d.refill_min = (uint32_t)env_int("HJ_REFILL_MIN", !pairs.empty() && M < 600000 ? 24 : (int)hj::kRefillMin, 1, 64);   // (20 k / 60 k / 200 k triangles: 24 lanes +2 / +3 / +1 %)
+    finish_tree_settings(d, N, M, !pairs.empty());
     // The walk adds 32 * index to the low word of the array's address without a carry (kernels/hj_walk.h): the
     // array must not cross a 4 GiB boundary.  Allocate twice the size and start at the boundary if it would.
     {
@@ -321,10 +360,11 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
   mark("pair + node upload");
   HJ_UP(upload(ctx, isect.data(), isect.size(), &d.tri_isect));
   HJ_UP(upload(ctx, shade.data(), shade.size(), &d.tri_shade));
-  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->spheres), s->num_spheres, &d.spheres));
-  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->quads), 3 * s->num_quads, &d.quads));
   HJ_UP(upload(ctx, s->triangles, s->num_triangles, &d.triangles));
   HJ_UP(upload(ctx, s->vertices, s->num_vertices, &d.vertices));
+  }   // (!on_device)
+  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->spheres), s->num_spheres, &d.spheres));
+  HJ_UP(upload(ctx, reinterpret_cast<const float4*>(s->quads), 3 * s->num_quads, &d.quads));
   HJ_UP(upload(ctx, s->materials, s->num_materials, &d.materials));
   HJ_UP(upload(ctx, s->emitters, s->num_emitters, &d.emitters));
   {
