@@ -32,6 +32,32 @@ int validate_scene(hj_context* ctx, const hj_scene_desc* s) {
     if (n.shape_index != HJ_BVH_INNER && n.shape_index >= shapes)
       return set_error(ctx, HJ_ERR_INVALID, "bvh node %zu: shape index %u out of range", i, n.shape_index);
   }
+  // The array must be what Scene::compile flattens (src/main.rs:203-231): a binary tree in pre-order - an inner node's left
+  // child is the next record, the left child's exit is the right child, a node's exit is the record behind its subtree, or
+  // beyond the array on the right spine.  The kernels lean on it (a subtree is left only through its root's exit: camera
+  // packets, the collapse, the sibling-group order); boxes may be anything, links may not.
+  if (s->num_bvh_nodes) {
+    const size_t N = s->num_bvh_nodes;
+    std::vector<uint32_t> size;
+    try { size.assign(N, 1); } catch (const std::bad_alloc&) { return set_error(ctx, HJ_ERR_NOMEM, "out of host memory"); }
+    for (size_t i = N; i-- > 0;) {
+      const hj_bvh_node& n = s->bvh[i];
+      if (n.shape_index == HJ_BVH_INNER) {
+        const size_t l = i + 1;
+        if (l >= N) return set_error(ctx, HJ_ERR_INVALID, "bvh node %zu: an inner node without children", i);
+        const size_t r = l + size[l];
+        if (r >= N || s->bvh[l].exit_index != r)
+          return set_error(ctx, HJ_ERR_INVALID, "bvh node %zu: not a pre-order skip-link tree (the left child's exit %u is not its sibling %zu)", i, s->bvh[l].exit_index, r);
+        size[i] = 1 + size[l] + size[r];
+        if (s->bvh[r].exit_index != n.exit_index)
+          return set_error(ctx, HJ_ERR_INVALID, "bvh node %zu: not a pre-order skip-link tree (the right child leaves through %u, the node through %u)", i, s->bvh[r].exit_index, n.exit_index);
+      }
+      const size_t end = i + size[i];
+      if (end < N ? n.exit_index != end : n.exit_index < N)
+        return set_error(ctx, HJ_ERR_INVALID, "bvh node %zu: not a pre-order skip-link tree (exit %u, its subtree ends at %zu)", i, n.exit_index, end);
+    }
+    if (size[0] != N) return set_error(ctx, HJ_ERR_INVALID, "bvh: %zu records, the tree under record 0 has %u", N, size[0]);
+  }
   for (size_t i = 0; i < s->num_triangles; i++)
     for (int k = 0; k < 3; k++)
       if (s->triangles[i].v[k] >= s->num_vertices)

@@ -202,6 +202,10 @@ void hj_default_render_opts(hj_render_opts* opts);
  * and the bind-group plumbing (src/main.rs:808-855).  Validates the same
  * invariants the reference asserts (src/main.rs:562-565) plus index ranges,
  * copies, and re-lays the data out for the kernels (same boxes, same leaves, same visiting order per ray: DESIGN.md 4).
+ * scene->bvh must be what Scene::compile flattens (src/main.rs:203-231): a binary tree in pre-order with skip links (left child =
+ * next record, its exit = the right child, a node's exit = the record behind its subtree or, on the right spine, any index >= the
+ * node count); the boxes may be anything (a box that does not bound its subtree just culls what the reference would cull), other
+ * link structures return HJ_ERR_INVALID.
  * Limit: the device node array is 32 bytes per record and must fit in 4 GiB (about 134 M records = 67 M shapes);
  * larger trees return HJ_ERR_UNSUPPORTED. */
 int hj_scene_upload(hj_context* ctx, const hj_scene_desc* scene);

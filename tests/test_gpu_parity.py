@@ -268,6 +268,55 @@ def test_uploaded_tree_with_inconsistent_boxes(gpu_renderer, oracle):
     assert_same(got, want, "shrunk inner boxes")
 
 
+@pytest.fixture
+def device_relayout(monkeypatch):
+    """hj_scene_upload's re-layout on the device (api/scene_relayout.hip) forced for every tree, not only the large ones."""
+    monkeypatch.setenv("HJ_UPLOAD_DEVICE", "1")
+
+
+def test_device_relayout_matches_the_oracle(gpu_renderer, oracle, cbox, cbox_spheres, device_relayout):
+    """The kernels' tree derived ON THE DEVICE (collapse by levels, pair nodes, hot-first order, sibling groups or pre-order):
+    every scene kind bit for bit against the oracle, with and without pair nodes, both node orders, a tree with shrunk inner
+    boxes (still a tree: device path, the collapse must keep those nodes); a skip-link array that is NOT a tree is refused."""
+    W = H = 128
+    blocks = host.make_blocks(W, H, 2, 21)
+    for name, cs in (("cbox", cbox), ("spheres", cbox_spheres), ("rich", scenes.rich_scene()), ("random", scenes.random_scene(3)),
+                     ("mesh 20k", host.Scene.synthetic(host.SYNTH_CBOX_MESH, mesh_triangles=20000).compile())):
+        want, ctr, _ = oracle.render_blocks(cs, blocks, W, H)
+        got, st = render(gpu_renderer, cs, W, H, blocks)
+        assert_same(got, want, f"device re-layout, {name}")
+        assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"]
+    want, _, _ = oracle.render_blocks(cbox, blocks, W, H)
+    for env in ({"HJ_PAIR_LEAVES": "0"}, {"HJ_NODE_ORDER": "1"}, {"HJ_NODE_ORDER": "0", "HJ_COLLAPSE_PCT": "0"}, {"HJ_COLLAPSE_PCT": "1000"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            got, _ = render(gpu_renderer, cbox, W, H, blocks)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        assert_same(got, want, f"device re-layout with {env}")
+    cs = host.Scene.synthetic(host.SYNTH_CBOX, mesh_triangles=1280).compile()
+    f = cs.bvh_f32
+    inner = np.nonzero(cs.bvh[:, 3] == 0xFFFFFFFF)[0]
+    for i in np.random.default_rng(5).choice(inner[1:], size=len(inner) // 3, replace=False):
+        c = 0.5 * (f[i, 0:3] + f[i, 4:7])
+        f[i, 0:3], f[i, 4:7] = c + (f[i, 0:3] - c) * 0.8, c + (f[i, 4:7] - c) * 0.8
+    want, _, _ = oracle.render_blocks(cs, blocks, W, H)
+    assert_same(render(gpu_renderer, cs, W, H, blocks)[0], want, "device re-layout, shrunk inner boxes")
+    # not a tree: hj_scene_upload refuses links that are not a pre-order skip-link tree (boxes may be anything, links may not:
+    # camera packets, the collapse and the node order lean on "a subtree is left only through its root's exit")
+    cs = host.Scene.synthetic(host.SYNTH_CBOX, mesh_triangles=320).compile()
+    nodes = cs.bvh
+    i = int(np.nonzero(nodes[:, 3] == 0xFFFFFFFF)[0][5])
+    r = int(nodes[i + 1, 7])
+    assert int(nodes[r, 7]) < len(nodes) - 1
+    nodes[r, 7] = int(nodes[r, 7]) + 1
+    with pytest.raises(abi.HijikiError, match="not a pre-order skip-link tree"):
+        gpu_renderer.upload_scene(cs)
+    gpu_renderer.upload_scene(cbox)
+
+
 def _check_skip_link_tree(nodes, boxes_of_shapes):
     """The invariants of the reference's flattened tree (src/main.rs:203-231) on an (N, 8) uint32 array."""
     N = len(nodes)
