@@ -439,7 +439,9 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     const int big = (int)(s->num_bvh_nodes >= (size_t)env_int("HJ_STREAM_MIN_NODES", 300000, 0, 1 << 30));
     const int res = env_int("HJ_LIGHT_GRID", big ? 0 : 64, 0, 256);
     LightGrid lg;
-    if (res >= 2 && build_light_grid(s, (uint32_t)res, lg)) {
+    bool have_grid = false;
+    try { have_grid = res >= 2 && build_light_grid(s, (uint32_t)res, lg); } catch (const std::exception&) { have_grid = false; }   // (out of host memory: no grid)
+    if (have_grid) {
       HJ_UP(upload(ctx, lg.bits.data(), lg.bits.size(), &d.light_grid));
       d.lg_res = lg.res;
       for (int k = 0; k < 3; k++) { d.lg_lo[k] = lg.lo[k]; d.lg_inv[k] = lg.inv[k]; }
