@@ -355,6 +355,12 @@ int hj_reduce_framebuffers(hj_context* const* ctxs, int n, int root);
  *   framebuffer untouched. */
 int hj_debug_trace(hj_context* ctx, const float* rays, size_t n, uint32_t use_bvh, uint32_t any_hit, float* hits);
 int hj_debug_samples(hj_context* ctx, const hj_image_block* block, const hj_render_opts* opts, float* samples);
+/* hj_debug_light_grid: the light-shaft visibility grid hj_scene_upload would build for `scene` (pure host code: no context,
+ *   no GPU).  Returns the cells per axis (0: nothing can be proven for this scene).  bits (may be NULL) = res^3 bytes, x fastest:
+ *   bit e of a cell set = every next-event shadow ray from a hit point in that cell to emitter e is unoccluded; the cell of a
+ *   point p along axis k is (int)((p[k] - lo[k]) * inv[k]) in float arithmetic; stats = cells that hold a surface, cells whose
+ *   surfaces lie in one plane, (cell, emitter) pairs proven free.  tests/test_light_grid.py attacks the claim with the oracle. */
+int hj_debug_light_grid(const hj_scene_desc* scene, uint32_t res, uint8_t* bits, float lo[3], float inv[3], uint64_t stats[3]);
 
 /* The deterministic replacement of `rand::random()` in the block generator.
  * Pure functions (no context); the same definitions are used by the host
