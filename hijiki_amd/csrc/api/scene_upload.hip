@@ -221,11 +221,48 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
   // device node array (kernels/hj_device.h): redundant inner nodes dropped, hottest (largest surface area) nodes
   // first, explicit left/exit links.
   {
-    const size_t N = s->num_bvh_nodes;
+    // Guard nodes for sphere leaves (HJ_SPHERE_GUARDS, default on).  The reference never tests a leaf's box: every ray that
+    // enters the box of a sphere leaf's parent stops at the leaf and runs the sphere test - a leaf stop ends the lane's burst -
+    // and the parent's box, the union with a sibling, is much larger than the sphere.  Here the leaf gets a one-child inner
+    // node in front of it whose box is the sphere's OWN bounds padded by a thousandth of the radius (plus an absolute 2e-4):
+    // an ordinary box step (no new code in the walk) that fails for most of those rays and sends them to the leaf's exit.
+    // Exact: a ray that fails this box test cannot pass the sphere test (sphere.glsl:18-41) - it misses the padded box, or
+    // enters it behind tMax (the sphere lies at least the padding further on), or leaves it before tMin (the far root lies
+    // at least the padding earlier) - with the padding orders of magnitude above float rounding in either test.
+    std::vector<hj_bvh_node> guarded;
+    const hj_bvh_node* bvh = s->bvh;
+    size_t N = s->num_bvh_nodes;
+    if (s->num_spheres != 0 && env_int("HJ_SPHERE_GUARDS", 1, 0, 1) != 0) {
+      std::vector<uint32_t> before(N + 1, 0);                 // sphere leaves in front of node i
+      for (size_t i = 0; i < N; i++) before[i + 1] = before[i] + ((s->bvh[i].shape_index != HJ_BVH_INNER && s->bvh[i].shape_index < s->num_spheres) ? 1u : 0u);
+      if (before[N] != 0 && N + before[N] < 0x3FFFFFFFu) {
+        guarded.reserve(N + before[N]);
+        auto moved = [&](uint32_t e) { return e < N ? e + before[e] : e + before[N]; };      // (an exit beyond the array stays beyond it)
+        for (size_t i = 0; i < N; i++) {
+          hj_bvh_node nd = s->bvh[i];
+          nd.exit_index = moved(nd.exit_index);
+          if (nd.shape_index != HJ_BVH_INNER && nd.shape_index < s->num_spheres) {
+            const hj_sphere& sp = s->spheres[nd.shape_index];
+            const float r = std::fabs(sp.radius), pad = r * 1e-3f + 2e-4f;
+            hj_bvh_node g = nd;
+            g.shape_index = HJ_BVH_INNER;
+            for (int k = 0; k < 3; k++) {
+              g.aabb_min[k] = std::nextafter((sp.center[k] - r) - pad, -INFINITY);
+              g.aabb_max[k] = std::nextafter((sp.center[k] + r) + pad, INFINITY);
+            }
+            if (!(r == r) || !std::isfinite(pad)) { g.aabb_min[0] = g.aabb_min[1] = g.aabb_min[2] = -INFINITY; g.aabb_max[0] = g.aabb_max[1] = g.aabb_max[2] = INFINITY; }
+            guarded.push_back(g);
+          }
+          guarded.push_back(nd);
+        }
+        bvh = guarded.data();
+        N = guarded.size();
+      }
+    }
     std::vector<float> sa(N);
     for (size_t i = 0; i < N; i++) {
-      const float dx = s->bvh[i].aabb_max[0] - s->bvh[i].aabb_min[0], dy = s->bvh[i].aabb_max[1] - s->bvh[i].aabb_min[1],
-                  dz = s->bvh[i].aabb_max[2] - s->bvh[i].aabb_min[2];
+      const float dx = bvh[i].aabb_max[0] - bvh[i].aabb_min[0], dy = bvh[i].aabb_max[1] - bvh[i].aabb_min[1],
+                  dz = bvh[i].aabb_max[2] - bvh[i].aabb_min[2];
       sa[i] = (dx >= 0 && dy >= 0 && dz >= 0) ? dx * dy + dy * dz + dz * dx : 0.f;
       if (!(sa[i] == sa[i])) sa[i] = 0.f;                       // (inf * 0: keep the sort's comparison a strict weak order)
     }
@@ -238,17 +275,18 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     std::vector<char> del(N, 0);
     {
       const float thr = (float)env_int("HJ_COLLAPSE_PCT", 50, 0, 1000) / 100.0f;
-      auto inner = [&](size_t i) { return s->bvh[i].shape_index == HJ_BVH_INNER; };
+      auto inner = [&](size_t i) { return bvh[i].shape_index == HJ_BVH_INNER; };
       auto inside = [&](size_t c, size_t p) {   // false for NaN bounds
         bool ok = true;
         for (int k = 0; k < 3; k++)
-          ok = ok && s->bvh[c].aabb_min[k] >= s->bvh[p].aabb_min[k] && s->bvh[c].aabb_max[k] <= s->bvh[p].aabb_max[k];
+          ok = ok && bvh[c].aabb_min[k] >= bvh[p].aabb_min[k] && bvh[c].aabb_max[k] <= bvh[p].aabb_max[k];
         return ok;
       };
       std::vector<float> anc(N, 0.f);   // area of the nearest kept ancestor
       for (size_t i = 0; i < N; i++) {  // pre-order: ancestors come first
         if (!inner(i) || i + 1 >= N) continue;
-        const size_t l = i + 1, r = s->bvh[l].exit_index;
+        const size_t l = i + 1, r = bvh[l].exit_index;
+        if (bvh[l].exit_index == bvh[i].exit_index) { anc[l] = sa[i]; continue; }   // a sphere leaf's guard node: one child
         if (r >= N || r <= l) continue;                       // not a well-formed pre-order pair: leave it alone
         // (an uploaded tree whose child boxes stick out of P's box keeps P: the argument above needs containment)
         if (i != 0 && inner(l) && inner(r) && anc[i] > 0.f && sa[i] > thr * anc[i] && inside(l, i) && inside(r, i)) del[i] = 1;
@@ -271,12 +309,12 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     if (pair_env == 1 || (pair_env < 0 && N >= (size_t)env_int("HJ_PAIR_MIN_NODES", 0, 0, 1 << 30))) {
       const size_t first_tri = s->num_spheres + s->num_quads;
       for (size_t i = 0; i + 2 < N; i++) {
-        if (s->bvh[i].shape_index != HJ_BVH_INNER) continue;
-        const size_t l = i + 1, r = s->bvh[l].exit_index;
+        if (bvh[i].shape_index != HJ_BVH_INNER) continue;
+        const size_t l = i + 1, r = bvh[l].exit_index;
         if (r >= N || r != l + 1) continue;
-        const uint32_t sl = s->bvh[l].shape_index, sr = s->bvh[r].shape_index;
+        const uint32_t sl = bvh[l].shape_index, sr = bvh[r].shape_index;
         if (sl == HJ_BVH_INNER || sr == HJ_BVH_INNER || sl < first_tri || sr < first_tri) continue;
-        if (s->bvh[r].exit_index != s->bvh[i].exit_index) continue;      // (a well-formed tree: the right child's exit is its parent's)
+        if (bvh[r].exit_index != bvh[i].exit_index) continue;      // (a well-formed tree: the right child's exit is its parent's)
         pair_of[i] = (uint32_t)(pairs.size() / 6);
         for (uint32_t sh : {sl, sr}) {
           const size_t t = sh - first_tri;
@@ -318,13 +356,13 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
       while (!stack.empty()) {
         const uint32_t i = stack.back();
         stack.pop_back();
-        const hj_bvh_node& nd = s->bvh[i];
+        const hj_bvh_node& nd = bvh[i];
         if (nd.shape_index != HJ_BVH_INNER || pair_of[i] != 0xFFFFFFFFu) continue;
         const size_t end = nd.exit_index < N ? resolve(nd.exit_index) : N;
         kids.clear();
         for (size_t c = resolve((size_t)i + 1); c < N && c != end;) {
           kids.push_back((uint32_t)c);
-          const uint32_t e = s->bvh[c].exit_index;
+          const uint32_t e = bvh[c].exit_index;
           c = e < N ? resolve(e) : N;
         }
         uint32_t cold = 0;
@@ -340,7 +378,7 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     std::vector<float4> dev(2 * M_all, make_float4(0.f, 0.f, 0.f, 0.f));
     for (size_t i = 0; i < N; i++) {
       if (del[i]) continue;
-      const hj_bvh_node& nd = s->bvh[i];
+      const hj_bvh_node& nd = bvh[i];
       uint32_t a;
       if (nd.shape_index != HJ_BVH_INNER) a = nd.shape_index;
       else if (pair_of[i] != 0xFFFFFFFFu) a = hj::kInnerFlag | hj::kPairFlag | pair_of[i];
@@ -360,7 +398,7 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     d.num_nodes = (uint32_t)M_all;
     d.root = N ? map[0] : 0u;
     d.num_hot = hot;
-    finish_tree_settings(d, N, M, !pairs.empty());
+    finish_tree_settings(d, s->num_bvh_nodes, M, !pairs.empty());
     // The walk adds 32 * index to the low word of the array's address without a carry (kernels/hj_walk.h): the
     // array must not cross a 4 GiB boundary.  Allocate twice the size and start at the boundary if it would.
     {
