@@ -221,10 +221,10 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
   // device node array (kernels/hj_device.h): redundant inner nodes dropped, hottest (largest surface area) nodes
   // first, explicit left/exit links.
   {
-    // Guard nodes for sphere leaves (HJ_SPHERE_GUARDS, default on).  The reference never tests a leaf's box: every ray that
+    // Guard nodes for single leaves (HJ_LEAF_GUARDS).  The reference never tests a leaf's box: every ray that
     // enters the box of a sphere leaf's parent stops at the leaf and runs the sphere test - a leaf stop ends the lane's burst -
     // and the parent's box, the union with a sibling, is much larger than the sphere.  Here the leaf gets a one-child inner
-    // node in front of it whose box is the sphere's OWN bounds padded by a thousandth of the radius (plus an absolute 2e-4):
+    // node in front of it whose box is the sphere's OWN bounds padded by a thousandth of its size (plus an absolute 2e-4):
     // an ordinary box step (no new code in the walk) that fails for most of those rays and sends them to the leaf's exit.
     // Exact: a ray that fails this box test cannot pass the sphere test (sphere.glsl:18-41) - it misses the padded box, or
     // enters it behind tMax (the sphere lies at least the padding further on), or leaves it before tMin (the far root lies
@@ -232,25 +232,62 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     std::vector<hj_bvh_node> guarded;
     const hj_bvh_node* bvh = s->bvh;
     size_t N = s->num_bvh_nodes;
-    if (s->num_spheres != 0 && env_int("HJ_SPHERE_GUARDS", 1, 0, 1) != 0) {
-      std::vector<uint32_t> before(N + 1, 0);                 // sphere leaves in front of node i
-      for (size_t i = 0; i < N; i++) before[i + 1] = before[i] + ((s->bvh[i].shape_index != HJ_BVH_INNER && s->bvh[i].shape_index < s->num_spheres) ? 1u : 0u);
-      if (before[N] != 0 && N + before[N] < 0x3FFFFFFFu) {
-        guarded.reserve(N + before[N]);
-        auto moved = [&](uint32_t e) { return e < N ? e + before[e] : e + before[N]; };      // (an exit beyond the array stays beyond it)
-        for (size_t i = 0; i < N; i++) {
+    // HJ_LEAF_GUARDS: 0 none, 1 sphere leaves, 2 (default) every leaf that does not become half of a pair node (a padded box is
+    // exact in front of ANY shape: the ray enters it at least the padding before it can reach the shape).  c3 +1 ... 2.7 % with
+    // the spheres' guards, another +1 % on c2 and c3 with the single triangles' (profiles/r05_ab_sphere_guards.txt).
+    const int guard_mode = env_int("HJ_LEAF_GUARDS", 2, 0, 2);
+    if (guard_mode != 0 && (s->num_spheres != 0 || guard_mode == 2)) {
+      const size_t n0 = N, first_tri = s->num_spheres + s->num_quads;
+      std::vector<uint8_t> want(n0, 0);
+      for (size_t i = 0; i < n0; i++) {
+        const uint32_t sh = s->bvh[i].shape_index;
+        if (sh == HJ_BVH_INNER) continue;
+        want[i] = guard_mode == 2 || sh < s->num_spheres;
+      }
+      if (guard_mode == 2)                                    // the two triangle leaves of a future pair node keep their parent's box as their guard
+        for (size_t i = 0; i + 2 < n0; i++) {
+          if (s->bvh[i].shape_index != HJ_BVH_INNER) continue;
+          const size_t l = i + 1, r = s->bvh[l].exit_index;
+          if (r != l + 1 || s->bvh[l].shape_index == HJ_BVH_INNER || s->bvh[r].shape_index == HJ_BVH_INNER) continue;
+          if (s->bvh[l].shape_index >= first_tri && s->bvh[r].shape_index >= first_tri) want[l] = want[r] = 0;
+        }
+      std::vector<uint32_t> before(n0 + 1, 0);               // guards in front of node i
+      for (size_t i = 0; i < n0; i++) before[i + 1] = before[i] + want[i];
+      if (before[n0] != 0 && n0 + before[n0] < 0x3FFFFFFFu) {
+        guarded.reserve(n0 + before[n0]);
+        auto moved = [&](uint32_t e) { return e < n0 ? e + before[e] : e + before[n0]; };      // (an exit beyond the array stays beyond it)
+        for (size_t i = 0; i < n0; i++) {
           hj_bvh_node nd = s->bvh[i];
           nd.exit_index = moved(nd.exit_index);
-          if (nd.shape_index != HJ_BVH_INNER && nd.shape_index < s->num_spheres) {
-            const hj_sphere& sp = s->spheres[nd.shape_index];
-            const float r = std::fabs(sp.radius), pad = r * 1e-3f + 2e-4f;
+          if (want[i]) {
+            // the shape's own bounds, outward, padded
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, size = 0.f;
+            auto grow = [&](float x, float y, float z) { const float p[3] = {x, y, z}; for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } };
+            const uint32_t sh = nd.shape_index;
+            if (sh < s->num_spheres) {
+              const hj_sphere& sp = s->spheres[sh];
+              const float r = std::fabs(sp.radius);
+              grow(sp.center[0] - r, sp.center[1] - r, sp.center[2] - r); grow(sp.center[0] + r, sp.center[1] + r, sp.center[2] + r);
+              size = r;
+            } else if (sh < first_tri) {
+              const hj_quad& q = s->quads[sh - s->num_spheres];
+              for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++)
+                grow(q.origin[0] + a * q.edge1[0] + b * q.edge2[0], q.origin[1] + a * q.edge1[1] + b * q.edge2[1], q.origin[2] + a * q.edge1[2] + b * q.edge2[2]);
+            } else {
+              const hj_triangle& t = s->triangles[sh - first_tri];
+              for (int c = 0; c < 3; c++) grow(s->vertices[t.v[c]].pos[0], s->vertices[t.v[c]].pos[1], s->vertices[t.v[c]].pos[2]);
+            }
+            for (int k = 0; k < 3; k++) size = std::max(size, hi[k] - lo[k]);
+            const float pad = size * 1e-3f + 2e-4f;
             hj_bvh_node g = nd;
             g.shape_index = HJ_BVH_INNER;
+            bool ok = std::isfinite(pad);
             for (int k = 0; k < 3; k++) {
-              g.aabb_min[k] = std::nextafter((sp.center[k] - r) - pad, -INFINITY);
-              g.aabb_max[k] = std::nextafter((sp.center[k] + r) + pad, INFINITY);
+              g.aabb_min[k] = std::nextafter(lo[k] - pad, -INFINITY);
+              g.aabb_max[k] = std::nextafter(hi[k] + pad, INFINITY);
+              ok = ok && g.aabb_min[k] <= g.aabb_max[k];
             }
-            if (!(r == r) || !std::isfinite(pad)) { g.aabb_min[0] = g.aabb_min[1] = g.aabb_min[2] = -INFINITY; g.aabb_max[0] = g.aabb_max[1] = g.aabb_max[2] = INFINITY; }
+            if (!ok) for (int k = 0; k < 3; k++) { g.aabb_min[k] = -INFINITY; g.aabb_max[k] = INFINITY; }   // (NaN geometry: a box every ray enters)
             guarded.push_back(g);
           }
           guarded.push_back(nd);
