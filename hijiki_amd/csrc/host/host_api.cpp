@@ -182,6 +182,13 @@ int hjh_compiled_set_bvh(hjh_compiled* c, const hj_bvh_node* nodes, size_t n) {
     return (int)HJ_OK;
   });
 }
+int hjh_compiled_tune_bvh(hjh_compiled* c, int reinsert_passes, size_t vote_paths) {
+  if (!c) return fail(HJ_ERR_INVALID, "null argument");
+  return guarded([&] {
+    tune_bvh(c->cs, reinsert_passes, vote_paths);
+    return (int)HJ_OK;
+  });
+}
 size_t hjh_compiled_packed_size(const hjh_compiled* c) { return c ? c->cs.packed_size() : 0; }
 int hjh_compiled_pack(const hjh_compiled* c, void* buffer, size_t size) {
   if (!c || !buffer) return fail(HJ_ERR_INVALID, "null argument");

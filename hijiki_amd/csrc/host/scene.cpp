@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <functional>
 #include <future>
 #include <numeric>
 #include <stdexcept>
@@ -319,6 +320,118 @@ std::vector<BuildNode> build_bvh(const std::vector<Aabb>& boxes) {
   return std::move(b.nodes);
 }
 
+// The flattening step of Scene::compile (src/main.rs:203-231): pre-order numbering, every node stores the box its PARENT kept
+// for it, exit links.  `global_index` maps a leaf's shape to the index the kernels use.
+void flatten_bvh(const std::vector<BuildNode>& tree, const std::function<uint32_t(int32_t)>& global_index, std::vector<hj_bvh_node>& out_bvh) {
+  // pass 1: pre-order numbering, left before right (src/main.rs:203-213)
+  std::vector<uint32_t> slot(tree.size(), 0);
+  {
+    std::vector<int32_t> st{0};
+    uint32_t next = 0;
+    while (!st.empty()) {
+      int32_t nd = st.back();
+      st.pop_back();
+      slot[nd] = next++;
+      if (tree[nd].shape < 0) {
+        st.push_back(tree[nd].right);
+        st.push_back(tree[nd].left);
+      }
+    }
+  }
+  // pass 2: every node stores the box its PARENT kept for it; exit of a left
+  // child = its right sibling, of a right child = the parent's exit, of the
+  // root = 1 000 000 (src/main.rs:214-231).
+  out_bvh.resize(tree.size());
+  struct Work { int32_t node; Aabb box; uint32_t exit; };
+  Aabb root_box = tree[0].left_box;
+  root_box.join(tree[0].right_box);  // src/main.rs:230
+  std::vector<Work> st;
+  // The reference hard-codes 1 000 000 (src/main.rs:231); with more than a million nodes that
+  // index lies INSIDE the array and the shader's walk would never terminate, so larger trees
+  // get the node count instead (any value >= the node count ends the walk).
+  const uint32_t root_exit = tree.size() > HJ_BVH_ROOT_EXIT ? (uint32_t)tree.size() : HJ_BVH_ROOT_EXIT;
+  st.push_back({0, root_box, root_exit});
+  while (!st.empty()) {
+    Work w = st.back();
+    st.pop_back();
+    const BuildNode& bn = tree[w.node];
+    hj_bvh_node& nd = out_bvh[slot[w.node]];
+    std::memcpy(nd.aabb_min, w.box.lo, 12);
+    std::memcpy(nd.aabb_max, w.box.hi, 12);
+    nd.shape_index = bn.shape >= 0 ? global_index(bn.shape) : HJ_BVH_INNER;
+    nd.exit_index = w.exit;
+    if (bn.shape < 0) {
+      st.push_back({bn.right, bn.right_box, w.exit});
+      st.push_back({bn.left, bn.left_box, slot[bn.right]});
+    }
+  }
+}
+
+// The inverse: the binary tree of a flattened pre-order skip-link array (leaf shapes = the array's global shape indices).
+// Throws when the array is not such a tree.
+std::vector<BuildNode> unflatten_bvh(const std::vector<hj_bvh_node>& bvh) {
+  const size_t N = bvh.size();
+  if (N < 3) throw std::runtime_error("tree of fewer than three nodes");
+  std::vector<BuildNode> tree(N);
+  std::vector<uint32_t> size(N, 1);
+  auto box_of = [&](size_t i) { Aabb b; std::memcpy(b.lo, bvh[i].aabb_min, 12); std::memcpy(b.hi, bvh[i].aabb_max, 12); return b; };
+  for (size_t i = N; i-- > 0;) {
+    if (bvh[i].shape_index != HJ_BVH_INNER) { tree[i].shape = (int32_t)bvh[i].shape_index; continue; }
+    const size_t l = i + 1;
+    if (l >= N) throw std::runtime_error("not a pre-order skip-link tree");
+    const size_t r = l + size[l];
+    if (r >= N || bvh[l].exit_index != r) throw std::runtime_error("not a pre-order skip-link tree");
+    size[i] = 1 + size[l] + size[r];
+    tree[i].left = (int32_t)l; tree[i].right = (int32_t)r;
+    tree[i].left_box = box_of(l); tree[i].right_box = box_of(r);
+  }
+  if (size[0] != N) throw std::runtime_error("not a pre-order skip-link tree");
+  return tree;
+}
+
+// The scene model behind a compiled scene, shapes in the kernels' global order (spheres, quads, triangles): what the ray vote
+// needs to trace its sample when only the compiled arrays are at hand.
+Scene scene_of(const CompiledScene& cs) {
+  Scene s;
+  s.camera = cs.camera;
+  s.vertices = cs.vertices;
+  const size_t total = cs.spheres.size() + cs.quads.size() + cs.triangles.size();
+  if (cs.materials.size() != total) throw std::runtime_error("materials != shapes");
+  s.objects.reserve(total);
+  s.materials.reserve(total);
+  auto material = [&](uint32_t word) {
+    Material m{};
+    m.tag = (hj_material_tag)(word >> HJ_MATERIAL_TAG_SHIFT);
+    const uint32_t ix = word & HJ_MATERIAL_INDEX_MASK;
+    switch (m.tag) {
+      case HJ_MAT_DIFFUSE: if (ix < cs.diffuse.size()) m.diffuse = cs.diffuse[ix]; break;
+      case HJ_MAT_DIFFUSECBOARD: if (ix < cs.diffusecb.size()) m.cboard = cs.diffusecb[ix]; break;
+      case HJ_MAT_DIELECTRIC: if (ix < cs.dielectric.size()) m.dielectric = cs.dielectric[ix]; break;
+      case HJ_MAT_EMISSIVE: if (ix < cs.emissive.size()) m.emissive = cs.emissive[ix]; break;
+      default: break;
+    }
+    return m;
+  };
+  size_t k = 0;
+  auto add = [&](Shape sh) { s.materials.push_back(material(cs.materials[k])); s.objects.emplace_back(sh, (int)k); k++; };
+  for (const hj_sphere& sp : cs.spheres) { Shape sh{}; sh.kind = ShapeKind::Sphere; sh.sphere = sp; add(sh); }
+  for (const hj_quad& q : cs.quads) { Shape sh{}; sh.kind = ShapeKind::Quad; sh.quad = q; add(sh); }
+  for (const hj_triangle& t : cs.triangles) {
+    for (int c = 0; c < 3; c++) if (t.v[c] >= cs.vertices.size()) throw std::runtime_error("triangle refers to unknown vertex");
+    Shape sh{}; sh.kind = ShapeKind::Triangle; sh.tri = t; add(sh);
+  }
+  return s;
+}
+
+// The tree passes of compile() on an INSTALLED tree (hj_build_bvh_device's, or any tree a host brought): optional reinsertion,
+// then the ray-voted child order.  The image changes at most in epsilon ties, like with any other tree.
+void tune_bvh(CompiledScene& cs, int reinsert_passes, size_t vote_paths) {
+  std::vector<BuildNode> tree = unflatten_bvh(cs.bvh);
+  if (reinsert_passes > 0) optimize_by_reinsertion(tree, reinsert_passes);
+  if (vote_paths > 0) order_children_by_rays(tree, scene_of(cs), vote_paths);
+  flatten_bvh(tree, [](int32_t shape) { return (uint32_t)shape; }, cs.bvh);
+}
+
 // ---------------------------------------------------------------- compile
 
 CompiledScene compile(const Scene& scene) {
@@ -368,7 +481,7 @@ CompiledScene compile(const Scene& scene) {
     static const int child_order = [] { const char* e = std::getenv("HJ_BVH_CHILD_ORDER"); return e ? std::atoi(e) : 4; }();
     static const long vote_paths = [] { const char* e = std::getenv("HJ_BVH_VOTE_PATHS"); return e ? std::atol(e) : 0l; }();
     if (child_order >= 4) {
-      const size_t paths = vote_paths > 0 ? (size_t)vote_paths : std::min<size_t>(200000, std::max<size_t>(60000, n / 2));
+      const size_t paths = vote_paths > 0 ? (size_t)vote_paths : 60000;   // (more buys nothing: 8 k paths order cbox as 60 k do, 50 k the 1 M-triangle tree as 1 M do)
       order_children_by_rays(tree, scene, paths);
     }
   }
@@ -380,50 +493,7 @@ CompiledScene compile(const Scene& scene) {
       default: return ns + nq + index_in_kind[obj];
     }
   };
-  // pass 1: pre-order numbering, left before right (src/main.rs:203-213)
-  std::vector<uint32_t> slot(tree.size(), 0);
-  {
-    std::vector<int32_t> st{0};
-    uint32_t next = 0;
-    while (!st.empty()) {
-      int32_t nd = st.back();
-      st.pop_back();
-      slot[nd] = next++;
-      if (tree[nd].shape < 0) {
-        st.push_back(tree[nd].right);
-        st.push_back(tree[nd].left);
-      }
-    }
-  }
-  // pass 2: every node stores the box its PARENT kept for it; exit of a left
-  // child = its right sibling, of a right child = the parent's exit, of the
-  // root = 1 000 000 (src/main.rs:214-231).
-  out.bvh.resize(tree.size());
-  {
-    struct Work { int32_t node; Aabb box; uint32_t exit; };
-    Aabb root_box = tree[0].left_box;
-    root_box.join(tree[0].right_box);  // src/main.rs:230
-    std::vector<Work> st;
-    // The reference hard-codes 1 000 000 (src/main.rs:231); with more than a million nodes that
-    // index lies INSIDE the array and the shader's walk would never terminate, so larger trees
-    // get the node count instead (any value >= the node count ends the walk).
-    const uint32_t root_exit = tree.size() > HJ_BVH_ROOT_EXIT ? (uint32_t)tree.size() : HJ_BVH_ROOT_EXIT;
-    st.push_back({0, root_box, root_exit});
-    while (!st.empty()) {
-      Work w = st.back();
-      st.pop_back();
-      const BuildNode& bn = tree[w.node];
-      hj_bvh_node& nd = out.bvh[slot[w.node]];
-      std::memcpy(nd.aabb_min, w.box.lo, 12);
-      std::memcpy(nd.aabb_max, w.box.hi, 12);
-      nd.shape_index = bn.shape >= 0 ? global_index(bn.shape) : HJ_BVH_INNER;
-      nd.exit_index = w.exit;
-      if (bn.shape < 0) {
-        st.push_back({bn.right, bn.right_box, w.exit});
-        st.push_back({bn.left, bn.left_box, slot[bn.right]});
-      }
-    }
-  }
+  flatten_bvh(tree, global_index, out.bvh);
 
   // material words (src/main.rs:246-287)
   std::vector<uint32_t> reprs;

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -81,6 +82,11 @@ std::vector<BuildNode> build_bvh(const std::vector<Aabb>& boxes);  // node 0 is 
 // order of every node's two children voted by a sample of the rays the renderer will trace through `scene`.
 double optimize_by_reinsertion(std::vector<BuildNode>& nodes, int passes);
 size_t order_children_by_rays(std::vector<BuildNode>& nodes, const Scene& scene, size_t num_paths);
+// Flattening (src/main.rs:203-231) and its inverse; the tree passes on an installed tree (scene.cpp).
+void flatten_bvh(const std::vector<BuildNode>& tree, const std::function<uint32_t(int32_t)>& global_index, std::vector<hj_bvh_node>& out_bvh);
+std::vector<BuildNode> unflatten_bvh(const std::vector<hj_bvh_node>& bvh);
+Scene scene_of(const CompiledScene& cs);
+void tune_bvh(CompiledScene& cs, int reinsert_passes, size_t vote_paths);
 
 // Synthetic bench scenes.
 Scene make_synthetic(int kind, uint32_t mesh_triangles, uint32_t gen_seed);

@@ -52,6 +52,7 @@ def lib():
         L.hjh_compiled_packed_size.restype = C.c_size_t
         L.hjh_compiled_pack.argtypes = [vp, vp, C.c_size_t]
         L.hjh_compiled_set_bvh.argtypes = [vp, C.POINTER(abi.BvhNode), C.c_size_t]
+        L.hjh_compiled_tune_bvh.argtypes = [vp, C.c_int, C.c_size_t]
         L.hjh_num_blocks_per_pass.argtypes = [C.c_uint32] * 3
         L.hjh_num_blocks_per_pass.restype = C.c_size_t
         L.hjh_make_blocks.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
@@ -246,6 +247,12 @@ class CompiledScene:
         of `device.Renderer.build_bvh`."""
         nodes = np.ascontiguousarray(nodes, np.uint32).reshape(-1, 8)
         _check(lib().hjh_compiled_set_bvh(self._h, nodes.ctypes.data_as(C.POINTER(abi.BvhNode)), len(nodes)))
+        _check(lib().hjh_compiled_desc(self._h, C.byref(self.desc)))
+
+    def tune_bvh(self, reinsert_passes=0, vote_paths=60000):
+        """hjh_compiled_tune_bvh: compile()'s tree passes (insertion-based optimisation, ray-voted child order) on the installed
+        tree, e.g. after `set_bvh(renderer.build_bvh(self))`."""
+        _check(lib().hjh_compiled_tune_bvh(self._h, int(reinsert_passes), int(vote_paths)))
         _check(lib().hjh_compiled_desc(self._h, C.byref(self.desc)))
 
     def packed(self):

@@ -65,6 +65,11 @@ void hjh_compiled_destroy(hjh_compiled* c);
 int  hjh_compiled_desc(const hjh_compiled* c, hj_scene_desc* out);
 /* Replace the tree (e.g. by the one hj_build_bvh_device made from this scene's shapes); n must be 2 * shapes - 1. */
 int  hjh_compiled_set_bvh(hjh_compiled* c, const hj_bvh_node* nodes, size_t n);
+/* The tree passes of hjh_scene_compile on the INSTALLED tree (e.g. hj_build_bvh_device's): `reinsert_passes` passes of the
+ * insertion-based optimisation, then - when vote_paths != 0 - the order of every node's two children voted by that many sampled
+ * camera paths (60000 is what compile uses).  The tree must be a pre-order skip-link tree; the image changes at most in epsilon
+ * ties, as with any other tree over the same shapes. */
+int  hjh_compiled_tune_bvh(hjh_compiled* c, int reinsert_passes, size_t vote_paths);
 /* Size of the reference's packed scene buffer (12 sub-buffers padded to
  * 256 B, src/main.rs:314-339) and the packing itself (src/main.rs:561-605),
  * for tools that want the reference's exact buffer image. */

@@ -225,3 +225,60 @@ def test_tree_passes_change_the_walk_not_the_image(tmp_path):
     assert best["sah"] < 0.995 * full["sah"] and best["nodes"] < 0.97 * full["nodes"], (full, best)    # (measured: -0.9 %, -4.6 %)
     assert full["sah"] < 0.99 * plain["sah"] and abs(ordered["sah"] - plain["sah"]) < 1e-6 * plain["sah"]   # (measured: -2.4 %)
     assert ordered["nodes"] < 0.97 * plain["nodes"] and full["nodes"] < 0.98 * ordered["nodes"], (plain, ordered, full)
+
+
+def test_tune_bvh_on_an_installed_tree(oracle):
+    """hjh_compiled_tune_bvh: compile()'s tree passes on a tree that came from elsewhere (here: compile's own tree with every
+    inner node's children exchanged - a valid tree in a poor order).  The result is a valid flattened tree over the same shapes,
+    the frame is the same, the reference walk visits fewer nodes."""
+    import hashlib
+    from test_gpu_parity import _check_skip_link_tree, _shape_boxes
+    cs = host.Scene.synthetic(host.SYNTH_CBOX_SPHERES).compile()
+    blocks = host.make_blocks(96, 64, 2, 5)
+    want, c_best, _ = oracle.render_blocks(cs, blocks, 96, 64)
+    # exchange the children of every inner node: re-flatten by hand
+    nodes = cs.bvh.copy()
+    N = len(nodes)
+    out = np.zeros_like(nodes)
+    pos = [0]
+
+    def emit(i, exit_index):
+        me = pos[0]
+        pos[0] += 1
+        out[me] = nodes[i]
+        if nodes[i, 3] == 0xFFFFFFFF:
+            l, r = i + 1, int(nodes[i + 1, 7])
+            first = emit(r, None)                       # the right child first
+            second_at = pos[0]
+            emit(l, None)
+            fix.append((first, second_at))
+        return me
+
+    fix = []
+    import sys
+    sys.setrecursionlimit(10000)
+    emit(0, None)
+
+    def set_exits(me, exit_index):
+        out[me, 7] = exit_index
+        if out[me, 3] == 0xFFFFFFFF:
+            second = second_of[me + 1]
+            set_exits(me + 1, second)
+            set_exits(second, exit_index)
+
+    second_of = dict(fix)
+    set_exits(0, int(nodes[0, 7]))
+    cs.set_bvh(out)
+    _check_skip_link_tree(cs.bvh, _shape_boxes(cs))
+    got, c_swapped, _ = oracle.render_blocks(cs, blocks, 96, 64)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == hashlib.sha256(want.tobytes()).hexdigest()
+    cs.tune_bvh(reinsert_passes=0, vote_paths=60000)
+    _check_skip_link_tree(cs.bvh, _shape_boxes(cs))
+    got, c_tuned, _ = oracle.render_blocks(cs, blocks, 96, 64)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == hashlib.sha256(want.tobytes()).hexdigest()
+    assert c_tuned["nodes"] < 0.97 * c_swapped["nodes"] and c_tuned["nodes"] < 1.02 * c_best["nodes"], (c_best["nodes"], c_swapped["nodes"], c_tuned["nodes"])
+    with pytest.raises(abi.HijikiError):
+        bad = cs.bvh.copy()
+        bad[1, 7] += 1                                  # not a tree any more
+        cs.set_bvh(bad)
+        cs.tune_bvh()

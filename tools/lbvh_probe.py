@@ -36,5 +36,8 @@ for name, kind, tris, size, spp in (("cbox", host.SYNTH_CBOX, 0, 1024, 512), ("1
             else: os.environ[k] = v
         cs.set_bvh(nodes)
         v = rate()
+        t = time.time(); cs.tune_bvh(0, 60000); t_tune = time.time() - t      # the ray-voted child order on the device-built tree
+        v2 = rate()
         cs.set_bvh(host_nodes)
-        print(f"  device build ({label}): {t_dev*1e3:.1f} ms, {v:.0f} Mpaths/s = {v / base:.3f} of the host tree", flush=True)
+        print(f"  device build ({label}): {t_dev*1e3:.1f} ms, {v:.0f} Mpaths/s = {v / base:.3f} of the host tree; + hjh_compiled_tune_bvh "
+              f"(vote, {t_tune*1e3:.0f} ms): {v2:.0f} Mpaths/s = {v2 / base:.3f}", flush=True)
