@@ -516,6 +516,10 @@ def main():
                                      "reconstruct_sum_ms": round(agg["reconstruct_ms"] / args.steps, 3),
                                      "total_ms": round(agg["total_ms"] / args.steps, 3)}
         out["rays_per_path"] = round((agg["closest_rays"] + agg["shadow_rays"]) / max(1, agg["paths"]), 3)
+        # next-event shadow rays the light-shaft grid proved unoccluded: counted in rays_per_path (they are intersectScene(shadowRay)
+        # calls of the reference), never traced
+        out["shadow_rays_proven_free_share"] = round(agg.get("shadow_rays_proven_free", 0) / max(1, agg["shadow_rays"]), 4)
+        out["rays_walked_per_path"] = round((agg["closest_rays"] + agg["shadow_rays"] - agg.get("shadow_rays_proven_free", 0)) / max(1, agg["paths"]), 3)
         if secondary:
             out["secondary"] = {}
             for name, r in secondary.items():
@@ -531,6 +535,7 @@ def main():
                     "blocking_frame_ms": None if r["latency_ms"] is None else round(r["latency_ms"], 3),
                     "value_blocking": None if not r["latency_ms"] else round(r["W"] * r["H"] * r["spp"] / (r["latency_ms"] * 1e-3) / 1e6, 3),
                     "rays_per_path": round((r["agg"]["closest_rays"] + r["agg"]["shadow_rays"]) / max(1, r["agg"]["paths"]), 3),
+                    "shadow_rays_proven_free_share": round(r["agg"].get("shadow_rays_proven_free", 0) / max(1, r["agg"]["shadow_rays"]), 4),
                     "roofline": roofline_block(name, r["agg"], r["elapsed"], r["steps"], world, True)}
         print(json.dumps(out), flush=True)
     if world > 1:
