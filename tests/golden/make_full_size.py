@@ -16,7 +16,7 @@ configuration) and this script commits, per configuration, `full_size_<config>.j
 batching and compare digest + counters.  The reference itself cannot produce these values anywhere in this project
 (SURVEY 8(c)): they pin the HIP path to the ORACLE at full size, nothing more.
 
-    python tests/golden/make_full_size.py [c2 c3 c4 c5p ...]      # default: all four
+    python tests/golden/make_full_size.py [c2 c3 c4 c5p c2s2 c2s3 ...]      # default: all
 """
 import hashlib
 import json
@@ -40,6 +40,10 @@ FULL_SIZE = {
     # configs[4]'s frame: the pass prefix [0, 8) of its 4096 passes (the whole frame is 2^36 paths = hours of CPU); the GPU
     # test closes the rest through the bit-exact pass-range additivity it already checks
     "c5p": dict(kind="cbox", tris=0, size=4096, spp=4096, passes=(0, 8), seed=1),
+    # the headline frame again under two other master seeds (other block seeds and sub-pixel offsets: other random streams through
+    # the same kernels, light-shaft grid included)
+    "c2s2": dict(kind="cbox", tris=0, size=1024, spp=512, passes=(0, 512), seed=2),
+    "c2s3": dict(kind="cbox", tris=0, size=1024, spp=512, passes=(0, 512), seed=3),
 }
 BLOCK = 128
 

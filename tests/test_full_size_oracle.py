@@ -23,7 +23,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 sys.path.insert(0, GOLD)
 import make_full_size as mfs  # noqa: E402   (frame_digest / build_scene / tree_digest: one text for maker and checker)
 
-CONFIGS = ["c2", "c3", "c4", "c5p"]
+CONFIGS = ["c2", "c3", "c4", "c5p", "c2s2", "c2s3"]
 
 
 def load(name):
@@ -42,9 +42,9 @@ def test_fixture_is_well_formed(name):
     c = fx["counters"]
     assert c["paths"] == W * H * (cfg["passes"][1] - cfg["passes"][0])
     assert c["closest_calls"] >= c["paths"] and c["hits"] <= c["closest_calls"] and c["shadow_calls"] <= c["nee_evals"]
-    if name in ("c2", "c5p"):            # bench.py's headline configuration and its sizes
+    if name in ("c2", "c5p", "c2s2", "c2s3"):            # bench.py's headline configuration and its sizes
         import bench
-        b = bench.CONFIGS["c2" if name == "c2" else "c5"]
+        b = bench.CONFIGS["c5" if name == "c5p" else "c2"]
         assert (b["size"], b["spp"]) == (cfg["size"], cfg["spp"])
 
 
