@@ -150,29 +150,33 @@ class ShardedRenderer:
 
     def render_frames(self, steps, spp, master_seed, opts=None, reduce=True):
         """`steps` whole frames BACK TO BACK without draining the batch pipeline between them (hj_render_frame with
-        HJ_RENDER_NO_DRAIN): frame k + 1 is submitted - into the second of two framebuffers - before frame k is waited for and
+        HJ_RENDER_NO_DRAIN): frame k + 1 is submitted - into the next of three framebuffers - before frame k is waited for and
         reduced, so the path-depth tail of a frame's last batches runs beside the first batches of the next one, and the
         collective beside the rendering.  Every frame is complete and reduced when this returns; the LAST frame is in
         `self.fb`.  Returns the statistics summed over the frames.  Frames are the blocking call's, bit for bit."""
         import torch
-        if not hasattr(self, "_fb2"):
-            self._fb2 = torch.zeros_like(self.fb)
-        first, other = self.fb, self._fb2
-        bufs = [first, other] if steps % 2 == 1 else [other, first]      # so that frame steps - 1 lands in self.fb
+        # THREE framebuffers in turn, not two: frame k + 1 may only be submitted into a buffer whose last reduce has completed, and
+        # the collective's kernels have to find room on a GPU that frame k's persistent workgroups fill - with two buffers that
+        # reduce (frame k - 1's) was enqueued moments ago, with three it is frame k - 2's and has had a whole frame to run.
+        if not hasattr(self, "_fb_ring"):
+            self._fb_ring = [self.fb, torch.zeros_like(self.fb), torch.zeros_like(self.fb)]
+        n = len(self._fb_ring)
+        shift = (-(steps - 1)) % n                      # so that frame steps - 1 lands in self.fb (= ring[0])
+        bufs = [self._fb_ring[(k + shift) % n] for k in range(steps)]
         torch.cuda.synchronize(self.local)
         for k in range(steps):
-            fb = bufs[k % 2]
-            fb.zero_()                                 # (behind the reduce of frame k - 2 on torch's stream: same buffer)
+            fb = bufs[k]
+            fb.zero_()                                 # (behind the reduce of the frame that last used this buffer, on torch's stream)
             torch.cuda.current_stream(self.local).synchronize()
             self.renderer.bind_framebuffer(fb.data_ptr())
             self.renderer.submit_frame(spp, master_seed, rank=self.rank, world=self.world, opts=opts)
             if k >= 1:
                 self.renderer.pipeline_wait(keep=1)    # frame k - 1 is complete (frame k renders on)
                 if reduce:
-                    reduce_framebuffer(bufs[(k - 1) % 2], root=0)
+                    reduce_framebuffer(bufs[k - 1], root=0)
         stats = self.renderer.pipeline_wait(keep=0)
         if reduce:
-            reduce_framebuffer(bufs[(steps - 1) % 2], root=0)
+            reduce_framebuffer(bufs[steps - 1], root=0)
         self.renderer.bind_framebuffer(self.fb.data_ptr())
         return stats
 
