@@ -198,6 +198,10 @@ def roofs_block(inputs, agg, busy_s, traffic_gbs):
                                                      "frac": round(traffic_gbs / HBM_PEAK_GBS, 4), "what": "PMC traffic (FETCH_SIZE corrected + WRITE_SIZE)"}}
     if w.get("box_lane_steps_per_ray") is not None and busy_s > 0:
         hot = max(0.0, w["box_lane_steps_per_ray"] - w.get("cold_node_steps_per_ray", 0.0))
+        if w.get("merged_box_lane_steps") and w.get("rays"):
+            # per LANE in the merged walk (a 32-byte read each), per WAVE-step in the camera packets (one broadcast read)
+            hot = max(0.0, (w["merged_box_lane_steps"] + w.get("packet_wave_steps", 0) - w.get("packet_cold_wave_steps", 0)) / w["rays"]
+                      - w.get("cold_node_steps_per_ray", 0.0))
         lds = 32.0 * hot * rays / busy_s / 1e9
         out["lds"] = {"achieved": round(lds, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBS, 4),
                       "what": f"32 B x {hot:.2f} box steps per ray on the LDS copy of the 512 hottest nodes"}
