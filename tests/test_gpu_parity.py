@@ -380,6 +380,14 @@ def test_device_built_bvh(gpu_renderer, oracle, kind):
     rgb = lambda a: a[..., :3] / a[..., 3:4]
     differ = (np.abs(rgb(want) - rgb(ref)) > 1e-6).any(axis=-1).mean()
     assert differ < 0.02, differ                                          # a tie flips a whole path: rare pixels only
+    # ... and with compile's tree passes run on it (hjh_compiled_tune_bvh: the ray-voted child order): still a valid tree over the
+    # same shapes, cheaper to walk, bit-identical on GPU and oracle
+    cs.tune_bvh(reinsert_passes=1, vote_paths=20000)
+    _check_skip_link_tree(cs.bvh, _shape_boxes(cs))
+    want2, ctr2, _ = oracle.render_blocks(cs, blocks, W, H)
+    got2, _ = render(gpu_renderer, cs, W, H, blocks)
+    assert_same(got2, want2, "device-built tree, tuned")
+    assert ctr2["nodes"] < ctr["nodes"]
     cs.set_bvh(sah_nodes)
 
 
