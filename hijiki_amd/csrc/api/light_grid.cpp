@@ -15,8 +15,9 @@
 //   2. emitter e is a triangle or quad (plane Q) and all of it lies on one side of P at an angle: for every point y of its
 //      padded box, |dist(y, P)| - tol_p >= 0.25 |y - x| for every x of the padded cell.  A ray leaving P that steeply is more
 //      than tol_s away from P from t = 1e-4 on (tMin of a shadow ray is 2e-4, scene.glsl:85), so no shape coplanar with P
-//      - the one p lies on, its neighbours in the wall - can be hit; the same with the roles exchanged (0.1) at the emitter:
-//      shapes coplanar with Q, the emitter itself included, are met at t >= dist - 1e-5 > tMax = dist - 1e-4;
+//      - the one p lies on, its neighbours in the wall - can be hit; the same with the roles exchanged at the emitter (sin >= 0.03
+//      when the shapes in Q are exactly planar, 0.1 at most): shapes coplanar with Q, the emitter itself included, are met at
+//      t >= dist - 2.5e-5 > tMax = dist - 1e-4;
 //   3. no other shape's padded bounding box touches the convex hull of the padded cell and the padded box of the emitter
 //      (every segment p -> y lies in that hull).  The hull of two boxes is the intersection, over the three axes, of the
 //      extruded 2-D hulls of their projections (every facet normal of the hull is perpendicular to an axis), so a box is
@@ -360,13 +361,30 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
   });
   mark("planes + rasterisation");
   // emitters (bit e for e < 8)
-  struct Em { size_t shape; Plane q; Box box; bool ok; };
+  struct Em { size_t shape; Plane q; Box box; bool ok; double slack, sin_min; };
   std::vector<Em> ems;
   for (size_t e = 0; e < std::min<size_t>(s->num_emitters, 8); e++) {
     Em em{};
     em.shape = s->emitters[e].shape;
     em.ok = em.shape < shapes;
     if (em.ok) { em.q = g.plane(em.shape); em.ok = em.q.ok; em.box = pad(widen(sb[em.shape]), m); }
+    if (em.ok) {
+      // How steeply the emitter has to be seen: shapes "in Q" (the emitter, its neighbour triangle) are met at
+      // t >= dist - slack / sin, and that has to stay behind tMax = dist - 1e-4 with room for the rounding of either side
+      // (a quarter of eps for the geometry, the rest for the arithmetic: about 1e-5 at sin = 0.03).  slack = how far such shapes
+      // really are from Q (measured; exactly 0 for an axis-aligned light) + how far a sampled point can be (4 ulp of the
+      // emitter's largest coordinate).  0.1 as before when the measured figures give nothing better.
+      double dev = 0.0, big = 0.0;
+      for (size_t i = g.ns; i < shapes; i++) {
+        if (!g.coplanar(i, em.q, tol_s)) continue;
+        double v[4][3];
+        const int nv = g.vertices(i, v);
+        for (int c = 0; c < nv; c++) dev = std::max(dev, std::fabs(em.q.n[0] * v[c][0] + em.q.n[1] * v[c][1] + em.q.n[2] * v[c][2] - em.q.d));
+      }
+      { double v[4][3]; const int nv = g.vertices(em.shape, v); for (int c = 0; c < nv; c++) for (int k = 0; k < 3; k++) big = std::max(big, std::fabs(v[c][k])); }
+      em.slack = dev + 4.0 * 5.97e-8 * big;
+      em.sin_min = std::min(kSinEmitter, std::max(0.03, em.slack / (0.25 * kEps)));
+    }
     ems.push_back(em);
   }
 
@@ -404,7 +422,7 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
           // (the hit point is within tol_p of P, so its distance to Q is what the part of the cell near P has: the cell's box is a superset)
           side_dist(em.q, cb, lo_d, hi_d);
           const double near_q = lo_d > 0 ? lo_d : (hi_d < 0 ? -hi_d : 0.0);
-          if (!(near_q - tol_s >= kSinEmitter * dmax)) continue;
+          if (!(near_q - std::max(tol_s, em.slack) >= em.sin_min * dmax)) continue;
           // 3. the shaft holds nothing but shapes in P and shapes in Q
           const Shaft sh(cb, em.box);
           bool blocked = false;
