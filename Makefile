@@ -12,11 +12,11 @@ FP_STRICT = -ffp-contract=off -fno-fast-math
 HOST_SRC = hijiki_amd/csrc/host/scene.cpp hijiki_amd/csrc/host/tree_opt.cpp hijiki_amd/csrc/host/synth.cpp hijiki_amd/csrc/host/blockgen.cpp \
            hijiki_amd/csrc/host/obj_loader.cpp hijiki_amd/csrc/host/image_io.cpp hijiki_amd/csrc/host/host_api.cpp
 HOST_HDR = hijiki_amd/csrc/host/scene.hpp hijiki_amd/csrc/host/blockgen.hpp include/hijiki_hip.h include/hijiki_host.h
-# libhijiki_hip.so: five translation units (hijiki_amd/csrc/api/hj_internal.h lists them); only render.hip and
-# lbvh_build.hip hold device code.  The register / scratch / LDS report of the path kernels: hijiki_amd/lib/resource_usage.txt.
-HIP_UNITS = context scene_upload scene_relayout render comm lbvh_build
+# libhijiki_hip.so: its translation units (hijiki_amd/csrc/api/hj_internal.h lists them); render.hip, scene_relayout.hip,
+# lbvh_build.hip and tree_vote.hip hold device code.  The register / scratch / LDS report of the path kernels: hijiki_amd/lib/resource_usage.txt.
+HIP_UNITS = context scene_upload scene_relayout render comm lbvh_build tree_vote
 HIP_OBJ = $(HIP_UNITS:%=build/obj/%.o) build/obj/blockgen.o build/obj/light_grid.o
-HIP_HDR = $(wildcard hijiki_amd/csrc/kernels/*.h) hijiki_amd/csrc/api/hj_internal.h hijiki_amd/csrc/api/light_grid.hpp hijiki_amd/csrc/api/scene_relayout.hpp include/hijiki_hip.h hijiki_amd/csrc/host/blockgen.hpp
+HIP_HDR = $(wildcard hijiki_amd/csrc/kernels/*.h) hijiki_amd/csrc/api/hj_internal.h hijiki_amd/csrc/api/light_grid.hpp hijiki_amd/csrc/api/scene_relayout.hpp hijiki_amd/csrc/api/tree_vote.hpp include/hijiki_hip.h hijiki_amd/csrc/host/blockgen.hpp
 HIP_FLAGS = --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC $(FP_STRICT) -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden \
             -Wall -Wno-unused-function $(HIP_EXTRA)
 

@@ -6,6 +6,7 @@
 //   api/render.hip        batch slots, the launches of kernels/hj_kernels.h, render calls, probes
 //   api/comm.hip          RCCL (dlopen), hj_comm_*, hj_reduce_framebuffers
 //   api/lbvh_build.hip    hj_build_bvh_device: host half of kernels/hj_lbvh.h
+//   api/tree_vote.hip     hj_tune_bvh_device: host half of kernels/hj_vote.h (child order voted by sampled rays)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -145,6 +146,7 @@ int env_int(const char* name, int dflt, int lo, int hi);
 int set_error(hj_context* ctx, int code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
 std::string get_error(hj_context* ctx);
 int dev_alloc(hj_context* ctx, DevBuf& b, size_t bytes);
+int validate_scene(hj_context* ctx, const hj_scene_desc* s);   // api/scene_upload.hip: every invariant an upload checks
 void release_scene(hj_context* ctx);
 void release_slot(hj_context::BatchSlot& sl);
 void release_batch(hj_context* ctx);

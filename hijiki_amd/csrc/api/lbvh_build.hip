@@ -1,5 +1,6 @@
 // hj_build_bvh_device: the host half of the device BVH build (kernels/hj_lbvh.h) - SURVEY.md 8(f) #2.
 #include "hj_internal.h"
+#include "tree_vote.hpp"
 #include "../kernels/hj_lbvh.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -473,9 +474,25 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
     hipLaunchKernelGGL(hj::lbvh::k_emit_clusters, grid_sub, blk, 0, st, t, m, cl, idx_mask, d_out);
   HJ_HIP(ctx, hipGetLastError());
   mark("cluster subtrees");
-  HJ_HIP(ctx, hipMemcpyAsync(out_nodes, d_out, sizeof(hj_bvh_node) * total, hipMemcpyDeviceToHost, st));
-  HJ_HIP(ctx, hipStreamSynchronize(st));
-  for (const auto& pr : top_records) out_nodes[pr.first] = pr.second;
+  // ---- child order voted by a sample of the scene's own rays (kernels/hj_vote.h; HJ_LBVH_VOTE_PATHS camera paths, 0 = the order
+  // by shape count the stages above produced): the host-built records join the others on the device first
+  const size_t vote_paths = (size_t)env_int("HJ_LBVH_VOTE_PATHS", 60000, 0, 1 << 24);
+  if (vote_paths != 0 && total >= 3) {
+    hj_bvh_node* d_voted = nullptr;
+    HJ_DEVBUF(d_voted, hj_bvh_node, total);
+    rc = put_records(ctx, top_records, d_out);
+    if (rc != HJ_OK) return rc;
+    const VoteShapes vsh{sh.spheres, sh.quads, sh.triangles, sh.vertices};
+    rc = vote_on_device(ctx, s, vsh, d_out, total, vote_paths, d_voted, timing, nullptr);
+    if (rc != HJ_OK) return rc;
+    mark("ray-voted child order");
+    HJ_HIP(ctx, hipMemcpyAsync(out_nodes, d_voted, sizeof(hj_bvh_node) * total, hipMemcpyDeviceToHost, st));
+    HJ_HIP(ctx, hipStreamSynchronize(st));
+  } else {
+    HJ_HIP(ctx, hipMemcpyAsync(out_nodes, d_out, sizeof(hj_bvh_node) * total, hipMemcpyDeviceToHost, st));
+    HJ_HIP(ctx, hipStreamSynchronize(st));
+    for (const auto& pr : top_records) out_nodes[pr.first] = pr.second;
+  }
   mark("records to the host");
 #undef HJ_DEVBUF
   if (out_num_nodes) *out_num_nodes = total;

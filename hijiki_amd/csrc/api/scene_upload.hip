@@ -8,7 +8,7 @@
 
 using namespace hjapi;
 
-namespace {
+namespace hjapi {
 
 // Same invariants the reference asserts while packing (src/main.rs:562-565)
 // plus every index range a kernel dereferences, and the monotonic-exit
@@ -83,6 +83,10 @@ int validate_scene(hj_context* ctx, const hj_scene_desc* s) {
   }
   return HJ_OK;
 }
+
+}  // namespace hjapi
+
+namespace {
 
 // What depends on the tree's size once its records exist (host and device re-layout alike): N = nodes of the uploaded array,
 // M = device records without padding.

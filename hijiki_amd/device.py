@@ -22,7 +22,7 @@ EXPORTS = ("hj_context_create", "hj_context_destroy", "hj_last_error", "hj_versi
            "hj_pass_offset", "hj_block_owner", "hj_debug_trace", "hj_debug_samples", "hj_reduce_framebuffers",
            "hj_build_bvh_device", "hj_render_frame_async", "hj_sync", "hj_set_progress_callback", "hj_device_count",
            "hj_comm_create", "hj_comm_destroy", "hj_comm_reduce_framebuffers", "hj_reserve", "hj_framebuffer_bind",
-           "hj_pipeline_wait", "hj_debug_light_grid")
+           "hj_pipeline_wait", "hj_debug_light_grid", "hj_tune_bvh_device")
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
 
@@ -71,6 +71,7 @@ def lib():
         L.hj_debug_trace.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
         L.hj_debug_samples.argtypes = [vp, C.POINTER(abi.ImageBlock), C.POINTER(abi.RenderOpts), C.POINTER(C.c_float)]
         L.hj_build_bvh_device.argtypes = [vp, C.POINTER(abi.SceneDesc), C.POINTER(abi.BvhNode), C.c_size_t, C.POINTER(C.c_size_t)]
+        L.hj_tune_bvh_device.argtypes = [vp, C.POINTER(abi.SceneDesc), C.POINTER(abi.BvhNode), C.c_size_t, C.c_size_t]
         L.hj_block_seed.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         L.hj_block_seed.restype = C.c_uint32
         L.hj_pass_offset.argtypes = [C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]
@@ -236,6 +237,14 @@ class Renderer:
         self._check(lib().hj_build_bvh_device(self._h, C.byref(compiled.desc), nodes.ctypes.data_as(C.POINTER(abi.BvhNode)),
                                               len(nodes), C.byref(got)))
         return nodes[:got.value]
+
+    def tune_bvh_device(self, compiled, vote_paths=60000):
+        """The tree of `compiled` with its child order voted by `vote_paths` sampled camera paths on the device
+        (hj_tune_bvh_device): (nodes, 8) uint32 records, same boxes and leaves.  `compiled.set_bvh(nodes)` installs it."""
+        nodes = np.zeros((max(len(compiled.bvh), 1), 8), np.uint32)
+        self._check(lib().hj_tune_bvh_device(self._h, C.byref(compiled.desc), nodes.ctypes.data_as(C.POINTER(abi.BvhNode)),
+                                             len(nodes), int(vote_paths)))
+        return nodes[:len(compiled.bvh)]
 
     def trace(self, rays, use_bvh=True, any_hit=False):
         """intersectScene for (n,8) rays -> ids (n,) int32, t, u, v (n,) float32 (raw hit, before populate)."""

@@ -268,13 +268,24 @@ int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed,
 /* ------------------------------------------------------------- BVH on device */
 
 /* The tree of `Scene::compile` (src/main.rs:199-231) built on the device instead of by the host's SAH builder
- * (SURVEY.md 8f #2): a Morton-code LBVH over the shapes of `scene` (scene->bvh is ignored), written to
+ * (SURVEY.md 8f #2): a Morton-code LBVH over the shapes of `scene` (scene->bvh is ignored; camera, materials and emitters feed the
+ * ray vote at its end: hj_tune_bvh_device), written to
  * out_nodes in the reference's flattened format - one shape per leaf, pre-order with skip links, every record
  * holding the bounds of its own subtree, 2 * shapes - 1 records.  Start-up path for large meshes (1 M triangles
  * in milliseconds); its topology is not the host builder's, which changes images only through epsilon-ties and
  * traversal cost.  Put the result into scene->bvh before hj_scene_upload. */
 int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* scene, hj_bvh_node* out_nodes, size_t capacity,
                         size_t* out_num_nodes /* may be NULL */);
+
+/* The child order of a flattened tree, voted by a sample of the scene's own rays - on the device (no counterpart upstream: the
+ * reference walks the tree the `bvh` crate hands it, src/main.rs:199-231, children in array order, shader/scene.glsl:97-133; host
+ * form of the same pass: hjh_compiled_tune_bvh).  `vote_paths` camera paths of `scene` (camera, materials, emitters) are traced
+ * through scene->bvh; every ray that hits votes, at the ancestors of its leaf, for the order that would have spared it more of
+ * the other child; where the sample says so the two children of a node change places.  out_nodes receives the same tree - same
+ * boxes, same leaves - as another valid pre-order skip-link array of scene->num_bvh_nodes records (60 000 paths: a few
+ * milliseconds at 1 M triangles).  hj_build_bvh_device ends with this pass (HJ_LBVH_VOTE_PATHS, default 60000, 0 = off).  Images
+ * change only through epsilon-ties, traversal cost falls. */
+int hj_tune_bvh_device(hj_context* ctx, const hj_scene_desc* scene, hj_bvh_node* out_nodes, size_t capacity, size_t vote_paths);
 
 /* ------------------------------------------------- asynchronous frame, progress */
 

@@ -380,15 +380,105 @@ def test_device_built_bvh(gpu_renderer, oracle, kind):
     rgb = lambda a: a[..., :3] / a[..., 3:4]
     differ = (np.abs(rgb(want) - rgb(ref)) > 1e-6).any(axis=-1).mean()
     assert differ < 0.02, differ                                          # a tie flips a whole path: rare pixels only
-    # ... and with compile's tree passes run on it (hjh_compiled_tune_bvh: the ray-voted child order): still a valid tree over the
-    # same shapes, cheaper to walk, bit-identical on GPU and oracle
+    # the build ends with the ray-voted child order (kernels/hj_vote.h); without it (HJ_LBVH_VOTE_PATHS=0): the same leaves and
+    # boxes in the order by shape count, more nodes per ray
+    os.environ["HJ_LBVH_VOTE_PATHS"] = "0"
+    try:
+        plain = gpu_renderer.build_bvh(cs)
+    finally:
+        del os.environ["HJ_LBVH_VOTE_PATHS"]
+    _check_skip_link_tree(plain, _shape_boxes(cs))
+    assert _record_multiset(plain) == _record_multiset(nodes)
+    cs.set_bvh(plain)
+    want0, ctr0, _ = oracle.render_blocks(cs, blocks, W, H)
+    got0, _ = render(gpu_renderer, cs, W, H, blocks)
+    assert_same(got0, want0, "device-built tree, no vote")
+    assert ctr["nodes"] + ctr["shadow_nodes"] < ctr0["nodes"] + ctr0["shadow_nodes"], (ctr, ctr0)
+    # ... and with compile's tree passes run on it (hjh_compiled_tune_bvh: reinsertion + the host's vote): still a valid tree over
+    # the same shapes, cheaper to walk than the unvoted one, bit-identical on GPU and oracle
     cs.tune_bvh(reinsert_passes=1, vote_paths=20000)
     _check_skip_link_tree(cs.bvh, _shape_boxes(cs))
     want2, ctr2, _ = oracle.render_blocks(cs, blocks, W, H)
     got2, _ = render(gpu_renderer, cs, W, H, blocks)
     assert_same(got2, want2, "device-built tree, tuned")
-    assert ctr2["nodes"] < ctr["nodes"]
+    assert ctr2["nodes"] < ctr0["nodes"]
     cs.set_bvh(sah_nodes)
+
+
+def _record_multiset(nodes):
+    """The records of a flattened tree without their links: (box, shape word), sorted."""
+    n = np.asarray(nodes, np.uint32).reshape(-1, 8)
+    return sorted(map(tuple, n[:, :7].tolist()))
+
+
+@pytest.mark.parametrize("kind,tris", [(host.SYNTH_CBOX_SPHERES, 0), (host.SYNTH_CBOX_MESH, 20000)])
+def test_device_vote_keeps_the_tree_and_the_image(gpu_renderer, oracle, kind, tris):
+    """hj_tune_bvh_device: the child order of an installed tree voted by sampled rays on the device.  What comes back is the same
+    tree - same boxes, same leaves, children exchanged - as a valid pre-order skip-link array; the HIP path and the oracle walk it
+    to the same bits; it is as cheap to walk as the host's vote makes it (hjh_compiled_tune_bvh) and cheaper than before."""
+    cs = host.Scene.synthetic(kind, mesh_triangles=tris).compile()
+    sah_nodes = cs.bvh.copy()
+    cs.tune_bvh(reinsert_passes=0, vote_paths=0)                          # (identity: the passes are off)
+    assert (cs.bvh == sah_nodes).all()
+    # an order the vote has something to say about: every node's children exchanged where the right one has more shapes
+    worst = _order_children(sah_nodes, larger_first=True)
+    _check_skip_link_tree(worst, _shape_boxes(cs))
+    cs.set_bvh(worst)
+    W, H = 128, 96
+    blocks = host.make_blocks(W, H, 2, 5)
+    _, ctr_w, _ = oracle.render_blocks(cs, blocks, W, H)
+    assert (gpu_renderer.tune_bvh_device(cs, vote_paths=0) == worst).all()
+    voted = gpu_renderer.tune_bvh_device(cs, vote_paths=30000)
+    assert (gpu_renderer.tune_bvh_device(cs, vote_paths=30000) == voted).all()          # deterministic (integer votes)
+    _check_skip_link_tree(voted, _shape_boxes(cs))
+    assert _record_multiset(voted) == _record_multiset(worst)
+    cs.set_bvh(voted)
+    want, ctr_v, _ = oracle.render_blocks(cs, blocks, W, H)
+    got, _ = render(gpu_renderer, cs, W, H, blocks)
+    assert_same(got, want, "device-voted tree")
+    cs.set_bvh(worst)
+    cs.tune_bvh(reinsert_passes=0, vote_paths=30000)                      # the host's vote from the same starting point
+    _, ctr_h, _ = oracle.render_blocks(cs, blocks, W, H)
+    total = lambda c: c["nodes"] + c["shadow_nodes"]
+    assert total(ctr_v) < 0.97 * total(ctr_w), (total(ctr_v), total(ctr_w))
+    assert total(ctr_v) < 1.02 * total(ctr_h), (total(ctr_v), total(ctr_h))
+    # links that are not a tree's are refused (the same check as hj_scene_upload's)
+    cs.set_bvh(sah_nodes)
+    nodes = cs.bvh                                                        # (a view of the installed array)
+    i = int(np.nonzero(nodes[:, 3] == 0xFFFFFFFF)[0][5])
+    r = int(nodes[i + 1, 7])
+    assert int(nodes[r, 7]) < len(nodes) - 1
+    nodes[r, 7] = int(nodes[r, 7]) + 1
+    with pytest.raises(abi.HijikiError, match="not a pre-order skip-link tree"):
+        gpu_renderer.tune_bvh_device(cs)
+    cs.set_bvh(sah_nodes)
+
+
+def _order_children(nodes, larger_first):
+    """The flattened tree `nodes` with the children of every inner node in the order of their record counts."""
+    n = np.asarray(nodes, np.uint32).reshape(-1, 8)
+    N = len(n)
+    out = np.zeros_like(n)
+
+    def end(i):
+        return min(int(n[i, 7]), N)
+
+    stack = [(0, 0, int(n[0, 7]))]                                        # (old index, new position, new exit)
+    while stack:
+        i, pos, ex = stack.pop()
+        out[pos] = n[i]
+        out[pos, 7] = ex
+        if n[i, 3] != 0xFFFFFFFF:
+            continue
+        l = i + 1
+        r = int(n[l, 7])
+        sl, sr = r - l, end(i) - r
+        first, second, sf = (l, r, sl)
+        if (sr > sl) == larger_first and sr != sl:
+            first, second, sf = (r, l, sr)
+        stack.append((first, pos + 1, pos + 1 + sf))
+        stack.append((second, pos + 1 + sf, ex))
+    return out
 
 
 def _sah_cost(nodes):
