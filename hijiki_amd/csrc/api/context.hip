@@ -18,6 +18,7 @@ thread_local std::string g_create_error;
 namespace hjapi {
 
 std::atomic<size_t> g_dev_bytes{0};
+std::mutex& alloc_mutex() { static std::mutex mu; return mu; }
 
 int env_int(const char* name, int dflt, int lo, int hi) {
   const char* v = std::getenv(name);

@@ -469,6 +469,12 @@ int run_submit(hj_context* ctx, RenderRun& run, const hj_image_block* blocks, si
     run.paths += (uint64_t)std::min(b.dimension[0], b.original_dimension[0]) * std::min(b.dimension[1], b.original_dimension[1]);
   }
   int rc = HJ_OK;
+  // The contexts of one process (one per GPU, or several on one) enqueue their batches - and allocate a slot's arrays where they
+  // are missing - under one lock.  A context that runs out of memory keeps the lock from the moment it gives its slots back until
+  // its retry has its arrays: without it another context's larger attempt took what was just released and the first one found not
+  // even its smallest configuration (two contexts under HJ_ALLOC_LIMIT_MB starting frames at once: HJ_ERR_NOMEM once in ten runs).
+  // An enqueue does not wait for the GPU; the out-of-memory path does, for this context's own batches only.
+  std::unique_lock<std::mutex> alloc_lock(alloc_mutex(), std::defer_lock);
   // (Shrinking the last batches of a run - each 1/2 .. 1/6 of what is left - was measured: no change; the ~3.5 ms a
   // frame loses to pipeline fill and drain does not depend on the size of the last kernels.)
   for (size_t begin = 0; begin < n && rc == HJ_OK; run.k++) {
@@ -477,6 +483,7 @@ int run_submit(hj_context* ctx, RenderRun& run, const hj_image_block* blocks, si
     hj_context::BatchSlot& other = ctx->slots[(run.k + ctx->slots_eff - 1) % ctx->slots_eff];   // the previous batch's slot
     rc = harvest(ctx, sl, run.st);          // an older batch used this slot: its state arrays are free again
     if (rc != HJ_OK) break;
+    if (!run.split && !alloc_lock.owns_lock()) alloc_lock.lock();   // (the split path, a diagnostic, waits for its batch inside)
     rc = run.split ? render_batch_split(ctx, sl, other, blocks + begin, nb, run.o, run.tm, run.st, true)
                    : enqueue_batch_fused(ctx, sl, other, blocks + begin, nb, run.o, run.tm, run.st, true);
     if (rc == HJ_ERR_NOMEM && !run.split) {
@@ -493,8 +500,9 @@ int run_submit(hj_context* ctx, RenderRun& run, const hj_image_block* blocks, si
       if (!shrink_footprint(ctx, run)) { set_error(ctx, HJ_ERR_NOMEM, "%s (pool, batch and slots are at their minimum)", first_error.c_str()); break; }
       rc = HJ_OK;
       run.k--;                               // (the loop's increment: this batch has not been enqueued)
-      continue;
+      continue;                              // (with the lock)
     }
+    if (alloc_lock.owns_lock()) alloc_lock.unlock();
     begin += nb;
   }
   return rc;
@@ -591,6 +599,7 @@ int hj_reserve(hj_context* ctx, size_t total_blocks, const hj_render_opts* opts)
   RenderRun run;
   int rc = run_begin(ctx, run, opts, nullptr, total_blocks);        // (the call's batch size, pool and workgroup count)
   if (rc != HJ_OK || run.split) return rc;
+  std::lock_guard<std::mutex> alloc_lock(alloc_mutex());           // (run_submit: one context at a time sizes its slots)
   for (;;) {
     size_t left = total_blocks;
     rc = HJ_OK;
