@@ -484,10 +484,12 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
     if (rc != HJ_OK) return rc;
     const VoteShapes vsh{sh.spheres, sh.quads, sh.triangles, sh.vertices};
     rc = vote_on_device(ctx, s, vsh, d_out, total, vote_paths, d_voted, timing, nullptr);
-    if (rc != HJ_OK) return rc;
+    if (rc != HJ_OK && rc != HJ_ERR_UNSUPPORTED) return rc;
     mark("ray-voted child order");
-    HJ_HIP(ctx, hipMemcpyAsync(out_nodes, d_voted, sizeof(hj_bvh_node) * total, hipMemcpyDeviceToHost, st));
+    // (a tree deeper than the exchange's level loop goes - thousands of shapes in a chain - keeps the order it has)
+    HJ_HIP(ctx, hipMemcpyAsync(out_nodes, rc == HJ_OK ? d_voted : d_out, sizeof(hj_bvh_node) * total, hipMemcpyDeviceToHost, st));
     HJ_HIP(ctx, hipStreamSynchronize(st));
+    rc = HJ_OK;
   } else {
     HJ_HIP(ctx, hipMemcpyAsync(out_nodes, d_out, sizeof(hj_bvh_node) * total, hipMemcpyDeviceToHost, st));
     HJ_HIP(ctx, hipStreamSynchronize(st));

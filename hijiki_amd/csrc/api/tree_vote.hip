@@ -102,7 +102,8 @@ int vote_on_device(hj_context* ctx, const hj_scene_desc* s, const VoteShapes& sh
   HJ_HIP(ctx, hipStreamSynchronize(st));
   HJ_HIP(ctx, hipGetLastError());
   mark("exchange");
-  if (info[2]) return set_error(ctx, HJ_ERR_INVALID, "ray-voted child order: the array is not a pre-order skip-link tree");
+  if (info[2] & 1u) return set_error(ctx, HJ_ERR_INVALID, "ray-voted child order: the array is not a pre-order skip-link tree");
+  if (info[2] & 2u) return set_error(ctx, HJ_ERR_UNSUPPORTED, "ray-voted child order: the tree is deeper than 8192 levels");
   if (result) { result->exchanged = info[1]; result->levels = info[0]; }
   if (timing) std::fprintf(stderr, "ray-voted child order (device): %zu paths, %u of %zu inner nodes exchanged, %u levels\n", paths, info[1], N / 2, info[0]);
   return HJ_OK;

@@ -35,6 +35,7 @@
 #include <math.h>
 #include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -596,6 +597,19 @@ static inline ray_t camera_ray(const hj_camera* cam, float tanHalf, float px, fl
 
 typedef struct { float rgb[3]; float w; float n[3]; float depth; } sample_t;   /* layers 0,1 of render.glsl:172-173 */
 
+/* Diagnostic (tests and tools only): hjo_set_ray_log(path) makes every ray of the single-threaded entry points (hjo_integrate_block)
+ * append a record of ten floats - o, d, tMin, tMax, kind (0 closest, 1 shadow), hit id or -1 - to `path`; NULL closes the log. */
+static FILE* g_ray_log = NULL;
+HJO_EXPORT void hjo_set_ray_log(const char* path) {
+  if (g_ray_log) { fclose(g_ray_log); g_ray_log = NULL; }
+  if (path) g_ray_log = fopen(path, "wb");
+}
+static void log_ray(const ray_t* r, int kind, int id) {
+  if (!g_ray_log) return;
+  const float rec[10] = {r->o.x, r->o.y, r->o.z, r->d.x, r->d.y, r->d.z, r->tmin, r->tmax, (float)kind, (float)id};
+  fwrite(rec, sizeof rec, 1, g_ray_log);
+}
+
 /* shader/render.glsl:81-147 */
 static void integrate_ray(const scene_t* S, ray_t ray, uint32_t* rng, uint32_t max_bounces, uint32_t rr_start,
                           sample_t* out) {
@@ -606,7 +620,11 @@ static void integrate_ray(const scene_t* S, ray_t ray, uint32_t* rng, uint32_t m
   its_t its; memset(&its, 0, sizeof its);
   for (uint32_t bounce = 0; bounce < max_bounces; bounce++) {
     c->closest_calls++;
-    if (!intersect_scene(S, ray, &its, closest_ctr(c))) break;
+    {
+      const int hit_ = intersect_scene(S, ray, &its, closest_ctr(c));
+      log_ray(&ray, 0, hit_ ? its.id : -1);
+      if (!hit_) break;
+    }
     c->hits++;
     if (bounce == 0) { out->depth = its.t; out->n[0] = its.n.x; out->n[1] = its.n.y; out->n[2] = its.n.z; }
     uint32_t mat = S->sc->materials[its.id];
@@ -623,6 +641,7 @@ static void integrate_ray(const scene_t* S, ray_t ray, uint32_t* rng, uint32_t m
         its_t dummy; memset(&dummy, 0, sizeof dummy);
         c->shadow_calls++;
         int occluded = intersect_scene(S, sh, &dummy, shadow_ctr(c));   /* scene.glsl:92-96: full closest hit */
+        log_ray(&sh, 1, occluded ? dummy.id : -1);
         c->shadow_hits += (uint64_t)occluded;
         if (!occluded) {
           v3 f = eval_bsdf(S, mat, sh.d, &its);

@@ -155,6 +155,25 @@ def integrate_block(compiled, block, opts=None):
     return out, ctr.as_dict()
 
 
+def logged_rays(compiled, blocks, opts=None):
+    """Every ray the oracle traces for `blocks` (hjo_set_ray_log around hjo_integrate_block, single-threaded): (n, 10) float32 =
+    o, d, tMin, tMax, kind (0 closest-hit, 1 shadow), id of the shape hit or -1.  Directions are whatever the reference's
+    arithmetic made them - not always unit vectors."""
+    import tempfile
+    L = lib()
+    L.hjo_set_ray_log.argtypes = [C.c_char_p]
+    L.hjo_set_ray_log.restype = None
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "rays.bin")
+        L.hjo_set_ray_log(path.encode())
+        try:
+            for b in blocks:
+                integrate_block(compiled, b, opts)
+        finally:
+            L.hjo_set_ray_log(None)
+        return np.fromfile(path, np.float32).reshape(-1, 10)
+
+
 def reconstruct_block(block, samples, accum, opts=None):
     from hijiki_amd import abi
     opts = opts or abi.RenderOpts.default()

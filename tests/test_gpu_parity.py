@@ -454,6 +454,79 @@ def test_device_vote_keeps_the_tree_and_the_image(gpu_renderer, oracle, kind, tr
     cs.set_bvh(sah_nodes)
 
 
+def test_device_vote_on_a_chain_deeper_than_its_level_loop(gpu_renderer, oracle):
+    """A tree that is one long right spine (9000 spheres, every inner node = one leaf + the rest): deeper than the 8192 levels the
+    exchange's top-down pass walks.  hj_tune_bvh_device says HJ_ERR_UNSUPPORTED, nothing hangs, the context stays usable and the
+    chain itself uploads and renders like the oracle."""
+    n = 9000
+    s = host.Scene()
+    s.set_camera_cbox()
+    m, e = s.add_diffuse((0.6, 0.6, 0.6)), s.add_emissive((9, 9, 9))
+    rng = np.random.default_rng(11)
+    for k in range(n):
+        s.add_sphere(tuple(rng.uniform(-0.9, 0.9, 3) + (0, 1, 0)), 0.01 + 0.02 * rng.random(), e if k % 600 == 0 else m)
+    cs = s.compile()
+    boxes = _shape_boxes(cs)                                              # (lo, hi) per shape
+    N = 2 * n - 1
+    chain = np.zeros((N, 8), np.uint32)
+    f = chain.view(np.float32)
+    lo, hi = boxes
+    suf_lo, suf_hi = np.minimum.accumulate(lo[::-1])[::-1], np.maximum.accumulate(hi[::-1])[::-1]
+    for k in range(n - 1):
+        i = 2 * k
+        f[i, 0:3], f[i, 4:7] = suf_lo[k], suf_hi[k]
+        chain[i, 3], chain[i, 7] = 0xFFFFFFFF, max(N, abi.BVH_ROOT_EXIT)
+        f[i + 1, 0:3], f[i + 1, 4:7] = lo[k], hi[k]
+        chain[i + 1, 3], chain[i + 1, 7] = k, i + 2
+    f[N - 1, 0:3], f[N - 1, 4:7] = lo[n - 1], hi[n - 1]
+    chain[N - 1, 3], chain[N - 1, 7] = n - 1, max(N, abi.BVH_ROOT_EXIT)
+    _check_skip_link_tree(chain, boxes)
+    cs.set_bvh(chain)
+    with pytest.raises(abi.HijikiError) as err:
+        gpu_renderer.tune_bvh_device(cs, vote_paths=2000)
+    assert err.value.status == abi.HJ_ERR_UNSUPPORTED and "deeper" in str(err.value)
+    W, H = 64, 48
+    blocks = host.make_blocks(W, H, 1, 2)
+    want, _, _ = oracle.render_blocks(cs, blocks, W, H)
+    got, _ = render(gpu_renderer, cs, W, H, blocks)
+    assert_same(got, want, "chain tree")
+
+
+def _sphere_cluster(n, radius_scale, seed=11):
+    s = host.Scene()
+    s.set_camera_cbox()
+    m, e = s.add_diffuse((0.6, 0.6, 0.6)), s.add_emissive((9, 9, 9))
+    rng = np.random.default_rng(seed)
+    for _ in range(n):
+        s.add_sphere(tuple(rng.uniform(-0.9, 0.9, 3) + (0, 1, 0)), radius_scale * (0.01 + 0.02 * rng.random()), m)
+    s.add_quad((-0.3, 1.98, -0.3), (0.6, 0, 0), (0, 0, 0.6), e)
+    return s.compile()
+
+
+@pytest.mark.parametrize("n,scale,spp", [(20, 5.0, 16), (100, 5.0, 4), (600, 1.0, 2)])
+def test_sphere_clusters_and_directions_that_are_not_unit_vectors(gpu_renderer, oracle, n, scale, spp):
+    """Many small overlapping diffuse spheres.  The reference never re-normalises a path's direction: a hit point is o + t d, the
+    next normal (p - c) / r, the next direction built on it, and among small spheres the error of one step is amplified at the next -
+    a few bounces deep directions have length 1.3 or 3, for which sphere.glsl:18-41 (a = 1 assumed) no longer finds the line's
+    intersection with the sphere.  A padded box in front of a sphere leaf (round 5's guard nodes) culled hits the reference
+    accepts: 3 of 56 000 rays of the first scene.  Guards are for triangles and quads only now; here the frame, the counters and
+    EVERY ray the oracle traced - replayed through the uploaded tree - must agree."""
+    cs = _sphere_cluster(n, scale)
+    W, H = 64, 48
+    blocks = host.make_blocks(W, H, spp, 2)
+    want, ctr, _ = oracle.render_blocks(cs, blocks, W, H)
+    got, st = render(gpu_renderer, cs, W, H, blocks)
+    assert_same(got, want, f"{n} spheres")
+    assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"] and st["hits"] == ctr["hits"]
+    log = oracle.logged_rays(cs, blocks)
+    assert len(log) == ctr["closest_calls"] + ctr["shadow_calls"]
+    length = np.linalg.norm(log[:, 3:6].astype(np.float64), axis=1)
+    if n == 20:
+        assert (np.abs(length - 1.0) > 0.05).any()                        # (the premise: such rays exist in this frame)
+    ids, t, _, _ = gpu_renderer.trace(np.ascontiguousarray(log[:, 0:8]))
+    assert (ids == log[:, 9].astype(np.int32)).all(), np.nonzero(ids != log[:, 9].astype(np.int32))[0][:10]
+
+
 def _order_children(nodes, larger_first):
     """The flattened tree `nodes` with the children of every inner node in the order of their record counts."""
     n = np.asarray(nodes, np.uint32).reshape(-1, 8)
