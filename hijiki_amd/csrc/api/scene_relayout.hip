@@ -232,7 +232,23 @@ __global__ void k_rl_group_offsets(RL r, uint32_t L) {
   for (int k = 0; k < n; k++) if (rl_has_group(r, kids[k])) { r.goff[kids[k]] = next; next += r.tsub[kids[k]]; }
 }
 
-__global__ void k_rl_records(RL r, float4* __restrict__ dev, uint32_t m_all) {
+// the second copy of the tree (api/scene_upload.hip, kernels/hj_intersect.h general_position): the reference's own array, record i
+// at base + i - nothing collapsed; pair nodes keep their mark, their two leaves' records are never reached
+__global__ void k_rl_records2(RL r, float4* __restrict__ dev, uint32_t base) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= r.N) return;
+  const hj_bvh_node nd = r.bvh[i];
+  uint32_t a;
+  if (nd.shape_index != HJ_BVH_INNER) a = nd.shape_index;
+  else if (r.pair_flag[i]) a = hj::kInnerFlag | hj::kPairFlag | r.pair_idx[i];
+  else a = hj::kInnerFlag | (i + 1 < r.N ? base + i + 1 : hj::kEndOfWalk);
+  const uint32_t b = nd.exit_index < r.N ? base + nd.exit_index : hj::kEndOfWalk;
+  float4* rec = dev + 2 * ((size_t)base + i);
+  rec[0] = make_float4(nd.aabb_min[0], nd.aabb_min[1], nd.aabb_min[2], __uint_as_float(a));
+  rec[1] = make_float4(nd.aabb_max[0], nd.aabb_max[1], nd.aabb_max[2], __uint_as_float(b));
+}
+
+__global__ void k_rl_records(RL r, float4* __restrict__ dev) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= r.N || r.del[i]) return;
   const hj_bvh_node nd = r.bvh[i];
@@ -241,10 +257,10 @@ __global__ void k_rl_records(RL r, float4* __restrict__ dev, uint32_t m_all) {
   else if (r.pair_flag[i]) a = hj::kInnerFlag | hj::kPairFlag | r.pair_idx[i];
   else {
     const uint32_t l = rl_resolve(r, i + 1);
-    a = hj::kInnerFlag | (l < r.N ? r.map[l] : m_all);
+    a = hj::kInnerFlag | (l < r.N ? r.map[l] : hj::kEndOfWalk);
   }
   const uint32_t e = nd.exit_index < r.N ? rl_resolve(r, nd.exit_index) : r.N;
-  const uint32_t b = e < r.N ? r.map[e] : m_all;
+  const uint32_t b = e < r.N ? r.map[e] : hj::kEndOfWalk;
   float4* rec = dev + 2 * (size_t)r.map[i];
   rec[0] = make_float4(nd.aabb_min[0], nd.aabb_min[1], nd.aabb_min[2], __uint_as_float(a));
   rec[1] = make_float4(nd.aabb_max[0], nd.aabb_max[1], nd.aabb_max[2], __uint_as_float(b));
@@ -419,7 +435,8 @@ int relayout_on_device(hj_context* ctx, const hj_scene_desc* s, const hj_triangl
   mark("node order");
 
   // device records (zero-filled padding), placed so that the array does not cross a 4 GiB boundary (kernels/hj_walk.h)
-  const size_t rec_bytes = sizeof(float4) * 2 * (size_t)m_all;
+  if ((size_t)m_all + N >= hj::kEndOfWalk) return set_error(ctx, HJ_ERR_UNSUPPORTED, "BVH of %zu records: too large", (size_t)m_all + N);
+  const size_t rec_bytes = sizeof(float4) * 2 * ((size_t)m_all + N);      // the two copies of the tree
   const size_t bytes = std::max<size_t>(rec_bytes, 16) + 128;
   if (bytes >= (1ull << 32)) return set_error(ctx, HJ_ERR_UNSUPPORTED, "BVH of %u records: the device node array is limited to 4 GiB", M);
   ctx->scene_bufs.emplace_back();
@@ -437,7 +454,8 @@ int relayout_on_device(hj_context* ctx, const hj_scene_desc* s, const hj_triangl
     }
     float4* dev = reinterpret_cast<float4*>(start);
     HJ_HIP(ctx, hipMemsetAsync(dev, 0, rec_bytes, st));
-    hipLaunchKernelGGL(k_rl_records, grid, blk, 0, st, r, dev, m_all);
+    hipLaunchKernelGGL(k_rl_records, grid, blk, 0, st, r, dev);
+    hipLaunchKernelGGL(k_rl_records2, grid, blk, 0, st, r, dev, m_all);
     out.nodes = dev;
   }
   uint32_t root = 0;
@@ -446,7 +464,7 @@ int relayout_on_device(hj_context* ctx, const hj_scene_desc* s, const hj_triangl
   HJ_HIP(ctx, hipGetLastError());
   mark("device records");
   out.tri_isect = isect; out.tri_shade = shade; out.tri_pair = pairs;
-  out.num_nodes = m_all; out.root = root; out.num_hot = hot; out.num_pairs = num_pairs; out.kept = M;
+  out.num_nodes = m_all + n32; out.root = root; out.root2 = m_all; out.num_hot = hot; out.num_pairs = num_pairs; out.kept = M;
 #undef HJ_TMP
   return HJ_OK;
 }

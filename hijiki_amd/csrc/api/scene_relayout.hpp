@@ -12,7 +12,7 @@ struct RelayoutOut {
   const float4* tri_isect = nullptr;
   const float4* tri_shade = nullptr;
   const float4* tri_pair = nullptr;
-  uint32_t num_nodes = 0, root = 0, num_hot = 0, num_pairs = 0;
+  uint32_t num_nodes = 0, root = 0, root2 = 0, num_hot = 0, num_pairs = 0;   // root2: the second copy of the tree (the reference's own)
   size_t kept = 0;                     // records without padding
 };
 

@@ -172,7 +172,7 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
       if (rc == HJ_OK) {
         on_device = true;
         d.nodes = ro.nodes; d.tri_isect = ro.tri_isect; d.tri_shade = ro.tri_shade; d.tri_pair = ro.tri_pair;
-        d.num_nodes = ro.num_nodes; d.root = ro.root; d.num_hot = ro.num_hot; d.has_pairs = ro.num_pairs ? 1u : 0u;
+        d.num_nodes = ro.num_nodes; d.root = ro.root; d.root2 = ro.root2; d.num_hot = ro.num_hot; d.has_pairs = ro.num_pairs ? 1u : 0u;
         finish_tree_settings(d, s->num_bvh_nodes, ro.kept, ro.num_pairs != 0);
       } else if (rc == HJ_ERR_UNSUPPORTED) {
         while (ctx->scene_bufs.size() > mark_bufs) { ctx->scene_bufs.back().release(); ctx->scene_bufs.pop_back(); }
@@ -242,6 +242,7 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     // their parent's box as their only test, as upstream (modes 1 and 3 remain for measurements; c3, whose two large spheres never
     // saw such a ray in 10^9 paths, loses the 1 ... 2.7 % the sphere guards gave it).
     std::vector<hj_bvh_node> guarded;
+    std::vector<uint32_t> gidx;                               // index of original node i in `guarded` (empty: no guards, identity)
     const hj_bvh_node* bvh = s->bvh;
     size_t N = s->num_bvh_nodes;
     // HJ_LEAF_GUARDS: 0 none; 2 (default) every triangle or quad leaf that does not become half of a pair node: +1 % on c2 and c3
@@ -318,6 +319,8 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
         }
         bvh = guarded.data();
         N = guarded.size();
+        gidx.resize(n0);
+        for (size_t i = 0; i < n0; i++) gidx[i] = (uint32_t)(i + before[i] + want[i]);
       }
     }
     std::vector<float> sa(N);
@@ -445,19 +448,39 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
       else if (pair_of[i] != 0xFFFFFFFFu) a = hj::kInnerFlag | hj::kPairFlag | pair_of[i];
       else {
         const size_t l = resolve(i + 1);                                             // left child = next pre-order record
-        a = hj::kInnerFlag | (l < N ? map[l] : (uint32_t)M_all);
+        a = hj::kInnerFlag | (l < N ? map[l] : hj::kEndOfWalk);
       }
       const size_t e = nd.exit_index < N ? resolve(nd.exit_index) : N;
-      const uint32_t b = e < N ? map[e] : (uint32_t)M_all;                           // >= the record count ends the walk
+      const uint32_t b = e < N ? map[e] : hj::kEndOfWalk;                             // >= the record count ends the walk
       float4* rec = &dev[2 * (size_t)map[i]];
+      rec[0] = make_float4(nd.aabb_min[0], nd.aabb_min[1], nd.aabb_min[2], __builtin_bit_cast(float, a));
+      rec[1] = make_float4(nd.aabb_max[0], nd.aabb_max[1], nd.aabb_max[2], __builtin_bit_cast(float, b));
+    }
+    // The second copy of the tree: the reference's own array, record i at M_all + i - every node, no guards, nothing collapsed,
+    // the boxes as uploaded; pair nodes keep their mark (the same box test decides about the same two triangles; their two leaves'
+    // records are never reached).  Rays that are not in general position start here (kernels/hj_intersect.h general_position):
+    // for them the slab test is not monotone in a box's bounds, which the collapse and the guards rest on.
+    const size_t N0 = s->num_bvh_nodes;
+    if (M_all + N0 >= hj::kEndOfWalk) { release_scene(ctx); return set_error(ctx, HJ_ERR_UNSUPPORTED, "BVH of %zu records: too large", M_all + N0); }
+    dev.resize(2 * (M_all + N0), make_float4(0.f, 0.f, 0.f, 0.f));
+    for (size_t i = 0; i < N0; i++) {
+      const hj_bvh_node& nd = s->bvh[i];
+      const uint32_t pr = nd.shape_index == HJ_BVH_INNER ? pair_of[gidx.empty() ? i : gidx[i]] : 0xFFFFFFFFu;
+      uint32_t a;
+      if (nd.shape_index != HJ_BVH_INNER) a = nd.shape_index;
+      else if (pr != 0xFFFFFFFFu) a = hj::kInnerFlag | hj::kPairFlag | pr;
+      else a = hj::kInnerFlag | (i + 1 < N0 ? (uint32_t)(M_all + i + 1) : hj::kEndOfWalk);
+      const uint32_t b = nd.exit_index < N0 ? (uint32_t)(M_all + nd.exit_index) : hj::kEndOfWalk;
+      float4* rec = &dev[2 * (M_all + i)];
       rec[0] = make_float4(nd.aabb_min[0], nd.aabb_min[1], nd.aabb_min[2], __builtin_bit_cast(float, a));
       rec[1] = make_float4(nd.aabb_max[0], nd.aabb_max[1], nd.aabb_max[2], __builtin_bit_cast(float, b));
     }
     mark("device records");
     HJ_UP(upload(ctx, pairs.data(), pairs.size(), &d.tri_pair));
     d.has_pairs = pairs.empty() ? 0u : 1u;
-    d.num_nodes = (uint32_t)M_all;
+    d.num_nodes = (uint32_t)(M_all + N0);
     d.root = N ? map[0] : 0u;
+    d.root2 = (uint32_t)M_all;
     d.num_hot = hot;
     finish_tree_settings(d, s->num_bvh_nodes, M, !pairs.empty());
     // The walk adds 32 * index to the low word of the array's address without a carry (kernels/hj_walk.h): the

@@ -23,6 +23,7 @@ constexpr uint32_t kRefillMin = 32;   // free lanes at which a wave of the persi
 constexpr uint32_t kInnerFlag = 0x80000000u;
 constexpr uint32_t kPairFlag = 0x40000000u;    // with kInnerFlag: an inner node whose two children are triangle leaves
 constexpr uint32_t kIndexMask = 0x3FFFFFFFu;
+constexpr uint32_t kEndOfWalk = 0x3FFFFFFFu;   // the exit of the last nodes of a tree (the array holds two trees: no node count can serve)
 
 // Scene data in HBM.  `nodes` are 32-byte records (two float4 per node) derived from the reference's
 // skip-link array (same tree, same boxes, same visiting order) but RE-INDEXED: the kHotNodes nodes with the
@@ -32,7 +33,7 @@ constexpr uint32_t kIndexMask = 0x3FFFFFFFu;
 //   n0 = (aabb_min.xyz, A)   A = shape index for a leaf, 0x80000000 | left-child index for an inner node,
 //                            0xC0000000 | pair index for an inner node over two triangle leaves (those two leaves
 //                            have no records of their own: hj_intersect.h leaf_test)
-//   n1 = (aabb_max.xyz, B)   B = exit index (>= num_nodes ends the walk)
+//   n1 = (aabb_max.xyz, B)   B = exit index (>= num_nodes ends the walk: kEndOfWalk)
 // The walk starts at `root`.  Triangles are additionally pre-gathered per
 // triangle so that a leaf test is ONE dependent fetch instead of the
 // reference's index -> vertex chain (shader/shapes/triangle.glsl:16-18):
@@ -43,6 +44,8 @@ struct DeviceScene {
   const float4* nodes;
   uint32_t num_nodes;
   uint32_t root;                // device index of the reference's node 0
+  uint32_t root2;               // ... in the second copy of the tree, the reference's own (every node, no guards; pair nodes only): where
+                                // rays that are not in general position start (kernels/hj_intersect.h general_position)
   uint32_t num_hot;             // nodes [0, num_hot) are the LDS-cached ones (<= kHotNodes)
   uint32_t inner_burst;         // max box steps per round of the persistent walk before leaf tests run
   uint32_t refill_min;          // free lanes that trigger a ray refill

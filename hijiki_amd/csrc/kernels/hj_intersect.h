@@ -199,6 +199,17 @@ HJ_DEV bool node_step(float4 n0, float4 n1, v3 inv, v3 off, const Ray& r, uint32
   return stop;
 }
 
+// Rays in GENERAL POSITION: every 1 / d and every -o / d finite, no 1 / d zero.  For them the slab test (scene.glsl:120-131) is
+// monotone in the bounds of the box - "a box inside a box that the ray misses is missed" - which is what the upload's collapse and
+// its guard nodes rest on.  A direction with a zero (or denormal, infinite, NaN) component makes the test form
+// inf - inf and drop the NaN in its min / max: what it answers then depends on the SIGNS of the bounds, not on their order (a box
+// [0, 2] passes where [-1e-4, 2] fails), upstream and here alike - so those rays, one in 10^5 ... 10^7 where surfaces are
+// axis-aligned, walk the second copy of the tree, which is the reference's own (DeviceScene::root2).
+HJ_DEV bool general_position(v3 inv, v3 off) {
+  const float chk = ((inv.x - inv.x) + (inv.y - inv.y)) + ((inv.z - inv.z) + (off.x - off.x)) + ((off.y - off.y) + (off.z - off.z));
+  return chk == 0.0f && inv.x != 0.0f && inv.y != 0.0f && inv.z != 0.0f;
+}
+
 // reference shader/scene.glsl:97-158.  ANYHIT: stop at the first accepted hit
 // (the shadow overload scene.glsl:92-96 only uses the boolean, and the first
 // accepted hit in visiting order is the same with or without tMax shrinking).
@@ -209,7 +220,7 @@ HJ_DEV bool traverse(const DeviceScene& sc, Ray r, RawHit& h) {
     const v3 inv = V(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     const v3 off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
     const uint32_t nn = sc.num_nodes;
-    uint32_t cur = sc.root;
+    uint32_t cur = general_position(inv, off) ? sc.root : sc.root2;
     // "while-while": every lane first walks inner nodes until it stands on a leaf (or leaves the tree), then the
     // lanes that reached a leaf run the (much longer) shape test TOGETHER instead of interleaved with box tests.
     // Visiting order per ray is exactly the reference's pre-order skip-link walk.

@@ -304,7 +304,8 @@ HJ_DEV void stage_camera_packets(const BatchState& st, const DeviceScene& sc, ui
     const v3 off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
     RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
     uint32_t wake = valid ? kAwake : kNever; // the node at which a sleeping lane takes part again (a position without a sample: never)
-    uint32_t cur = sc.root;                  // wave-uniform
+    // (one lane not in general position - hj_intersect.h - and the whole packet walks the reference's own tree: exact for every ray)
+    uint32_t cur = __ballot(valid && !general_position(inv, off)) == 0ull ? sc.root : sc.root2;   // wave-uniform
     while (cur < nn) {
       float4 n0, n1;
       if (cur < nhot) {                      // (uniform address: a broadcast read)

@@ -184,7 +184,7 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
       slot = slot2; any = any2; r = r2; h = h2;
       inv = V(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
       off = V(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
-      cur = sc.root; active = true;
+      cur = general_position(inv, off) ? sc.root : sc.root2; active = true;
     }
     if (__ballot(active || pending) == 0) break;   // (a lane can finish in the merged first step: its result is written by the next service phase)
 #ifdef HJ_LDS_RT_PROBE

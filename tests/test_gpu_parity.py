@@ -527,6 +527,52 @@ def test_sphere_clusters_and_directions_that_are_not_unit_vectors(gpu_renderer, 
     assert (ids == log[:, 9].astype(np.int32)).all(), np.nonzero(ids != log[:, 9].astype(np.int32))[0][:10]
 
 
+@pytest.mark.parametrize("seed", [77, 3, 14])
+def test_cluster_scenes_and_rays_not_in_general_position(gpu_renderer, oracle, seed):
+    """tests/scenes.py random_cluster_scene: hundreds of small spheres of every material, small triangles, three lights - on the
+    compiled tree and on the device-built one.  Seed 77 holds the ray that showed what guard nodes (and, in principle, the collapse)
+    had overlooked: a direction with a component of exactly 0 (a cosine sample on an axis-aligned quad: sin(2 pi u) = 0).  The slab
+    test then forms inf - inf and drops the NaN in its min / max; its answer depends on the SIGNS of a box's bounds - the wall's
+    own box [0, 2] passes where the guard's [-1e-4, 2] fails - so nothing that replaces a box by another is exact for such rays.
+    They walk a second copy of the tree, the reference's own (kernels/hj_intersect.h general_position, DeviceScene::root2)."""
+    cs = scenes.random_cluster_scene(seed)
+    W, H = 160, 96
+    blocks = host.make_blocks(W, H, 3, seed)
+    compiled = cs.bvh.copy()
+    for tree in ("compiled", "device-built"):
+        if tree == "device-built":
+            cs.set_bvh(gpu_renderer.build_bvh(cs))
+        want, ctr, _ = oracle.render_blocks(cs, blocks, W, H)
+        got, st = render(gpu_renderer, cs, W, H, blocks)
+        assert_same(got, want, f"cluster scene {seed}, {tree} tree")
+        assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"] and st["hits"] == ctr["hits"]
+    cs.set_bvh(compiled)
+    gpu_renderer.upload_scene(cs)
+    if seed == 77:                                                        # the ray itself (bits as the oracle logged them)
+        ray = np.array([[-2.6812655e-01, 3.6761138e-01, -1.1999997e+00, -6.9234103e-01, 0.0, 7.2157043e-01, 1.9999999e-04, np.inf]], np.float32)
+        oi, ot, _, _ = oracle.intersect(cs, ray)
+        gi, gt, _, _ = gpu_renderer.trace(ray)
+        assert oi[0] >= 0 and gi[0] == oi[0] and bits(gt)[0] == bits(ot)[0]
+    # rays with zero components (+0, -0, two at once), origins on and off the scene's axis-aligned planes, open and closed intervals
+    rng = np.random.default_rng(seed)
+    n = 200000
+    rays = np.zeros((n, 8), np.float32)
+    planes = np.array([-1.2, -1.0, 0.0, 0.02, 1.2, 1.99, 2.0], np.float32)
+    rays[:, 0:3] = np.where(rng.random((n, 3)) < 0.3, rng.choice(planes, (n, 3)), rng.uniform(-1.2, 2.0, (n, 3)))
+    d = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    z = rng.integers(0, 3, n)
+    d[np.arange(n), z] = np.where(rng.random(n) < 0.5, 0.0, -0.0)
+    two = rng.random(n) < 0.2
+    d[two, (z[two] + 1) % 3] = 0.0
+    rays[:, 3:6] = d
+    rays[:, 6], rays[:, 7] = 2e-4, np.where(rng.random(n) < 0.5, np.inf, rng.uniform(0.2, 3.0, n))
+    oi, ot, _, _ = oracle.intersect(cs, rays)
+    gi, gt, _, _ = gpu_renderer.trace(rays)
+    ai, *_ = gpu_renderer.trace(rays, any_hit=True)
+    assert (oi >= 0).sum() > 1000
+    assert (gi == oi).all() and (bits(gt)[oi >= 0] == bits(ot)[oi >= 0]).all() and ((ai >= 0) == (oi >= 0)).all()
+
+
 def _order_children(nodes, larger_first):
     """The flattened tree `nodes` with the children of every inner node in the order of their record counts."""
     n = np.asarray(nodes, np.uint32).reshape(-1, 8)

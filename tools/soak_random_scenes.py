@@ -2,8 +2,10 @@
 different shape kinds, random cameras) through the HIP path with every exact shortcut on (light-shaft grid, leaf guards, pair nodes,
 collapse, camera packets) against the oracle, bit for bit; the share of shadow rays the grid proved free is printed per scene.
 
-    python tools/soak_random_scenes.py [first_seed] [count] [--device-tree]
+    python tools/soak_random_scenes.py [first_seed] [count] [--device-tree] [--clusters]
 
+--clusters: tests/scenes.py random_cluster_scene instead of random_scene (hundreds of small spheres of all materials, small triangles,
+three lights: the class of scene in which round 5's sphere guards were wrong).
 --device-tree: every scene a second time on the tree hj_build_bvh_device builds for it (Morton clusters, SAH re-split, host top, the
 ray vote of kernels/hj_vote.h on the device), which must be a valid tree the oracle and the HIP path walk to the same bits.
 """
@@ -16,6 +18,7 @@ from hijiki_amd import host, device
 from oracle import hj_oracle as O
 
 device_tree = "--device-tree" in sys.argv
+clusters = "--clusters" in sys.argv
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 first = int(argv[0]) if len(argv) > 0 else 100
 count = int(argv[1]) if len(argv) > 1 else 60
@@ -23,7 +26,7 @@ r = device.Renderer(0)
 W, H = 160, 96
 bad_total = proven = shadow = 0
 for seed in range(first, first + count):
-    cs = scenes.random_scene(seed)
+    cs = scenes.random_cluster_scene(seed) if clusters else scenes.random_scene(seed)
     blocks = host.make_blocks(W, H, 3, seed)
     want, ctr, _ = O.render_blocks(cs, blocks, W, H)
     r.upload_scene(cs); r.create_framebuffer(W, H)
