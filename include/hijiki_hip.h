@@ -206,7 +206,8 @@ void hj_default_render_opts(hj_render_opts* opts);
  * next record, its exit = the right child, a node's exit = the record behind its subtree or, on the right spine, any index >= the
  * node count); the boxes may be anything (a box that does not bound its subtree just culls what the reference would cull), other
  * link structures return HJ_ERR_INVALID.
- * Limit: the device node array is 32 bytes per record and must fit in 4 GiB (about 134 M records = 67 M shapes);
+ * Limit: the device node array - 32 bytes per record, TWO copies of the tree (the re-laid-out one and the reference's own, which
+ * rays with a zero or non-finite direction component walk: DESIGN.md 4) - must fit in 4 GiB: about 67 M records per tree = 33 M shapes;
  * larger trees return HJ_ERR_UNSUPPORTED. */
 int hj_scene_upload(hj_context* ctx, const hj_scene_desc* scene);
 
