@@ -112,24 +112,27 @@ def random_scene(seed):
     return s.compile()
 
 
-def random_cluster_scene(seed):
+def random_cluster_scene(seed, scale=1.0):
     """What random_scene lacks (round 5's sphere-guard bug lived there): many SMALL shapes.  An enclosure with a quad light and a
     triangle light, 30 ... 400 small spheres of all materials (some emissive, some overlapping, radii 0.005 ... 0.08) and a strip of
     small triangles.  Paths among small spheres leave the reference with directions far from unit length (it never re-normalises),
-    which is what every exact shortcut of the HIP path has to survive."""
+    which is what every exact shortcut of the HIP path has to survive.  `scale`: the whole scene (camera included) magnified - the
+    reference's epsilons (1e-4) stay what they are, so 100 and 0.01 put them at the other ends of float rounding."""
+    S = float(scale)
     rng = np.random.default_rng(5000 + seed)
     s = host.Scene()
-    s.set_camera((float(rng.uniform(-0.2, 0.2)), float(rng.uniform(0.8, 1.1)), float(rng.uniform(3.2, 3.8))), (0.0, 0.0, 0.0, 1.0),
+    s.set_camera((S * float(rng.uniform(-0.2, 0.2)), S * float(rng.uniform(0.8, 1.1)), S * float(rng.uniform(3.2, 3.8))), (0.0, 0.0, 0.0, 1.0),
                  float(rng.uniform(28, 42)))
     mats = [s.add_diffuse(tuple(rng.uniform(0.2, 0.9, 3))) for _ in range(3)]
     mats += [s.add_mirror(), s.add_dielectric(float(rng.uniform(1.3, 1.7))), s.add_dielectric(1.5, extinction=tuple(rng.uniform(0.0, 1.5, 3)))]
     lights = [s.add_emissive(tuple(rng.uniform(8, 30, 3))) for _ in range(3)]
-    s.add_quad((-1.2, 0, 1.2), (2.4, 0, 0), (0, 0, -2.4), mats[0])
-    s.add_quad((-1.2, 0, -1.2), (2.4, 0, 0), (0, 2.0, 0), mats[1])
-    s.add_quad((-1.2, 0, 1.2), (0, 0, -2.4), (0, 2.0, 0), mats[2])
-    s.add_quad((1.2, 0, -1.2), (0, 0, 2.4), (0, 2.0, 0), mats[0])
-    s.add_quad((-0.35, 1.99, -0.35), (0.7, 0, 0), (0, 0, 0.7), lights[0])
-    pos = np.array([[0.6, 1.7, -0.9], [1.0, 1.7, -0.9], [0.8, 1.95, -0.6]], np.float32)      # a triangle light near a wall
+    sc3 = lambda v: tuple(S * float(x) for x in v)
+    s.add_quad(sc3((-1.2, 0, 1.2)), sc3((2.4, 0, 0)), sc3((0, 0, -2.4)), mats[0])
+    s.add_quad(sc3((-1.2, 0, -1.2)), sc3((2.4, 0, 0)), sc3((0, 2.0, 0)), mats[1])
+    s.add_quad(sc3((-1.2, 0, 1.2)), sc3((0, 0, -2.4)), sc3((0, 2.0, 0)), mats[2])
+    s.add_quad(sc3((1.2, 0, -1.2)), sc3((0, 0, 2.4)), sc3((0, 2.0, 0)), mats[0])
+    s.add_quad(sc3((-0.35, 1.99, -0.35)), sc3((0.7, 0, 0)), sc3((0, 0, 0.7)), lights[0])
+    pos = np.float32(S) * np.array([[0.6, 1.7, -0.9], [1.0, 1.7, -0.9], [0.8, 1.95, -0.6]], np.float32)      # a triangle light near a wall
     nrm = np.tile(np.array([[0, -0.6, 0.8]], np.float32), (3, 1))
     b = s.add_vertices(pos, nrm, np.zeros((3, 2), np.float32))
     s.add_triangle(b, b + 1, b + 2, lights[1])
@@ -137,10 +140,10 @@ def random_cluster_scene(seed):
     rmax = float(rng.choice([0.02, 0.05, 0.08]))
     for k in range(n):
         mat = lights[2] if k % 97 == 5 else int(rng.choice(mats))
-        s.add_sphere(tuple(rng.uniform([-1.0, 0.1, -1.0], [1.0, 1.6, 1.0])), float(rng.uniform(0.005, rmax)), mat)
+        s.add_sphere(sc3(rng.uniform([-1.0, 0.1, -1.0], [1.0, 1.6, 1.0])), S * float(rng.uniform(0.005, rmax)), mat)
     m = int(rng.integers(4, 24))                                                               # a strip of small triangles on the floor
     xs = np.linspace(-0.9, 0.9, m + 1).astype(np.float32)
-    vp = np.array([[x, 0.02 + 0.03 * rng.random(), z] for x in xs for z in (-0.2, 0.0)], np.float32)
+    vp = np.float32(S) * np.array([[x, 0.02 + 0.03 * rng.random(), z] for x in xs for z in (-0.2, 0.0)], np.float32)
     vn = np.tile(np.array([[0, 1, 0]], np.float32), (len(vp), 1))
     b = s.add_vertices(vp, vn, rng.uniform(0, 1, (len(vp), 2)).astype(np.float32))
     for i in range(m):

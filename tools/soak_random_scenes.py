@@ -19,6 +19,7 @@ from oracle import hj_oracle as O
 
 device_tree = "--device-tree" in sys.argv
 clusters = "--clusters" in sys.argv
+scale = float(os.environ.get("SOAK_SCALE", "1"))              # with --clusters: the scene magnified (the reference's epsilons are not)
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 first = int(argv[0]) if len(argv) > 0 else 100
 count = int(argv[1]) if len(argv) > 1 else 60
@@ -26,7 +27,7 @@ r = device.Renderer(0)
 W, H = 160, 96
 bad_total = proven = shadow = 0
 for seed in range(first, first + count):
-    cs = scenes.random_cluster_scene(seed) if clusters else scenes.random_scene(seed)
+    cs = scenes.random_cluster_scene(seed, scale=scale) if clusters else scenes.random_scene(seed)
     blocks = host.make_blocks(W, H, 3, seed)
     want, ctr, _ = O.render_blocks(cs, blocks, W, H)
     r.upload_scene(cs); r.create_framebuffer(W, H)
