@@ -441,6 +441,7 @@ static inline void sample_quad(const hj_quad* qd, uint32_t* rng, srec_t* sr) {
 /* shader/scene.glsl:54-89.  Always consumes 3 random numbers.  With no
  * emitters the reference reads emitters[0] out of bounds (undefined); here
  * that case draws the 3 numbers and returns zero importance. */
+static _Thread_local int g_last_emitter = -1;     /* sample_emitter's choice: the last column of the diagnostic ray log below */
 static inline v3 sample_emitter(const scene_t* S, v3 ref, uint32_t* rng, ray_t* sh) {
   const hj_scene_desc* sc = S->sc;
   float xi = rng_float(rng);
@@ -454,6 +455,7 @@ static inline v3 sample_emitter(const scene_t* S, v3 ref, uint32_t* rng, ray_t* 
     xi -= sc->emitters[i].pdf;
     if (xi < 0.0f) { e = i; break; }
   }
+  g_last_emitter = (int)e;
   uint32_t shape = sc->emitters[e].shape;
   srec_t sr;
   if (shape < S->ns) sample_sphere(&sc->spheres[shape], rng, &sr);
@@ -598,7 +600,8 @@ static inline ray_t camera_ray(const hj_camera* cam, float tanHalf, float px, fl
 typedef struct { float rgb[3]; float w; float n[3]; float depth; } sample_t;   /* layers 0,1 of render.glsl:172-173 */
 
 /* Diagnostic (tests and tools only): hjo_set_ray_log(path) makes every ray of the single-threaded entry points (hjo_integrate_block)
- * append a record of ten floats - o, d, tMin, tMax, kind (0 closest, 1 shadow), hit id or -1 - to `path`; NULL closes the log. */
+ * append a record of eleven floats - o, d, tMin, tMax, kind (0 closest, 1 shadow), hit id or -1, index of the emitter a shadow ray
+ * aims at (-1 for a closest-hit ray) - to `path`; NULL closes the log. */
 static FILE* g_ray_log = NULL;
 HJO_EXPORT void hjo_set_ray_log(const char* path) {
   if (g_ray_log) { fclose(g_ray_log); g_ray_log = NULL; }
@@ -606,7 +609,8 @@ HJO_EXPORT void hjo_set_ray_log(const char* path) {
 }
 static void log_ray(const ray_t* r, int kind, int id) {
   if (!g_ray_log) return;
-  const float rec[10] = {r->o.x, r->o.y, r->o.z, r->d.x, r->d.y, r->d.z, r->tmin, r->tmax, (float)kind, (float)id};
+  const float rec[11] = {r->o.x, r->o.y, r->o.z, r->d.x, r->d.y, r->d.z, r->tmin, r->tmax, (float)kind, (float)id,
+                         kind == 1 ? (float)g_last_emitter : -1.0f};
   fwrite(rec, sizeof rec, 1, g_ray_log);
 }
 

@@ -156,8 +156,8 @@ def integrate_block(compiled, block, opts=None):
 
 
 def logged_rays(compiled, blocks, opts=None):
-    """Every ray the oracle traces for `blocks` (hjo_set_ray_log around hjo_integrate_block, single-threaded): (n, 10) float32 =
-    o, d, tMin, tMax, kind (0 closest-hit, 1 shadow), id of the shape hit or -1.  Directions are whatever the reference's
+    """Every ray the oracle traces for `blocks` (hjo_set_ray_log around hjo_integrate_block, single-threaded): (n, 11) float32 =
+    o, d, tMin, tMax, kind (0 closest-hit, 1 shadow), id of the shape hit or -1, index of the emitter a shadow ray aims at (else -1).  Directions are whatever the reference's
     arithmetic made them - not always unit vectors."""
     import tempfile
     L = lib()
@@ -171,7 +171,7 @@ def logged_rays(compiled, blocks, opts=None):
                 integrate_block(compiled, b, opts)
         finally:
             L.hjo_set_ray_log(None)
-        return np.fromfile(path, np.float32).reshape(-1, 10)
+        return np.fromfile(path, np.float32).reshape(-1, 11)
 
 
 def reconstruct_block(block, samples, accum, opts=None):

@@ -175,3 +175,38 @@ def test_no_grid_without_planar_emitters_or_at_huge_scale():
     s.add_quad((-2e4, 0, 2e4), (4e4, 0, 0), (0, 0, -4e4), white)               # coordinates where eps = 1e-4 is below float resolution
     s.add_quad((-2e3, 2e4, -2e3), (4e3, 0, 0), (0, 0, 4e3), lamp)
     assert build_grid(s.compile())[0] == 0
+
+
+@pytest.mark.parametrize("name", ["cbox", "cbox + spheres", "cluster 77", "cluster 3", "cluster 14 x 0.01", "random 5", "random 9"])
+def test_grid_against_the_oracles_own_shadow_rays(name):
+    """The attack above builds its own shadow rays; this one takes the ORACLE's: every next-event ray of a frame as the reference's
+    arithmetic produced it (oracle.logged_rays: origin = the computed hit point, target = the sampled point, the emitter's index),
+    looked up in the grid exactly as kernels/hj_shade.h shadow_ray_proven_free does.  A set bit and an occluded ray in the same log
+    would be a wrong pixel."""
+    from oracle import hj_oracle as O
+    if name == "cbox":
+        cs = host.Scene.synthetic(host.SYNTH_CBOX).compile()
+    elif name == "cbox + spheres":
+        cs = host.Scene.synthetic(host.SYNTH_CBOX_SPHERES).compile()
+    elif name.startswith("cluster"):
+        parts = name.split()
+        cs = scenes.random_cluster_scene(int(parts[1]), scale=float(parts[3]) if len(parts) > 3 else 1.0)
+    else:
+        cs = scenes.random_scene(int(name.split()[1]))
+    got, bits, lo, inv, st = build_grid(cs)
+    if not got:
+        pytest.skip("no grid for this scene")
+    log = O.logged_rays(cs, host.make_blocks(128, 96, 3, 4))
+    sh = log[log[:, 8] == 1]
+    assert len(sh) > 1000
+    e = sh[:, 10].astype(np.int64)
+    f = ((sh[:, 0:3] - lo) * inv).astype(np.float32)                      # (float32, as the kernel computes it)
+    inside = (f >= 0).all(1) & (f < RES).all(1) & (e >= 0) & (e < 8)
+    c = f[inside].astype(np.uint32)
+    cell = (c[:, 2].astype(np.int64) * RES + c[:, 1]) * RES + c[:, 0]
+    proven = np.zeros(len(sh), bool)
+    proven[inside] = ((bits[cell] >> e[inside]) & 1) != 0
+    occluded = sh[:, 9] >= 0
+    assert not (proven & occluded).any(), (name, int((proven & occluded).sum()), sh[proven & occluded][:3])
+    if name in ("cbox", "cbox + spheres"):
+        assert proven.mean() > 0.5                                        # (not vacuous: most of the box scenes' shadow rays are proven)
