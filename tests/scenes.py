@@ -150,3 +150,42 @@ def random_cluster_scene(seed, scale=1.0):
         s.add_triangle(b + 2 * i, b + 2 * i + 1, b + 2 * i + 2, int(rng.choice(mats[:3])))
         s.add_triangle(b + 2 * i + 1, b + 2 * i + 3, b + 2 * i + 2, int(rng.choice(mats[:3])))
     return s.compile()
+
+
+def nasty_scene(seed):
+    """Degenerate geometry on purpose: zero-area and collinear triangles, duplicated shapes, a sphere of radius 0 and one with a
+    negative radius, a quad with a zero edge, shapes far outside the rest, coincident coplanar quads (exact t ties), a light inside
+    a wall.  Nothing here has a "right" image; the oracle's arithmetic defines it and the HIP path has to reproduce it."""
+    rng = np.random.default_rng(7000 + seed)
+    s = host.Scene()
+    s.set_camera_cbox()
+    mats = [s.add_diffuse(tuple(rng.uniform(0.2, 0.9, 3))) for _ in range(2)] + [s.add_mirror(), s.add_dielectric(1.5)]
+    light = s.add_emissive((12, 11, 10))
+    s.add_quad((-1.2, 0, 1.2), (2.4, 0, 0), (0, 0, -2.4), mats[0])
+    s.add_quad((-1.2, 0, -1.2), (2.4, 0, 0), (0, 2.0, 0), mats[1])
+    s.add_quad((-1.2, 0, -1.2), (2.4, 0, 0), (0, 2.0, 0), mats[0])                  # the same quad again: exact ties
+    s.add_quad((-0.4, 1.99, -0.4), (0.8, 0, 0), (0, 0, 0.8), light)
+    s.add_quad((-0.4, 2.0, -0.4), (0.8, 0, 0), (0, 0, 0.0), mats[0])                # a zero edge
+    s.add_quad((-1.2, 0.5, -1.2), (0.3, 0, 0), (0, 0.3, 0), light)                  # a light in the back wall's plane
+    s.add_sphere((0.3, 0.4, 0.2), 0.0, mats[0])
+    s.add_sphere((-0.4, 0.5, 0.1), -0.3, mats[2])
+    s.add_sphere((0.5, 0.35, -0.3), 0.35, mats[3])
+    s.add_sphere((0.5, 0.35, -0.3), 0.35, mats[1])                                   # coincident spheres
+    s.add_sphere((300.0, 200.0, -5000.0), 1.0, mats[0])                              # far away: the scene's box explodes
+    nv = 24
+    pos = rng.uniform([-0.9, 0.05, -0.9], [0.9, 1.5, 0.9], (nv, 3)).astype(np.float32)
+    pos[3] = pos[2]                                                                   # duplicate vertices
+    pos[7] = 0.5 * (pos[5] + pos[6])                                                  # collinear
+    nrm = rng.normal(size=(nv, 3)).astype(np.float32)
+    nrm[4] = 0                                                                        # a zero shading normal
+    nrm[np.arange(nv) != 4] /= np.linalg.norm(nrm[np.arange(nv) != 4], axis=1, keepdims=True)
+    b = s.add_vertices(pos, nrm, rng.uniform(0, 1, (nv, 2)).astype(np.float32))
+    s.add_triangle(b + 2, b + 3, b + 9, mats[0])                                      # zero area (two equal vertices)
+    s.add_triangle(b + 1, b + 1, b + 1, mats[1])                                      # a point
+    s.add_triangle(b + 5, b + 6, b + 7, mats[0])                                      # collinear
+    s.add_triangle(b + 4, b + 10, b + 11, mats[1])                                    # zero normal at a vertex
+    for _ in range(int(rng.integers(6, 20))):
+        a, c, d = (int(x) for x in rng.choice(nv, 3, replace=False))
+        s.add_triangle(b + a, b + c, b + d, int(rng.choice(mats + [light])))
+        if rng.random() < 0.3: s.add_triangle(b + a, b + c, b + d, int(rng.choice(mats)))   # duplicates
+    return s.compile()

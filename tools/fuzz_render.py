@@ -1,5 +1,5 @@
-"""Differential fuzz of the render entry points: random scene (random_scene / random_cluster_scene / the synthetic box with a small
-mesh), random image size (not multiples of the block size), samples per pixel, master seed, pass range, rank of a random world size,
+"""Differential fuzz of the render entry points: random scene (random_scene / random_cluster_scene / nasty_scene - degenerate geometry on
+purpose - / the synthetic box with a small mesh), random image size (not multiples of the block size), samples per pixel, master seed, pass range, rank of a random world size,
 options (bounce limit, roulette start, batch size, light-shaft grid on / off, split kernels) - hj_render_frame on the GPU against the
 oracle's render of the same ImageBlocks with the same options, bit for bit, counters included.  The suite tests each of these on its
 own; this looks for what only their combinations do.
@@ -20,11 +20,12 @@ r = device.Renderer(0)
 fails = 0
 for it in range(first, first + count):
     rng = np.random.default_rng(90000 + it)
-    kind = int(rng.integers(0, 4))
+    kind = int(rng.integers(0, 5))
     if kind == 0: cs = scenes.random_scene(int(rng.integers(0, 10000)))
     elif kind == 1: cs = scenes.random_cluster_scene(int(rng.integers(0, 10000)), scale=float(rng.choice([1.0, 1.0, 0.1, 7.0])))
     elif kind == 2: cs = host.Scene.synthetic(host.SYNTH_CBOX_SPHERES, mesh_triangles=int(rng.choice([320, 1280]))).compile()
-    else: cs = host.Scene.synthetic(host.SYNTH_CBOX_MESH, mesh_triangles=int(rng.choice([2000, 20000]))).compile()
+    elif kind == 3: cs = host.Scene.synthetic(host.SYNTH_CBOX_MESH, mesh_triangles=int(rng.choice([2000, 20000]))).compile()
+    else: cs = scenes.nasty_scene(int(rng.integers(0, 10000)))
     if rng.random() < 0.25 and cs.num_shapes >= 2: cs.set_bvh(r.build_bvh(cs))
     W, H = int(rng.integers(16, 420)), int(rng.integers(16, 300))
     spp = int(rng.integers(1, 6))

@@ -40,6 +40,7 @@ todo = [("cbox", host.Scene.synthetic(host.SYNTH_CBOX).compile()), ("cbox + sphe
 todo += [("20 spheres", sphere_cluster(20, 5.0, 11)), ("300 spheres", sphere_cluster(300, 2.0, 12)), ("3000 spheres", sphere_cluster(3000, 1.0, 13))]
 todo += [(f"random scene {s}", scenes.random_scene(s)) for s in range(first, first + count)]
 todo += [(f"random cluster scene {s}", scenes.random_cluster_scene(s)) for s in range(first, first + count // 2)]
+todo += [(f"nasty scene {s}", scenes.nasty_scene(s)) for s in range(first, first + count // 2)]
 bad_total = 0
 for name, cs in todo:
     blocks = host.make_blocks(W, H, spp, 3)
