@@ -4,7 +4,7 @@ options (bounce limit, roulette start, batch size, light-shaft grid on / off, sp
 oracle's render of the same ImageBlocks with the same options, bit for bit, counters included.  The suite tests each of these on its
 own; this looks for what only their combinations do.
 
-    python tools/fuzz_render.py [first_seed] [count]
+    python tools/fuzz_render.py [first_seed] [count]          (FUZZ_BIG=1: frames up to 1700 x 1200 x 9 spp)
 """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,8 +27,9 @@ for it in range(first, first + count):
     elif kind == 3: cs = host.Scene.synthetic(host.SYNTH_CBOX_MESH, mesh_triangles=int(rng.choice([2000, 20000]))).compile()
     else: cs = scenes.nasty_scene(int(rng.integers(0, 10000)))
     if rng.random() < 0.25 and cs.num_shapes >= 2: cs.set_bvh(r.build_bvh(cs))
-    W, H = int(rng.integers(16, 420)), int(rng.integers(16, 300))
-    spp = int(rng.integers(1, 6))
+    big = os.environ.get("FUZZ_BIG") == "1"                      # frames of many batches: up to 1700 x 1200 x 9 spp (seconds of oracle time each)
+    W, H = int(rng.integers(16, 1700 if big else 420)), int(rng.integers(16, 1200 if big else 300))
+    spp = int(rng.integers(1, 10 if big else 6))
     seed = int(rng.integers(0, 2 ** 40))
     p0 = int(rng.integers(0, spp)); p1 = int(rng.integers(p0 + 1, spp + 1))
     world = int(rng.choice([1, 1, 2, 3, 8])); rank = int(rng.integers(0, world))
