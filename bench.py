@@ -391,6 +391,8 @@ def run_config(name, cfg, args, steps, warmup, hj, barrier):
     sr = hjdist.ShardedRenderer(cs, W, H, local_rank=local)
     opts = device.default_opts()
     opts.flags = abi.RENDER_TIME_KERNELS      # HIP events around every kernel class, on the library's own streams
+    if getattr(args, "static_deal", False):
+        opts.flags |= abi.RENDER_STATIC_DEAL   # all passes of a block on one rank (SURVEY 8(e)'s form): block interiors bit-identical to one GPU's
     sr.reserve(spp, opts)                     # set-up: the batch slots' device memory (50 GB at the defaults) is allocated here, not in a frame
     # Frames back to back: the batch pipeline is not drained between two frames (hj_render_frame with HJ_RENDER_NO_DRAIN,
     # ShardedRenderer.render_frames): frame k + 1's first batches run beside the path-depth tail of frame k's last ones, and
@@ -411,10 +413,16 @@ def run_config(name, cfg, args, steps, warmup, hj, barrier):
 
     frames(warmup)
     barrier()
+    sr.reset_timing()
     t0 = time.perf_counter()
     agg = frames(steps)
+    mine = time.perf_counter() - t0              # this rank's own wall time, before it waits for the others
     barrier()
     elapsed = hjdist.max_over_ranks(time.perf_counter() - t0, device=sr.local)     # the slowest rank's wall time
+    # per rank, gathered to every rank (rank 0 prints them): wall time, time inside the render calls and inside the reduces, the
+    # path kernels' exclusive GPU time, and the work it was dealt (paths, rays)
+    per_rank = hjdist.gather_over_ranks([mine, sr.timing["render_s"], sr.timing["reduce_s"], agg["path_busy_ms"] * 1e-3, agg["paths"],
+                                         agg["closest_rays"] + agg["shadow_rays"]], device=sr.local)
     # one BLOCKING frame after the timed region (not part of `value`): what a single frame takes from submission to the
     # reduced result when nothing overlaps its end - the latency figure beside the back-to-back throughput
     latency_ms = None
@@ -428,7 +436,7 @@ def run_config(name, cfg, args, steps, warmup, hj, barrier):
         import numpy as np
         np.save(args.dump_frame, sr.fb.cpu().numpy())          # the reduced frame of the last timed step (tests compare it)
     sr.close()
-    return dict(cs=cs, W=W, H=H, spp=spp, agg=agg, elapsed=elapsed, steps=steps, pipelined=pipelined, latency_ms=latency_ms,
+    return dict(cs=cs, W=W, H=H, spp=spp, agg=agg, elapsed=elapsed, steps=steps, pipelined=pipelined, latency_ms=latency_ms, per_rank=per_rank,
                 standard=(W, H, spp) == (cfg["size"], cfg["size"], cfg["spp"]))
 
 
@@ -451,6 +459,9 @@ def main():
                     help="skip the one blocking frame after the timed region (`blocking_frame_ms`): profiling runs that count frames")
     ap.add_argument("--dump-frame", default=None, metavar="FILE.npy",
                     help="rank 0 saves the reduced RGBA32F accumulation buffer of the last timed frame (after the timed region)")
+    ap.add_argument("--static-deal", action="store_true",
+                    help="N > 1: all passes of an ImageBlock on one rank (HJ_RENDER_STATIC_DEAL, SURVEY 8(e)'s partition) instead of the "
+                         "deal that moves one diagonal per pass")
     ap.add_argument("--inproc", action="store_true",
                     help="ONE process drives all --gpus GPUs through the C ABI alone (hj_render_frame_async per context, "
                          "hj_comm_reduce_framebuffers): no torch, no torchrun")
@@ -501,7 +512,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {label}, BVH, block 128, seed {args.seed}",
-                       "partition": f"ImageBlock (bx, by) of pass p -> rank (bx + by + p) mod {world}, RCCL sum-reduce of the {W}x{H} RGBA32F framebuffer"},
+                       "partition": (f"ImageBlock (bx, by) of every pass -> rank (bx + by) mod {world} (static deal)" if args.static_deal else
+                                     f"ImageBlock (bx, by) of pass p -> rank (bx + by + p) mod {world}") +
+                                    f", RCCL sum-reduce of the {W}x{H} RGBA32F framebuffer"},
+            "deal": "static" if args.static_deal else "rotating",
             # how many ranks the collective of the timed frames really spanned (torch.distributed's nccl backend = RCCL)
             "rccl_ranks": dist.get_world_size() if world > 1 and dist.is_initialized() else 1,
             "rccl_backend": dist.get_backend() if world > 1 and dist.is_initialized() else None,
@@ -510,6 +524,22 @@ def main():
             "blocking_frame_ms": None if res["latency_ms"] is None else round(res["latency_ms"], 3),   # one frame alone, after the timed region
             "value_blocking": None if not res["latency_ms"] else round(W * H * spp / (res["latency_ms"] * 1e-3) / 1e6, 3),   # Mrays/s of that frame
         }
+        if world > 1:
+            # the multi-GPU run explains itself: per rank (index = rank) over the K timed frames.  render_ms = host time inside the
+            # render calls (submission + waiting for the rank's own frames), reduce_ms = host time inside the framebuffer reduces
+            # (a rank that finished early waits for the slowest one HERE), kernel_busy_ms = exclusive GPU time of the path kernels;
+            # imbalance = max / mean of the ranks' kernel_busy_ms (1.0 = perfectly dealt work)
+            pr = res["per_rank"]
+            k = 1e3 / args.steps
+            busy = [r[3] for r in pr]
+            out["per_rank"] = {"wall_ms": [round(r[0] * k, 3) for r in pr], "render_ms": [round(r[1] * k, 3) for r in pr],
+                               "reduce_ms": [round(r[2] * k, 3) for r in pr], "kernel_busy_ms": [round(b * k, 3) for b in busy],
+                               "paths": [int(r[4]) for r in pr], "rays": [int(r[5]) for r in pr], "unit": "ms per step (frame)"}
+            mean_busy = sum(busy) / len(busy)
+            out["imbalance"] = None if mean_busy <= 0 else round(max(busy) / mean_busy, 4)
+            mean_render = sum(r[1] for r in pr) / len(pr)
+            out["imbalance_render"] = None if mean_render <= 0 else round(max(r[1] for r in pr) / mean_render, 4)
+            out["reduce_ms"] = round(max(r[2] for r in pr) * k, 3)          # the slowest rank's share of a step spent in the collective
         oracle_counters = None
         if not args.no_cpu_baseline and world == 1:        # the CPU baseline is a one-GPU-run item (rank 0, N = 1 only)
             out["cpu_baseline"], oracle_counters = cpu_baseline(res["cs"], W, H, spp, args.seed, cfg["short"])

@@ -38,6 +38,30 @@ class BvhNode(C.Structure):
     _fields_ = [("aabb_min", f32 * 3), ("shape_index", u32), ("aabb_max", f32 * 3), ("exit_index", u32)]
 
 
+def direction_classes(mode):
+    """hj_direction_classes (include/hijiki_hip.h): link orderings of a directional tree."""
+    if mode <= 0 or mode > 8:
+        return 1
+    return 6 if mode == 8 else 1 << bin(mode & 7).count("1")
+
+
+def ray_direction_class(mode, d):
+    """hj_ray_direction_class for an (n, 3) float32 array of directions."""
+    import numpy as np
+    b = np.ascontiguousarray(d, np.float32).view(np.uint32).reshape(-1, 3)
+    if mode <= 0 or mode > 8:
+        return np.zeros(len(b), np.int64)
+    if mode == 8:
+        major = np.argmax(b & 0x7FFFFFFF, axis=1)          # (first of equals, as the C text)
+        return 2 * major + (b[np.arange(len(b)), major] >> 31).astype(np.int64)
+    cls, k = np.zeros(len(b), np.int64), 0
+    for a in range(3):
+        if mode & (1 << a):
+            cls |= (b[:, a] >> 31).astype(np.int64) << k
+            k += 1
+    return cls
+
+
 class Sphere(C.Structure):
     _fields_ = [("center", f32 * 3), ("radius", f32)]
 

@@ -46,6 +46,12 @@ std::string get_error(hj_context* ctx) {
   return ctx->error;
 }
 
+// (for a call that tried something optional, failed at it and went on: hj_last_error must not show the attempt's message after HJ_OK)
+void put_error(hj_context* ctx, const std::string& text) {
+  std::lock_guard<std::mutex> lock(ctx->err_mu);
+  ctx->error = text;
+}
+
 int dev_alloc(hj_context* ctx, DevBuf& b, size_t bytes) {
   if (b.bytes >= bytes && b.p) return HJ_OK;
   b.release();
@@ -94,7 +100,7 @@ int sync_all(hj_context* ctx) {
 
 extern "C" {
 
-uint32_t hj_version(void) { return (0u << 16) | (2u << 8) | 0u; }
+uint32_t hj_version(void) { return (0u << 16) | (3u << 8) | 0u; }   // 0.3.0: hj_render_stats grew (shadow_rays_proven_free), hj_scene_upload refuses non-tree link arrays
 
 void hj_default_render_opts(hj_render_opts* o) {
   if (!o) return;

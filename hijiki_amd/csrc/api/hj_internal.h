@@ -145,6 +145,7 @@ namespace hjapi {
 int env_int(const char* name, int dflt, int lo, int hi);
 int set_error(hj_context* ctx, int code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
 std::string get_error(hj_context* ctx);
+void put_error(hj_context* ctx, const std::string& text);
 int dev_alloc(hj_context* ctx, DevBuf& b, size_t bytes);
 std::mutex& alloc_mutex();                           // process-wide: a context sizing its batch slots (api/render.hip run_submit)
 int validate_scene(hj_context* ctx, const hj_scene_desc* s);   // api/scene_upload.hip: every invariant an upload checks

@@ -483,8 +483,10 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
     rc = put_records(ctx, top_records, d_out);
     if (rc != HJ_OK) return rc;
     const VoteShapes vsh{sh.spheres, sh.quads, sh.triangles, sh.vertices};
+    const std::string error_before = get_error(ctx);
     rc = vote_on_device(ctx, s, vsh, d_out, total, vote_paths, d_voted, timing, nullptr);
     if (rc != HJ_OK && rc != HJ_ERR_UNSUPPORTED) return rc;
+    if (rc == HJ_ERR_UNSUPPORTED) put_error(ctx, error_before);      // the build succeeds without the vote: no stale message behind HJ_OK
     mark("ray-voted child order");
     // (a tree deeper than the exchange's level loop goes - thousands of shapes in a chain - keeps the order it has)
     HJ_HIP(ctx, hipMemcpyAsync(out_nodes, rc == HJ_OK ? d_voted : d_out, sizeof(hj_bvh_node) * total, hipMemcpyDeviceToHost, st));

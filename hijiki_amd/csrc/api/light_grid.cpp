@@ -258,6 +258,12 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
   constexpr double kSinCell = 0.25, kSinEmitter = 0.1, kTMin = 2e-4, kEps = 1e-4;
   // the two escape arguments of the header must hold with room to spare at this scale, or there is no grid
   if (!((tol_p + tol_s) / kSinCell < 0.5 * kTMin && 2 * tol_s / kSinEmitter < 0.5 * kEps)) return false;
+  double scene_diag = 0, scene_maxabs = 0;                  // (what the emitter-side argument's rounding terms scale with)
+  for (int k = 0; k < 3; k++) {
+    scene_diag += (scene.hi[k] - scene.lo[k]) * (scene.hi[k] - scene.lo[k]);
+    scene_maxabs = std::max(scene_maxabs, std::max(std::fabs(scene.lo[k]), std::fabs(scene.hi[k])));
+  }
+  scene_diag = std::sqrt(scene_diag);
 
   // subtree bounds from the shapes: sub[i] covers every leaf with an index in [i, exit(i)).  One reverse pass; on large
   // arrays the pass is cut at the top of the tree: the ranges [a, exit(a)) of a frontier of nodes are disjoint blocks of the
@@ -348,7 +354,9 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
     for (size_t i = a; i < b; i++) {
       int lo[3], hi[3];
       cell_range(pad(widen(sb[i]), 2 * m), lo, hi);             // (shape and cell both padded by m)
-      for (int k = 0; k < 3; k++) { range[i].lo[k] = (uint8_t)lo[k]; range[i].hi[k] = (uint8_t)std::max(hi[k], 0); if (hi[k] < lo[k]) { range[i].lo[2] = 255; range[i].hi[2] = 0; } }
+      bool none = false;                                        // (a shape outside the grid: every shape lies inside today)
+      for (int k = 0; k < 3; k++) { range[i].lo[k] = (uint8_t)lo[k]; range[i].hi[k] = (uint8_t)std::max(hi[k], 0); none = none || hi[k] < lo[k]; }
+      if (none) { range[i].lo[2] = 255; range[i].hi[2] = 0; }   // the empty range, set AFTER the loop (k = 2 would overwrite it)
     }
   });
   parallel_pieces(res, 1, [&](size_t z0, size_t z1, unsigned) {
@@ -397,7 +405,13 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
       }
       { double v[4][3]; const int nv = g.vertices(em.shape, v); for (int c = 0; c < nv; c++) for (int k = 0; k < 3; k++) big = std::max(big, std::fabs(v[c][k])); }
       em.slack = dev + 4.0 * 5.97e-8 * big;
-      em.sin_min = std::min(kSinEmitter, std::max(0.03, em.slack / (0.25 * kEps)));
+      // ... and the ARITHMETIC's share grows with the scene: the reference's t = (1 / (d.n)) * (-(n.ro)) for a shape in Q loses, to the
+      // cancellation in both dot products, about 6 ulp x |ro| / sin, and the rounding of ro = o - a another ulp of the largest
+      // coordinate / sin (|ro| <= the scene's diagonal).  Half of eps for that, a quarter for the geometry: the view has to be
+      // steeper in a larger scene, and where even 0.1 does not keep the sum inside eps this emitter proves nothing.
+      const double arith = 5.97e-8 * (6.0 * scene_diag + 2.0 * std::max(big, scene_maxabs));
+      em.sin_min = std::min(kSinEmitter, std::max(0.03, std::max(em.slack / (0.25 * kEps), arith / (0.5 * kEps))));
+      if (!(em.slack / em.sin_min <= 0.25 * kEps && arith / em.sin_min <= 0.5 * kEps)) em.ok = false;
     }
     ems.push_back(em);
   }
@@ -480,6 +494,17 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
 // Test entry (no GPU needed): the grid hj_scene_upload would build for `s`.  bits: res^3 bytes (may be null: sizes only).
 extern "C" __attribute__((visibility("default"))) int hj_debug_light_grid(const hj_scene_desc* s, uint32_t res, uint8_t* bits, float lo[3],
                                                                            float inv[3], uint64_t stats[3]) {
+  // build_light_grid trusts what hj_scene_upload has validated; this entry takes a desc nobody has looked at: the same range checks
+  // first (a desc that fails them has no grid)
+  if (!s || !s->bvh || s->num_bvh_nodes == 0) return 0;
+  const size_t shapes = s->num_spheres + s->num_quads + s->num_triangles;
+  if ((s->num_spheres && !s->spheres) || (s->num_quads && !s->quads) || (s->num_triangles && !s->triangles) ||
+      (s->num_vertices && !s->vertices) || (s->num_emitters && !s->emitters) || (shapes && !s->materials) || s->num_materials != shapes) return 0;
+  for (size_t i = 0; i < s->num_triangles; i++)
+    for (int c = 0; c < 3; c++) if (s->triangles[i].v[c] >= s->num_vertices) return 0;
+  for (size_t i = 0; i < s->num_bvh_nodes; i++)
+    if (s->bvh[i].shape_index != HJ_BVH_INNER && s->bvh[i].shape_index >= shapes) return 0;
+  for (size_t e = 0; e < s->num_emitters; e++) if (s->emitters[e].shape >= shapes) return 0;
   hjapi::LightGrid g;
   if (!hjapi::build_light_grid(s, res, g)) return 0;
   if (bits) std::memcpy(bits, g.bits.data(), g.bits.size());

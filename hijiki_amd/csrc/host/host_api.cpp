@@ -189,6 +189,18 @@ int hjh_compiled_tune_bvh(hjh_compiled* c, int reinsert_passes, size_t vote_path
     return (int)HJ_OK;
   });
 }
+int hjh_compiled_directional_bvh(const hjh_compiled* c, int mode, size_t vote_paths, int fallback, int geometric_only,
+                                 hj_bvh_node* out, size_t capacity) {
+  if (!c || !out) return fail(HJ_ERR_INVALID, "null argument");
+  if (mode < 0 || mode > 8) return fail(HJ_ERR_INVALID, "direction mode must be 0 ... 8");
+  if (capacity < c->cs.bvh.size() * (size_t)hj_direction_classes(mode)) return fail(HJ_ERR_INVALID, "out holds fewer than classes x nodes records");
+  return guarded([&] {
+    std::vector<hj_bvh_node> arrays;
+    directional_bvh(c->cs, mode, vote_paths, fallback, geometric_only != 0, arrays);
+    std::memcpy(out, arrays.data(), arrays.size() * sizeof(hj_bvh_node));
+    return (int)HJ_OK;
+  });
+}
 size_t hjh_compiled_packed_size(const hjh_compiled* c) { return c ? c->cs.packed_size() : 0; }
 int hjh_compiled_pack(const hjh_compiled* c, void* buffer, size_t size) {
   if (!c || !buffer) return fail(HJ_ERR_INVALID, "null argument");

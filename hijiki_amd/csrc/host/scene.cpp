@@ -432,6 +432,24 @@ void tune_bvh(CompiledScene& cs, int reinsert_passes, size_t vote_paths) {
   flatten_bvh(tree, [](int32_t shape) { return (uint32_t)shape; }, cs.bvh);
 }
 
+// K link orderings of an installed tree, one per direction class of the rays (include/hijiki_hip.h: hj_ray_direction_class): the
+// same boxes and leaves, flattened K times with the child order each class voted for.  out = K arrays of cs.bvh.size() records.
+void directional_bvh(const CompiledScene& cs, int mode, size_t vote_paths, int fallback, bool geometric_only, std::vector<hj_bvh_node>& out) {
+  const std::vector<BuildNode> tree = unflatten_bvh(cs.bvh);
+  const size_t n = tree.size(), K = (size_t)hj_direction_classes(mode);
+  std::vector<uint8_t> orders;
+  directional_child_orders(tree, scene_of(cs), vote_paths, mode, fallback, geometric_only, orders);
+  out.resize(n * K);
+  std::vector<hj_bvh_node> one;
+  for (size_t c = 0; c < K; c++) {
+    std::vector<BuildNode> t = tree;
+    for (size_t i = 0; i < n; i++)
+      if (orders[c * n + i]) { std::swap(t[i].left, t[i].right); std::swap(t[i].left_box, t[i].right_box); }
+    flatten_bvh(t, [](int32_t shape) { return (uint32_t)shape; }, one);
+    std::memcpy(out.data() + c * n, one.data(), n * sizeof(hj_bvh_node));
+  }
+}
+
 // ---------------------------------------------------------------- compile
 
 CompiledScene compile(const Scene& scene) {

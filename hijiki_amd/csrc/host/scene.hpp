@@ -87,6 +87,10 @@ void flatten_bvh(const std::vector<BuildNode>& tree, const std::function<uint32_
 std::vector<BuildNode> unflatten_bvh(const std::vector<hj_bvh_node>& bvh);
 Scene scene_of(const CompiledScene& cs);
 void tune_bvh(CompiledScene& cs, int reinsert_passes, size_t vote_paths);
+// One child order per direction class of the rays (tree_opt.cpp, scene.cpp): K = hj_direction_classes(mode) link orderings of the installed tree.
+void directional_child_orders(const std::vector<BuildNode>& nodes, const Scene& scene, size_t num_paths, int mode, int fallback,
+                              bool geometric_only, std::vector<uint8_t>& orders);
+void directional_bvh(const CompiledScene& cs, int mode, size_t vote_paths, int fallback, bool geometric_only, std::vector<hj_bvh_node>& out);
 
 // Synthetic bench scenes.
 Scene make_synthetic(int kind, uint32_t mesh_triangles, uint32_t gen_seed);

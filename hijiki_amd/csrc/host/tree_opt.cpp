@@ -20,6 +20,7 @@
 #include <cstring>
 #include <limits>
 #include <queue>
+#include <system_error>
 #include <thread>
 
 namespace hijiki {
@@ -142,6 +143,9 @@ double optimize_by_reinsertion(std::vector<BuildNode>& nodes, int passes) {
 
 namespace {
 
+inline int direction_classes(int mode) { return hj_direction_classes(mode); }
+inline int ray_direction_class(int mode, const float d[3]) { return hj_ray_direction_class(mode, d); }
+
 struct V3 { float x, y, z; };
 inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -169,14 +173,19 @@ struct Voter {
   std::vector<uint32_t> tin, tout;             // DFS interval of every node; a leaf's tin locates its shape
   std::vector<uint32_t> leaf_tin;              // per object
   std::vector<int32_t> emitters;               // objects with an emissive material
-  std::vector<std::atomic<uint32_t>> gain_l, gain_r;   // node visits the sample saves when the left / right child comes first
+  // node visits the sample saves when the left / right child comes first: [class * nodes + node], 64-bit (a node near the
+  // root collects up to 4 x its subtree's size per ray: a million paths would wrap 32 bits)
+  std::vector<std::atomic<uint64_t>> gain_l, gain_r;
+  int dir_mode = 0;                            // direction classes of the rays (ray_class): 0 = one class
+  size_t nclass = 1;
   // Weight of a shadow ray's vote in quarters of a closest-hit ray's (HJ_BVH_VOTE_SHADOW).  On the trees hj_scene_upload builds its
   // light-shaft grid for (fewer than 300 000 records) the renderer walks only the shadow rays the grid cannot prove free, a quarter
   // of them on the box scenes: 1; on larger trees all of them: 4.  (c3 +1.9 % with 1 against 4, c2 the same, c4 -1.5 %.)
   uint32_t w_shadow = 4;
 
-  Voter(const std::vector<BuildNode>& nd, const Scene& sc) : nodes(nd), scene(sc), box(nd.size()), tin(nd.size()), tout(nd.size()),
-        leaf_tin(sc.objects.size(), 0), gain_l(nd.size()), gain_r(nd.size()) {
+  Voter(const std::vector<BuildNode>& nd, const Scene& sc, int mode = 0) : nodes(nd), scene(sc), box(nd.size()), tin(nd.size()), tout(nd.size()),
+        leaf_tin(sc.objects.size(), 0), gain_l(nd.size() * (size_t)direction_classes(mode)), gain_r(nd.size() * (size_t)direction_classes(mode)),
+        dir_mode(mode), nclass((size_t)direction_classes(mode)) {
     box[0] = join2(nodes[0].left_box, nodes[0].right_box);
     uint32_t clock = 0;
     std::vector<std::pair<int32_t, bool>> st{{0, false}};
@@ -192,7 +201,7 @@ struct Voter {
       st.push_back({b.right, false});
       st.push_back({b.left, false});
     }
-    for (size_t i = 0; i < nd.size(); i++) { gain_l[i].store(0, std::memory_order_relaxed); gain_r[i].store(0, std::memory_order_relaxed); }
+    for (size_t i = 0; i < gain_l.size(); i++) { gain_l[i].store(0, std::memory_order_relaxed); gain_r[i].store(0, std::memory_order_relaxed); }
     for (size_t i = 0; i < sc.objects.size(); i++)
       if (sc.materials[sc.objects[i].second].tag == HJ_MAT_EMISSIVE) emitters.push_back((int32_t)i);
     const char* e = std::getenv("HJ_BVH_VOTE_SHADOW");
@@ -271,20 +280,20 @@ struct Voter {
   // before the ray's hit.  At a node whose child X holds the hit: putting X first spares a closest-hit ray the nodes of the
   // other child that lie behind the hit (ci - ct of the other child: tMax = t_hit culls them), an any-hit ray all of them (ci).
   struct Cnt { uint32_t ci, ct; };
-  Cnt vote(int32_t nd, const SRay& r, const Prep& p, bool before, uint32_t hit_pos, int depth) {
+  Cnt vote(int32_t nd, const SRay& r, const Prep& p, bool before, uint32_t hit_pos, int depth, size_t cls) {
     const BuildNode& b = nodes[nd];
     if (b.shape >= 0 || depth > 160) return {1u, before ? 1u : 0u};
     Cnt cl{0, 0}, cr{0, 0};
     const float el = entry(b.left_box, p, r.tmin, r.tmax), er = entry(b.right_box, p, r.tmin, r.tmax);
-    if (el < kInfF) cl = vote(b.left, r, p, el < r.hit_t, hit_pos, depth + 1);
-    if (er < kInfF) cr = vote(b.right, r, p, er < r.hit_t, hit_pos, depth + 1);
+    if (el < kInfF) cl = vote(b.left, r, p, el < r.hit_t, hit_pos, depth + 1, cls);
+    if (er < kInfF) cr = vote(b.right, r, p, er < r.hit_t, hit_pos, depth + 1, cls);
     if (r.hit >= 0) {
       if (hit_pos >= tin[b.left] && hit_pos < tout[b.left]) {
         const uint32_t g = r.any ? cr.ci * w_shadow : (cr.ci - cr.ct) * 4u;
-        if (g) gain_l[nd].fetch_add(g, std::memory_order_relaxed);
+        if (g) gain_l[cls + (size_t)nd].fetch_add(g, std::memory_order_relaxed);
       } else if (hit_pos >= tin[b.right] && hit_pos < tout[b.right]) {
         const uint32_t g = r.any ? cl.ci * w_shadow : (cl.ci - cl.ct) * 4u;
-        if (g) gain_r[nd].fetch_add(g, std::memory_order_relaxed);
+        if (g) gain_r[cls + (size_t)nd].fetch_add(g, std::memory_order_relaxed);
       }
     }
     return {1u + cl.ci + cr.ci, before ? 1u + cl.ct + cr.ct : 0u};
@@ -293,7 +302,8 @@ struct Voter {
     const Prep p = prep(r);
     const float e0 = entry(box[0], p, r.tmin, r.tmax);
     if (e0 == kInfF) return;
-    (void)vote(0, r, p, e0 < r.hit_t, r.hit >= 0 ? leaf_tin[r.hit] : 0u, 0);
+    const float d[3] = {r.d.x, r.d.y, r.d.z};
+    (void)vote(0, r, p, e0 < r.hit_t, r.hit >= 0 ? leaf_tin[r.hit] : 0u, 0, (size_t)ray_direction_class(dir_mode, d) * nodes.size());
   }
 
   // surface point, shading normal and material of a hit (populate*, scene.glsl:160-175, without the tangent frames)
@@ -388,16 +398,33 @@ struct Voter {
 
 }  // namespace
 
+namespace {
+
+// The sample's paths over the host's threads (the gains are integer sums: the result does not depend on the thread count).  A
+// thread that cannot be started leaves its paths to the caller's thread.
+void run_paths(Voter& v, size_t num_paths) {
+  unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (num_paths < 4096) nt = 1;
+  std::vector<std::thread> th;
+  std::vector<unsigned> inline_shares;
+  for (unsigned k = 0; k < nt; k++) {
+    try {
+      th.emplace_back([&v, k, nt, num_paths] { for (size_t i = k; i < num_paths; i += nt) v.path(i); });
+    } catch (const std::system_error&) {
+      inline_shares.push_back(k);
+    }
+  }
+  for (unsigned k : inline_shares) for (size_t i = k; i < num_paths; i += nt) v.path(i);
+  for (auto& t : th) t.join();
+}
+
+}  // namespace
+
 // Returns the number of inner nodes whose children were exchanged.
 size_t order_children_by_rays(std::vector<BuildNode>& nodes, const Scene& scene, size_t num_paths) {
   if (nodes.size() < 3 || num_paths == 0) return 0;
   Voter v(nodes, scene);
-  unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-  if (num_paths < 4096) nt = 1;
-  std::vector<std::thread> th;
-  for (unsigned k = 0; k < nt; k++)
-    th.emplace_back([&, k] { for (size_t i = k; i < num_paths; i += nt) v.path(i); });
-  for (auto& t : th) t.join();
+  run_paths(v, num_paths);
   size_t swapped = 0;
   for (size_t i = 0; i < nodes.size(); i++) {
     BuildNode& b = nodes[i];
@@ -410,6 +437,44 @@ size_t order_children_by_rays(std::vector<BuildNode>& nodes, const Scene& scene,
   }
   if (std::getenv("HJ_BVH_VERBOSE")) std::fprintf(stderr, "ray-voted child order: %zu paths, %zu of %zu inner nodes exchanged\n", num_paths, swapped, nodes.size() / 2);
   return swapped;
+}
+
+// One child order per DIRECTION CLASS of the rays (hj_ray_direction_class): the sample is partitioned by class and every class
+// votes for itself; a node on which a class has no opinion (no ray of the class that hit below it, or a tie) takes
+//   fallback 0: the order it has in `nodes` (the static order, voted by all rays or not);
+//   fallback 1: the class's geometric near-first order (the child whose box centre comes first along the class's mean direction).
+// orders[c * nodes.size() + i] = 1 when node i's children change places in class c.  `geometric_only` skips the vote.
+void directional_child_orders(const std::vector<BuildNode>& nodes, const Scene& scene, size_t num_paths, int mode, int fallback,
+                              bool geometric_only, std::vector<uint8_t>& orders) {
+  const size_t n = nodes.size(), K = (size_t)direction_classes(mode);
+  orders.assign(n * K, 0);
+  if (n < 3) return;
+  Voter v(nodes, scene, mode);
+  if (!geometric_only && num_paths > 0) run_paths(v, num_paths);
+  // mean direction of a class: signs (+-1, +-1, +-1) on the selected axes, 0 elsewhere; the major-axis classes: +-e_axis
+  auto class_dir = [&](size_t c, float out[3]) {
+    out[0] = out[1] = out[2] = 0.f;
+    if (mode == HJ_DIR_MODE_MAJOR_AXIS) { out[c / 2] = (c & 1) ? -1.f : 1.f; return; }
+    int k = 0;
+    for (int a = 0; a < 3; a++) if (mode & (1 << a)) out[a] = ((c >> k++) & 1) ? -1.f : 1.f;
+  };
+  for (size_t c = 0; c < K; c++) {
+    float dir[3];
+    class_dir(c, dir);
+    for (size_t i = 0; i < n; i++) {
+      const BuildNode& b = nodes[i];
+      if (b.shape >= 0) continue;
+      const uint64_t gl = v.gain_l[c * n + i].load(std::memory_order_relaxed), gr = v.gain_r[c * n + i].load(std::memory_order_relaxed);
+      bool swap = false;
+      if (gl != gr) swap = gr > gl;
+      else if (fallback == 1 || geometric_only) {
+        float s = 0.f;
+        for (int a = 0; a < 3; a++) s += dir[a] * ((b.right_box.lo[a] + b.right_box.hi[a]) - (b.left_box.lo[a] + b.left_box.hi[a]));
+        swap = s < 0.f;      // the right child's centre comes first along the class direction
+      }
+      orders[c * n + i] = swap ? 1 : 0;
+    }
+  }
 }
 
 }  // namespace hijiki

@@ -548,6 +548,9 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
             // intersectScene(shadowRay) is known to be false for this cell and emitter (api/light_grid.cpp): the sample is
             // added here, where render.glsl:122-124 adds it, instead of after a walk in the next round
             add_now = shadow_ray_proven_free(sc, its.p, em);
+#ifdef HJ_PROBE_ALL_SHADOW_FREE   // measurement only (WRONG image): no shadow ray is ever walked - the ceiling of everything a visibility structure could prove
+            add_now = true;
+#endif
             want_shadow = !add_now;
           }
           const v3 l = rand_cos_hemisphere(rng);                                           // material.glsl:37-46

@@ -115,6 +115,19 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+def gather_over_ranks(values, device=None):
+    """Every rank's list of host scalars, as a (world, len(values)) list of lists on every rank (one all_gather)."""
+    import torch
+    import torch.distributed as dist
+    if not _active():
+        return [[float(v) for v in values]]
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=(f"cuda:{device}" if on_gpu else "cpu"))
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.cpu().tolist() for o in out]
+
+
 class ShardedRenderer:
     """A `device.Renderer` whose framebuffer is a torch CUDA tensor, so RCCL can reduce it in place."""
 
@@ -131,6 +144,22 @@ class ShardedRenderer:
         self.renderer.upload_scene(compiled)
         self.renderer.create_framebuffer(width, height, external_device_ptr=self.fb.data_ptr())
         self.width, self.height = width, height
+        self.reset_timing()
+
+    def reset_timing(self):
+        """Host wall time this rank spent (a) inside the render calls - submitting frames and waiting for them - and (b) inside the
+        framebuffer reduces (the collective is made to finish before the clock stops: a rank that waits for a slower peer sees it
+        here), since the last reset.  bench.py gathers them per rank: the first multi-GPU run has to explain itself."""
+        self.timing = {"render_s": 0.0, "reduce_s": 0.0, "frames": 0}
+
+    def _timed_reduce(self, fb):
+        import time
+        import torch
+        t = time.perf_counter()
+        reduce_framebuffer(fb, root=0)
+        if _active() and fb.is_cuda:
+            torch.cuda.current_stream(self.local).synchronize()      # (torch's nccl work has been joined to this stream)
+        self.timing["reduce_s"] += time.perf_counter() - t
 
     def reserve(self, spp, opts=None):
         """Allocate the batch slots this rank's share of an spp-pass frame needs (set-up: the first frame then renders at speed)."""
@@ -140,12 +169,16 @@ class ShardedRenderer:
 
     def render_frame(self, spp, master_seed, opts=None, reduce=True):
         """Zero the buffer, render this rank's blocks of all passes, reduce to rank 0.  Returns the stats dict."""
+        import time
         import torch
         self.fb.zero_()
         torch.cuda.synchronize(self.local)      # the C ABI renders on its own stream
+        t = time.perf_counter()
         stats = self.renderer.render_frame(spp, master_seed, rank=self.rank, world=self.world, opts=opts)
+        self.timing["render_s"] += time.perf_counter() - t
+        self.timing["frames"] += 1
         if reduce:
-            reduce_framebuffer(self.fb, root=0)
+            self._timed_reduce(self.fb)
         return stats
 
     def render_frames(self, steps, spp, master_seed, opts=None, reduce=True):
@@ -154,6 +187,7 @@ class ShardedRenderer:
         reduced, so the path-depth tail of a frame's last batches runs beside the first batches of the next one, and the
         collective beside the rendering.  Every frame is complete and reduced when this returns; the LAST frame is in
         `self.fb`.  Returns the statistics summed over the frames.  Frames are the blocking call's, bit for bit."""
+        import time
         import torch
         # THREE framebuffers in turn, not two: frame k + 1 may only be submitted into a buffer whose last reduce has completed, and
         # the collective's kernels have to find room on a GPU that frame k's persistent workgroups fill - with two buffers that
@@ -168,15 +202,20 @@ class ShardedRenderer:
             fb = bufs[k]
             fb.zero_()                                 # (behind the reduce of the frame that last used this buffer, on torch's stream)
             torch.cuda.current_stream(self.local).synchronize()
+            t = time.perf_counter()
             self.renderer.bind_framebuffer(fb.data_ptr())
             self.renderer.submit_frame(spp, master_seed, rank=self.rank, world=self.world, opts=opts)
             if k >= 1:
                 self.renderer.pipeline_wait(keep=1)    # frame k - 1 is complete (frame k renders on)
-                if reduce:
-                    reduce_framebuffer(bufs[k - 1], root=0)
+            self.timing["render_s"] += time.perf_counter() - t
+            if k >= 1 and reduce:
+                self._timed_reduce(bufs[k - 1])
+        t = time.perf_counter()
         stats = self.renderer.pipeline_wait(keep=0)
+        self.timing["render_s"] += time.perf_counter() - t
+        self.timing["frames"] += steps
         if reduce:
-            reduce_framebuffer(bufs[steps - 1], root=0)
+            self._timed_reduce(bufs[steps - 1])
         self.renderer.bind_framebuffer(self.fb.data_ptr())
         return stats
 

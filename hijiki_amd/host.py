@@ -53,6 +53,7 @@ def lib():
         L.hjh_compiled_pack.argtypes = [vp, vp, C.c_size_t]
         L.hjh_compiled_set_bvh.argtypes = [vp, C.POINTER(abi.BvhNode), C.c_size_t]
         L.hjh_compiled_tune_bvh.argtypes = [vp, C.c_int, C.c_size_t]
+        L.hjh_compiled_directional_bvh.argtypes = [vp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(abi.BvhNode), C.c_size_t]
         L.hjh_num_blocks_per_pass.argtypes = [C.c_uint32] * 3
         L.hjh_num_blocks_per_pass.restype = C.c_size_t
         L.hjh_make_blocks.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
@@ -254,6 +255,15 @@ class CompiledScene:
         tree, e.g. after `set_bvh(renderer.build_bvh(self))`."""
         _check(lib().hjh_compiled_tune_bvh(self._h, int(reinsert_passes), int(vote_paths)))
         _check(lib().hjh_compiled_desc(self._h, C.byref(self.desc)))
+
+    def directional_bvh(self, mode, vote_paths=60000, fallback=0, geometric_only=False):
+        """hjh_compiled_directional_bvh: (K, num_nodes) link orderings of the installed tree, one per direction class of the rays."""
+        n = int(self.desc.num_bvh_nodes)
+        k = abi.direction_classes(mode)
+        out = np.zeros((k, n, 8), np.uint32)         # the reference's record layout, as set_bvh takes it
+        _check(lib().hjh_compiled_directional_bvh(self._h, int(mode), int(vote_paths), int(fallback), int(bool(geometric_only)),
+                                                  out.ctypes.data_as(C.POINTER(abi.BvhNode)), k * n))
+        return out
 
     def packed(self):
         """The reference's packed scene buffer image (src/main.rs:561-605)."""

@@ -78,6 +78,36 @@ typedef struct hj_bvh_node {
   uint32_t exit_index;   /* node to visit when this subtree is skipped / done   */
 } hj_bvh_node;
 
+/* Direction classes of a ray (no counterpart upstream: shader/scene.glsl:97-133 visits the two children of a node in ARRAY order
+ * whatever the ray's direction).  A "directional" tree is K skip-link arrays over the same boxes and leaves that differ only in
+ * which child of a node comes first; a ray walks array hj_ray_direction_class(mode, d) from its root to its end.  The class is
+ * a function of the SIGN BITS of the direction's components (mode 1..7: bit a of `mode` selects axis a, K = 2^axes, e.g. 7 = the
+ * eight octants) or of its major axis and that component's sign (mode 8, K = 6).  One text for the host compiler, the oracle and
+ * the kernels. */
+#define HJ_DIR_MODE_NONE 0
+#define HJ_DIR_MODE_OCTANTS 7
+#define HJ_DIR_MODE_MAJOR_AXIS 8
+#define HJ_DIR_MAX_CLASSES 8
+static inline int hj_direction_classes(int mode) {
+  if (mode <= 0 || mode > 8) return 1;
+  if (mode == 8) return 6;
+  return 1 << ((mode & 1) + ((mode >> 1) & 1) + ((mode >> 2) & 1));
+}
+static inline int hj_ray_direction_class(int mode, const float d[3]) {
+  uint32_t b[3];
+  int a, k = 0, cls = 0;
+  if (mode <= 0 || mode > 8) return 0;
+  for (a = 0; a < 3; a++) { union { float f; uint32_t u; } c; c.f = d[a]; b[a] = c.u; }
+  if (mode == 8) {
+    int major = 0;
+    uint32_t best = b[0] & 0x7FFFFFFFu;
+    for (a = 1; a < 3; a++) if ((b[a] & 0x7FFFFFFFu) > best) { best = b[a] & 0x7FFFFFFFu; major = a; }
+    return 2 * major + (int)(b[major] >> 31);
+  }
+  for (a = 0; a < 3; a++) if (mode & (1 << a)) cls |= (int)(b[a] >> 31) << k++;
+  return cls;
+}
+
 /* Sphere, src/shape.rs:6-11 / shader/shapes/sphere.glsl:1-3.  16 bytes. */
 typedef struct hj_sphere { float center[3]; float radius; } hj_sphere;
 

@@ -70,6 +70,13 @@ int  hjh_compiled_set_bvh(hjh_compiled* c, const hj_bvh_node* nodes, size_t n);
  * camera paths (60000 is what compile uses).  The tree must be a pre-order skip-link tree; the image changes at most in epsilon
  * ties, as with any other tree over the same shapes. */
 int  hjh_compiled_tune_bvh(hjh_compiled* c, int reinsert_passes, size_t vote_paths);
+/* K = hj_direction_classes(mode) link orderings of the installed tree, one per direction class of the rays (hijiki_hip.h:
+ * hj_ray_direction_class): same boxes, same leaves, the child order each class of a sample of `vote_paths` camera paths votes
+ * for; where a class has no opinion: the installed order (fallback 0) or the class's geometric near-first order (fallback 1);
+ * geometric_only skips the vote.  out receives K arrays of num_bvh_nodes records each, every one a valid pre-order skip-link
+ * tree (array 0 first).  No counterpart upstream (shader/scene.glsl:97-133 walks one fixed order). */
+int  hjh_compiled_directional_bvh(const hjh_compiled* c, int mode, size_t vote_paths, int fallback, int geometric_only,
+                                  hj_bvh_node* out, size_t capacity);
 /* Size of the reference's packed scene buffer (12 sub-buffers padded to
  * 256 B, src/main.rs:314-339) and the packing itself (src/main.rs:561-605),
  * for tools that want the reference's exact buffer image. */

@@ -57,6 +57,12 @@ typedef struct { float x, y, z; } v3;
 
 static inline float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+/* IEEE negation of a value an fmaf just produced.  gcc folds -fmaf(a, b, c) into ONE vfnmsub instruction, which computes
+ * -(a*b) - c: the same number, but +0 where the negated +0 sum is -0 (ab = -0, c = +0, or exact cancellation of non-zero terms).
+ * HJ-NUM-1 says negation flips the sign bit, as the kernels' source modifiers do; a zero's sign decides the
+ * sign of 1 / d for a direction component, i.e. what the slab test answers.  Found by tests/test_gpu_fuzz.py (round 6): rays that
+ * start exactly in a quad's plane gave t = +0 here and -0 on the GPU.  The empty asm hides the producer from the fold. */
+static inline float neg_of(float x) { __asm__("" : "+x"(x)); return -x; }
 
 /* IEEE-754-2008 minNum / maxNum (a quiet NaN loses against a number). */
 static inline float f_min(float a, float b) {
@@ -125,9 +131,9 @@ static inline void hj_sincos2pi(float v, float* s_out, float* c_out) {
   float c = fmaf(cp, z * z, fmaf(-0.5f, z, 1.0f));
   int q = ((int)k) & 3;
   float S = s, C = c;
-  if (q == 1) { S = c; C = -s; }
-  else if (q == 2) { S = -s; C = -c; }
-  else if (q == 3) { S = -c; C = s; }
+  if (q == 1) { S = c; C = neg_of(s); }
+  else if (q == 2) { S = neg_of(s); C = neg_of(c); }
+  else if (q == 3) { S = neg_of(c); C = s; }
   *s_out = S; *c_out = C;
 }
 
@@ -250,6 +256,17 @@ static inline walk_ctr shadow_ctr(hjo_counters* c) {
   walk_ctr w = {&c->shadow_nodes, &c->shadow_tri_tests, &c->shadow_sphere_tests, &c->shadow_quad_tests, NULL, g_shadow_anyhit}; return w;
 }
 
+/* DIRECTIONAL TREES (no counterpart upstream: scene.glsl:97-133 walks ONE array): K link orderings of the scene's tree, one per
+ * direction class of the rays (include/hijiki_hip.h: hj_ray_direction_class); a ray walks the array of its class from node 0 to
+ * the end.  Same boxes, same leaves, same tests: results differ from the one-array walk only at epsilon ties (SURVEY C-11).
+ * arrays = K consecutive arrays of sc->num_bvh_nodes records; mode 0 / NULL switches back to sc->bvh. */
+static int g_dir_mode = 0;
+static const hj_bvh_node* g_dir_arrays = NULL;
+HJO_EXPORT void hjo_set_directional_bvh(int mode, const hj_bvh_node* arrays) {
+  g_dir_mode = (arrays || mode < 0) ? mode : 0;
+  g_dir_arrays = arrays;
+}
+
 static inline v3 ld3(const float* p) { return V(p[0], p[1], p[2]); }
 
 /* ------------------------------------------------------------ intersection */
@@ -267,10 +284,10 @@ static inline int intersect_triangle(const scene_t* S, const ray_t* r, uint32_t 
   v3 ro = v_sub(r->o, a);
   v3 q = cross3(ro, r->d);
   float d = 1.0f / dot3(r->d, n);
-  float u = d * (-dot3(q, ac));
+  float u = d * neg_of(dot3(q, ac));
   float v = d * dot3(q, ab);
   if (u < 0.0f || v < 0.0f || u + v > 1.0f) return 0;
-  float t = d * (-dot3(n, ro));
+  float t = d * neg_of(dot3(n, ro));
   if (r->tmin <= t && t <= r->tmax) {
     its->t = t; its->u = u; its->v = v;
     return 1;   /* its.n = normalize(n) is overwritten by populate */
@@ -300,10 +317,10 @@ static inline int intersect_quad(const ray_t* r, const hj_quad* qd, its_t* its) 
   v3 ro = v_sub(r->o, ld3(qd->origin));
   v3 q = cross3(ro, r->d);
   float d = 1.0f / dot3(r->d, n);
-  float u = d * (-dot3(q, e2));
+  float u = d * neg_of(dot3(q, e2));
   float v = d * dot3(q, e1);
   if (u < 0.0f || u > 1.0f || v < 0.0f || v > 1.0f) return 0;
-  float t = d * (-dot3(n, ro));
+  float t = d * neg_of(dot3(n, ro));
   if (r->tmin <= t && t <= r->tmax) { its->t = t; its->u = u; its->v = v; return 1; }
   return 0;
 }
@@ -353,10 +370,53 @@ static int intersect_scene(const scene_t* S, ray_t ray, its_t* its, walk_ctr c) 
   its->id = -1;
   const uint32_t ns = S->ns, nq = S->nq, nt = S->nt;
   if (S->use_bvh) {
-    const hj_bvh_node* bvh = S->sc->bvh;
     const uint32_t nn = (uint32_t)S->sc->num_bvh_nodes;
+    const hj_bvh_node* bvh = S->sc->bvh;
+    if (g_dir_mode > 0) {
+      const float dd[3] = {ray.d.x, ray.d.y, ray.d.z};
+      bvh = g_dir_arrays + (size_t)hj_ray_direction_class(g_dir_mode, dd) * nn;
+    }
     v3 inv = V(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
     v3 off = V(-(ray.o.x * inv.x), -(ray.o.y * inv.y), -(ray.o.z * inv.z));
+    if (g_dir_mode < 0) {
+      /* PROBE ONLY (tools/dir_order_probe.py): the bound a direction-dependent order can approach - every inner node's children
+       * visited nearer-box-first for THIS ray (an explicit stack; the far child is re-tested against the tMax the near one left,
+       * as the skip-link walk would).  Counts node records fetched like the walk below; finds the same hits but for epsilon ties. */
+      uint32_t stack[256];
+      int sp = 0;
+      stack[sp++] = 0;
+      while (sp) {
+        const uint32_t cur = stack[--sp];
+        const hj_bvh_node* nd = &bvh[cur];
+        (*c.nodes)++;
+        uint32_t shape = nd->shape_index;
+        if (shape != HJ_BVH_INNER) {
+          int hit;
+          if (shape < ns) { hit = intersect_sphere(&ray, &S->sc->spheres[shape], its); (*c.sphere)++; }
+          else if (shape < ns + nq) { hit = intersect_quad(&ray, &S->sc->quads[shape - ns], its); (*c.quad)++; }
+          else { hit = intersect_triangle(S, &ray, shape - ns - nq, its); (*c.tri)++; }
+          if (hit) { ray.tmax = its->t - M_EPSF; its->id = (int)shape; if (c.anyhit) return 1; }
+          continue;
+        }
+        float tnx = fmaf(nd->aabb_min[0], inv.x, off.x), tpx = fmaf(nd->aabb_max[0], inv.x, off.x);
+        float tny = fmaf(nd->aabb_min[1], inv.y, off.y), tpy = fmaf(nd->aabb_max[1], inv.y, off.y);
+        float tnz = fmaf(nd->aabb_min[2], inv.z, off.z), tpz = fmaf(nd->aabb_max[2], inv.z, off.z);
+        float t0 = f_max(f_max(f_min(tnx, tpx), f_min(tny, tpy)), f_min(tnz, tpz));
+        float t1 = f_min(f_min(f_max(tnx, tpx), f_max(tny, tpy)), f_max(tnz, tpz));
+        if (!(t0 < t1 + M_EPSF && t0 < ray.tmax && t1 > ray.tmin)) continue;
+        const uint32_t l = cur + 1, r = bvh[l].exit_index;
+        float e[2];
+        for (int k = 0; k < 2; k++) {
+          const hj_bvh_node* ch = &bvh[k ? r : l];
+          float ax = fmaf(ch->aabb_min[0], inv.x, off.x), bx = fmaf(ch->aabb_max[0], inv.x, off.x);
+          float ay = fmaf(ch->aabb_min[1], inv.y, off.y), by = fmaf(ch->aabb_max[1], inv.y, off.y);
+          float az = fmaf(ch->aabb_min[2], inv.z, off.z), bz = fmaf(ch->aabb_max[2], inv.z, off.z);
+          e[k] = f_max(f_max(f_min(ax, bx), f_min(ay, by)), f_min(az, bz));
+        }
+        if (sp + 2 > 256) continue;
+        if (e[0] <= e[1]) { stack[sp++] = r; stack[sp++] = l; } else { stack[sp++] = l; stack[sp++] = r; }
+      }
+    } else
     for (uint32_t cur = 0; cur < nn;) {
       const hj_bvh_node* nd = &bvh[cur];
       (*c.nodes)++;
@@ -467,7 +527,7 @@ static inline v3 sample_emitter(const scene_t* S, v3 ref, uint32_t* rng, ray_t* 
   float dist = len3(dir);
   dir = v_divs(dir, dist);
   sh->o = ref; sh->d = dir; sh->tmin = 2.0f * M_EPSF; sh->tmax = dist - M_EPSF;
-  float cosT = -dot3(dir, sr.n);
+  float cosT = neg_of(dot3(dir, sr.n));
   if (cosT < 0.0f) return V(0, 0, 0);
   float pdf = (((sc->emitters[e].pdf * sr.pdf) * dist) * dist) / cosT;
   return v_divs(power, pdf);
@@ -524,7 +584,7 @@ static inline v3 sample_bsdf(const scene_t* S, uint32_t mat, v3 wi, const its_t*
       const hj_dielectric* m = &S->sc->dielectric[idx];
       float eta = m->eta;
       float etaInv = 1.0f / eta;
-      float cosI = -dot3(its->n, wi);
+      float cosI = neg_of(dot3(its->n, wi));
       v3 normal = its->n;
       int inside = cosI > 0.0f;                 /* sic: the reference's flag is inverted (C-3) */
       if (cosI < 0.0f) {

@@ -75,6 +75,8 @@ def lib():
         L.hjo_dielectric_probe.argtypes = [C.c_float, fp, fp, u32p, fp]
         L.hjo_dielectric_probe.restype = None
         L.hjo_shade_probe.argtypes = [C.POINTER(abi.SceneDesc), fp, u32p, C.c_size_t, fp]
+        L.hjo_set_directional_bvh.argtypes = [C.c_int, C.c_void_p]
+        L.hjo_set_directional_bvh.restype = None
         L.hjo_sizeof_counters.restype = C.c_size_t
         assert L.hjo_sizeof_counters() == C.sizeof(Counters)
         _LIB = L

@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"static inline [^{]*\{.*?\n\}\n", "", text, flags=re.S)      # inline definitions (hj_ray_direction_class): not exports
     return sorted(set(re.findall(r"\b(hjh?_[a-z0-9_]+)\s*\(", text)))
 
 

@@ -55,11 +55,44 @@ def test_bench_two_ranks_under_torchrun(tmp_path, config, size, spp):
         assert out["value"] > 0 and abs(out["value"] - size * size * spp / (out["ms_per_step"] * 1e-3) / 1e6) < 0.01 * out["value"]
         assert out["roofline"]["launches"] >= 1 and out["roofline"]["achieved"] > 0
         assert config + ":" in out["config"]["workload"] and f"{size}x{size} {spp}spp" in out["config"]["workload"]
-    assert "mod 2" in two["config"]["partition"]
+    assert "mod 2" in two["config"]["partition"] and two["deal"] == "rotating"
+    _check_per_rank(two, 2, size * size * spp)
+    assert "per_rank" not in one
     # the reduced two-rank frame is the one-rank frame: every pixel's passes are summed as two partial sums (a few ulp)
     assert f1.shape == f2.shape == (size, size, 4) and np.isfinite(f2).all() and (f2[..., 3] > 0).all()
     np.testing.assert_allclose(f2, f1, rtol=5e-5, atol=1e-5)
     assert (f1 != f2).any() or spp == 1          # (really two partial sums: not the same bits everywhere)
+
+
+def _check_per_rank(out, n, paths_per_step):
+    """The fields that make a multi-GPU line explain itself (VERDICT r5 task 5): per rank and per step, wall time, time inside the
+    render calls and inside the reduces, the path kernels' exclusive GPU time, the work dealt; imbalance = max / mean."""
+    pr = out["per_rank"]
+    for key in ("wall_ms", "render_ms", "reduce_ms", "kernel_busy_ms", "paths", "rays"):
+        assert len(pr[key]) == n, key
+    assert all(v > 0 for v in pr["wall_ms"] + pr["render_ms"] + pr["kernel_busy_ms"]) and all(v >= 0 for v in pr["reduce_ms"])
+    assert sum(pr["paths"]) == paths_per_step * out["steps"] and min(pr["paths"]) > 0.8 * max(pr["paths"])      # every rank got its share
+    assert max(pr["wall_ms"]) <= out["ms_per_step"] * 1.001                     # the line's clock is the slowest rank's + the barrier
+    assert out["imbalance"] >= 1.0 and abs(out["imbalance"] - max(pr["kernel_busy_ms"]) / (sum(pr["kernel_busy_ms"]) / n)) < 1e-3
+    assert out["imbalance_render"] >= 1.0 and out["reduce_ms"] == max(pr["reduce_ms"])
+
+
+@pytest.mark.timeout(900)
+def test_bench_static_deal_two_ranks(tmp_path):
+    """`--static-deal`: all passes of a block on one rank (SURVEY 8(e)'s partition).  The line says so, and the reduced frame is the
+    one-rank frame BIT FOR BIT away from the 2-pixel aprons of the block borders (a pixel's passes are then summed on one rank, in
+    order, and the other rank adds zeros)."""
+    extra = ["--config", "c2", "--spp", "4"]
+    one, f1 = _bench(tmp_path, 1, extra, "n1")
+    two, f2 = _bench(tmp_path, 2, extra + ["--static-deal"], "n2s")
+    assert two["deal"] == "static" and "static deal" in two["config"]["partition"] and "mod 2" in two["config"]["partition"]
+    _check_per_rank(two, 2, 1024 * 1024 * 4)
+    interior = np.ones((1024, 1024), bool)
+    for b in range(128, 1024, 128):
+        interior[b - 2:b + 2, :] = False
+        interior[:, b - 2:b + 2] = False
+    assert (f2[interior].view(np.uint32) == f1[interior].view(np.uint32)).all()
+    np.testing.assert_allclose(f2, f1, rtol=5e-5, atol=1e-5)
 
 
 @pytest.mark.timeout(1500)
@@ -73,7 +106,8 @@ def test_bench_four_ranks_under_torchrun(tmp_path):
     one, f1 = _bench(tmp_path, 1, extra, "n1")
     four, f4 = _bench(tmp_path, 4, extra, "n4")
     assert four["n_gpus"] == 4 and four["rccl_ranks"] == 4 and four["rccl_backend"] == "gloo"
-    assert "mod 4" in four["config"]["partition"] and four["scaling"] == "strong" and four["steps"] == 1
+    assert "mod 4" in four["config"]["partition"] and four["scaling"] == "strong" and four["steps"] == 1 and four["deal"] == "rotating"
+    _check_per_rank(four, 4, 4096 * 4096 * 8)
     assert abs(four["value"] - 4096 * 4096 * 8 / (four["ms_per_step"] * 1e-3) / 1e6) < 0.01 * four["value"]
     assert f4.shape == (4096, 4096, 4) and np.isfinite(f4).all() and (f4[..., 3] > 0).all()
     np.testing.assert_allclose(f4, f1, rtol=5e-5, atol=1e-5)

@@ -48,3 +48,30 @@ def test_atan2_asin_accuracy(oracle):
     assert np.abs(got - np.arcsin(s.astype(np.float64))).max() < 5e-7
     assert np.isnan(L.hjo_atan2(0.0, 0.0))          # -> the reference's isnan guard sets uv.x = 0 (sphere.glsl:49-51)
     assert abs(L.hjo_atan2(1.0, 0.0) - np.pi / 2) < 1e-7 and abs(L.hjo_atan2(0.0, -1.0) - np.pi) < 1e-6
+
+
+def test_negation_keeps_the_sign_of_zero(oracle):
+    """HJ-NUM-1: negation flips the sign bit.  gcc folds -fmaf(a, b, c) into one vfnmsub (-(a b) - c): +0 where the negated sum is
+    -0.  The oracle hides the producer from that fold (neg_of); found in round 6 by tests/test_gpu_fuzz.py - rays that start exactly
+    in a quad's plane came back with t = +0 here and -0 from the kernels, whose source modifiers negate exactly.  A zero's sign is
+    the sign of 1 / d for a direction component: it decides what the slab test answers."""
+    from hijiki_amd import host
+    L = oracle.lib()
+    out = (C.c_float * 2)()
+    # sin(2 pi 0.5): quadrant 2, s = +0 -> S = -s = -0 (cos: exactly -1)
+    L.hjo_sincos2pi(0.5, out)
+    assert np.float32(out[0]).view(np.uint32) == 0x80000000 and out[1] == -1.0
+    L.hjo_sincos2pi(0.75, out)                      # quadrant 3: S = -c = -1, C = s = +0
+    assert out[0] == -1.0 and np.float32(out[1]).view(np.uint32) == 0
+    # a ray that starts IN the plane x = -1.2 of an axis-aligned quad, tMin = 0: n = e1 x e2 = (4.8, -0, +0), ro = (+0, y, z),
+    # n . ro = +0, t = d * (-(n . ro)) = -0 - and the hit is accepted (0 <= -0 in IEEE)
+    s = host.Scene()
+    s.set_camera_cbox()
+    m = s.add_diffuse((0.5, 0.5, 0.5))
+    s.add_quad((-1.2, 0.0, 1.2), (0.0, 0.0, -2.4), (0.0, 2.0, 0.0), m)
+    s.add_quad((1.2, 0.0, -1.2), (0.0, 0.0, 2.4), (0.0, 2.0, 0.0), s.add_emissive((1, 1, 1)))
+    cs = s.compile()
+    ray = np.array([[-1.2000000476837158, 0.6664191484451294, -0.800000011920929, 1.5898617506027222, -0.0, 1.8284574747085571, 0.0, np.inf]], np.float32)
+    for use_bvh in (False, True):
+        ids, t, u, v = oracle.intersect(cs, ray, use_bvh=use_bvh)
+        assert ids[0] == 0 and t.view(np.uint32)[0] == 0x80000000, (use_bvh, ids, t)
