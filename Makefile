@@ -16,7 +16,7 @@ HOST_HDR = hijiki_amd/csrc/host/scene.hpp hijiki_amd/csrc/host/blockgen.hpp incl
 # lbvh_build.hip and tree_vote.hip hold device code.  The register / scratch / LDS report of the path kernels: hijiki_amd/lib/resource_usage.txt.
 HIP_UNITS = context scene_upload scene_relayout render comm lbvh_build tree_vote
 HIP_OBJ = $(HIP_UNITS:%=build/obj/%.o) build/obj/blockgen.o build/obj/light_grid.o
-HIP_HDR = $(wildcard hijiki_amd/csrc/kernels/*.h) hijiki_amd/csrc/api/hj_internal.h hijiki_amd/csrc/api/light_grid.hpp hijiki_amd/csrc/api/scene_relayout.hpp hijiki_amd/csrc/api/tree_vote.hpp include/hijiki_hip.h hijiki_amd/csrc/host/blockgen.hpp
+HIP_HDR = $(wildcard hijiki_amd/csrc/kernels/*.h) hijiki_amd/csrc/api/hj_internal.h hijiki_amd/csrc/api/hj_tuning.h hijiki_amd/csrc/api/light_grid.hpp hijiki_amd/csrc/api/scene_relayout.hpp hijiki_amd/csrc/api/tree_vote.hpp include/hijiki_hip.h hijiki_amd/csrc/host/blockgen.hpp
 HIP_FLAGS = --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC $(FP_STRICT) -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden \
             -Wall -Wno-unused-function $(HIP_EXTRA)
 
@@ -40,7 +40,7 @@ build/obj/%.o: hijiki_amd/csrc/api/%.hip $(HIP_HDR)
 	@mkdir -p build/obj
 	$(HIPCC) $(HIP_FLAGS) -c $< -o $@
 
-build/obj/light_grid.o: hijiki_amd/csrc/api/light_grid.cpp hijiki_amd/csrc/api/light_grid.hpp include/hijiki_hip.h
+build/obj/light_grid.o: hijiki_amd/csrc/api/light_grid.cpp hijiki_amd/csrc/api/light_grid.hpp hijiki_amd/csrc/api/hj_tuning.h include/hijiki_hip.h
 	@mkdir -p build/obj
 	$(CXX) -std=c++17 -O2 -fPIC -pthread -Wall -Wextra $(FP_STRICT) -fvisibility=hidden -c $< -o $@
 

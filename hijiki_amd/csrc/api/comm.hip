@@ -62,7 +62,7 @@ std::vector<hj_comm*> g_cached_comms;        // communicators made on behalf of 
 // Test rigs without several GPUs (HJ_COMM_SHARED_GPU=1): the contexts of a communicator may live on one GPU; their
 // framebuffers are then summed by a kernel, in context order, instead of by RCCL.  Everything else of the multi-context
 // path (worker threads, frames in flight on all contexts, the joins inside the reduce) is the real thing.
-bool shared_gpu_allowed() { return env_int("HJ_COMM_SHARED_GPU", 0, 0, 1) != 0; }
+bool shared_gpu_allowed() { return Tuning::from_env().comm_shared_gpu != 0; }
 
 int check_reduce_args(hj_context* const* ctxs, int n, int root) {
   if (!ctxs || n < 1 || root < 0 || root >= n || !ctxs[root]) return HJ_ERR_INVALID;
@@ -108,7 +108,7 @@ int hj_comm_create(hj_context* const* ctxs, int n, hj_comm** out) {
   c->shared_gpu = shared;
   // HJ_COMM_FORCE_RCCL=1 (test rigs with one GPU): a single context also gets a communicator and its reduce goes through
   // ncclReduce (one rank, in place), so that the loader, the entry points and the stream handling run before a second GPU exists.
-  if ((n > 1 || env_int("HJ_COMM_FORCE_RCCL", 0, 0, 1) != 0) && !shared) {
+  if ((n > 1 || Tuning::from_env().comm_force_rccl != 0) && !shared) {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (!g_rccl.load()) {
       delete c;

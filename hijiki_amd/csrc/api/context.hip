@@ -20,12 +20,6 @@ namespace hjapi {
 std::atomic<size_t> g_dev_bytes{0};
 std::mutex& alloc_mutex() { static std::mutex mu; return mu; }
 
-int env_int(const char* name, int dflt, int lo, int hi) {
-  const char* v = std::getenv(name);
-  if (!v || !*v) return dflt;
-  return std::min(hi, std::max(lo, std::atoi(v)));
-}
-
 int set_error(hj_context* ctx, int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -39,6 +33,27 @@ int set_error(hj_context* ctx, int code, const char* fmt, ...) {
     g_create_error = buf;
   }
   return code;
+}
+
+uint64_t shape_arrays_hash(const hj_scene_desc* s) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  auto mix = [&](uint64_t v) { h = (h ^ v) * 0x100000001b3ull; h ^= h >> 29; };
+  auto array = [&](const void* p, size_t count, size_t elem) {
+    mix(count);
+    const size_t bytes = count * elem;
+    if (!p || bytes < 16) { if (p) for (size_t i = 0; i < bytes; i++) mix(static_cast<const unsigned char*>(p)[i]); return; }
+    const size_t pieces = std::min<size_t>(4096, bytes / 16), step = (bytes - 16) / std::max<size_t>(1, pieces - 1);
+    for (size_t k = 0; k < pieces; k++) {
+      uint64_t w[2];
+      std::memcpy(w, static_cast<const char*>(p) + std::min(bytes - 16, k * step), 16);
+      mix(w[0]); mix(w[1]);
+    }
+  };
+  array(s->spheres, s->num_spheres, sizeof(hj_sphere));
+  array(s->quads, s->num_quads, sizeof(hj_quad));
+  array(s->triangles, s->num_triangles, sizeof(hj_triangle));
+  array(s->vertices, s->num_vertices, sizeof(hj_vertex));
+  return h;
 }
 
 std::string get_error(hj_context* ctx) {
@@ -58,7 +73,7 @@ int dev_alloc(hj_context* ctx, DevBuf& b, size_t bytes) {
   if (bytes == 0) bytes = 16;
   // HJ_ALLOC_LIMIT_MB (test rig): the process's contexts together may hold no more than this; an allocation beyond it fails
   // the way hipMalloc does on a full device - how the out-of-memory paths run on a 288 GB card.
-  static const size_t limit = (size_t)env_int("HJ_ALLOC_LIMIT_MB", 0, 0, 1 << 30) << 20;
+  static const size_t limit = (size_t)Tuning::from_env().alloc_limit_mb << 20;
   if (limit != 0 && g_dev_bytes.load(std::memory_order_relaxed) + bytes > limit)
     return set_error(ctx, HJ_ERR_NOMEM, "hipMalloc(%zu bytes): out of memory (HJ_ALLOC_LIMIT_MB)", bytes);
   HJ_HIP(ctx, hipMalloc(&b.p, bytes));
@@ -152,21 +167,22 @@ int hj_context_create(int device, hj_context** out) {
   ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   // Tuning knobs (environment overrides exist only for sweeps; the defaults are the measured optima: DESIGN.md 4, profiles/NOTES.md).
-  ctx->num_wg = (uint32_t)ctx->num_cus * (uint32_t)env_int("HJ_WG_PER_CU", 8, 1, 32);   // 8 x 4 waves = the 32-wave CU limit
+  const Tuning tn = ctx->tuning = Tuning::from_env();
+  ctx->num_wg = (uint32_t)ctx->num_cus * (uint32_t)tn.wg_per_cu;   // 8 x 4 waves = the 32-wave CU limit
   // Small render calls (a rank's share of a frame on many GPUs) run 6 workgroups per CU: all of a kernel's workgroups are then
   // resident at once (7 x 4 waves fit a CU at 72 registers; with 8 per CU the last eighth of a batch's workgroups start when the
   // first ones end, a thin second wave that nothing covers at the end of a short frame) - an 8-rank share of the c2 frame 24.6 ->
   // 23.4 ms; large calls keep 8 (the 32768-block frame: 161 against 170 ms).  HJ_WG_SMALL / HJ_WG_SMALL_BLOCKS.
-  ctx->num_wg_small = std::min(ctx->num_wg, (uint32_t)ctx->num_cus * (uint32_t)env_int("HJ_WG_SMALL", 6, 1, 32));
+  ctx->num_wg_small = std::min(ctx->num_wg, (uint32_t)ctx->num_cus * (uint32_t)tn.wg_small);
   ctx->num_wg_eff = ctx->num_wg;
-  ctx->num_slots = (uint32_t)env_int("HJ_SLOTS", 3, 1, (int)kMaxSlots);
+  ctx->num_slots = (uint32_t)std::min<int>(tn.slots, (int)kMaxSlots);
   // positions per workgroup: the more paths a workgroup has in flight, the longer the walk phases of its rounds and the less
   // their ramp-down weighs.  One blocking frame after the other: 32768 is +4.5 % over 8192 on c2 / c3, 65536 (every sample
   // of a workgroup's share of an 8192-block batch in flight at once: round 3's default, 24.7 GB of path state per slot) +6 %.
   // Frames back to back: 16384 ... 65536 are the same within a per cent (c2 3433-3441 / 3404-3412 / 3391-3411, c3 2769 / 2773-2791 /
   // 2779-2788, c4 1166-1171 / 1160-1172 / 1160 Mrays/s at 16384 / 32768 / 65536; 8192: -2.5 %): the tails that a large pool
   // shortens are covered by the next frame there.  32768 = 12.4 GB per slot, 50 GB per context instead of 86.
-  ctx->pool = (uint32_t)env_int("HJ_POOL", 32768, 64, 1 << 20) / 64u * 64u;
+  ctx->pool = (uint32_t)tn.pool / 64u * 64u;
   for (auto& sl : ctx->slots) {
     if ((e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     if ((e = hipHostMalloc((void**)&sl.h_counts, sizeof(uint32_t) * 7 * ctx->num_wg, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
@@ -174,7 +190,7 @@ int hj_context_create(int device, hj_context** out) {
       if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   }
   // HJ_RECON_PRIORITY (default 1): the reconstructions run on one stream per slot of the device's highest priority.
-  if (env_int("HJ_RECON_PRIORITY", 1, 0, 1) != 0) {
+  if (tn.recon_priority != 0) {
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
       for (auto& sl : ctx->slots)
@@ -202,6 +218,7 @@ void hj_context_destroy(hj_context* ctx) {
     if (sl.rstream) (void)hipStreamSynchronize(sl.rstream);
   }
   release_scene(ctx);
+  ctx->resident.release();
   release_batch(ctx);
   for (auto& sl : ctx->slots) {
     sl.d_blocks.release();

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../../include/hijiki_hip.h"
+#include "hj_tuning.h"
 #include "../host/blockgen.hpp"
 #include "../kernels/hj_device.h"
 
@@ -136,15 +137,32 @@ struct hj_context {
   size_t pipe_k = 0;
   std::chrono::steady_clock::time_point pipe_wall0;
 
+  // The tree hj_build_bvh_device built last, still on the device together with the shape arrays it was built over: hj_scene_upload
+  // with scene->bvh == NULL takes it over (no trip through the host), hj_bvh_device_read copies it out.  Released by the next
+  // build, by the upload that consumes it, and with the context.
+  struct ResidentTree {
+    hjapi::DevBuf nodes, spheres, quads, triangles, vertices;
+    size_t total = 0, ns = 0, nq = 0, nt = 0, nv = 0;
+    uint64_t shapes_hash = 0;                    // hjapi::shape_arrays_hash of the arrays the tree was built over
+    bool valid = false;
+    void release() { nodes.release(); spheres.release(); quads.release(); triangles.release(); vertices.release(); total = 0; valid = false; }
+  } resident;
+
+  // the library's environment switches (api/hj_tuning.h) as the entry point in progress read them: hj_context_create, then every
+  // hj_scene_upload / render call / BVH build refreshes the copy at its start; nothing below an entry point reads the environment
+  hjapi::Tuning tuning;
+
   // hj_last_error: the worker thread writes `error` while the caller's thread may read it
   std::mutex err_mu;
 };
 
 namespace hjapi {
 
-int env_int(const char* name, int dflt, int lo, int hi);
 int set_error(hj_context* ctx, int code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
 std::string get_error(hj_context* ctx);
+// A fingerprint of a scene's shape arrays (counts + 4096 evenly spaced 16-byte pieces of each): guards the hand-over of a tree that
+// stayed on the device against an upload of OTHER geometry with the same counts (an accident, not an adversary).
+uint64_t shape_arrays_hash(const hj_scene_desc* s);
 void put_error(hj_context* ctx, const std::string& text);
 int dev_alloc(hj_context* ctx, DevBuf& b, size_t bytes);
 std::mutex& alloc_mutex();                           // process-wide: a context sizing its batch slots (api/render.hip run_submit)

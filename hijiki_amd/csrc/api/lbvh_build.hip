@@ -16,12 +16,12 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
   if (!ctx) return HJ_ERR_INVALID;
   HJ_NOT_BUSY(ctx);
   HJ_NOT_PIPELINED(ctx);
-  if (!s || !out_nodes) return set_error(ctx, HJ_ERR_INVALID, "null argument");
+  if (!s) return set_error(ctx, HJ_ERR_INVALID, "null argument");
   const size_t n = s->num_spheres + s->num_quads + s->num_triangles;
   if (n < 2) return set_error(ctx, HJ_ERR_INVALID, "scene needs at least 2 shapes (reference panics: root would be a leaf, src/main.rs:230)");
   if (n >= hj::kInnerFlag / 4) return set_error(ctx, HJ_ERR_INVALID, "scene too large");
   const size_t total = 2 * n - 1;
-  if (capacity < total) return set_error(ctx, HJ_ERR_INVALID, "node buffer holds %zu records, the tree has %zu", capacity, total);
+  if (out_nodes && capacity < total) return set_error(ctx, HJ_ERR_INVALID, "node buffer holds %zu records, the tree has %zu", capacity, total);
   if ((s->num_spheres && !s->spheres) || (s->num_quads && !s->quads) || (s->num_triangles && (!s->triangles || !s->vertices)))
     return set_error(ctx, HJ_ERR_INVALID, "null shape array");
   for (size_t i = 0; i < s->num_triangles; i++)
@@ -29,7 +29,8 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
       if (s->triangles[i].v[k] >= s->num_vertices) return set_error(ctx, HJ_ERR_INVALID, "triangle %zu refers to unknown vertex", i);
   HJ_HIP(ctx, hipSetDevice(ctx->device));
   // HJ_LBVH_TIMING=1: wall time of the build's stages on stderr (the stream is drained at every mark)
-  const bool timing = env_int("HJ_LBVH_TIMING", 0, 0, 1) != 0;
+  const Tuning tn = ctx->tuning = Tuning::from_env();
+  const bool timing = tn.lbvh_timing != 0;
   auto t_last = std::chrono::steady_clock::now();
   auto mark = [&](const char* what) {
     if (!timing) return;
@@ -51,6 +52,8 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
   int rc = HJ_OK;
 #define HJ_DEVBUF(ptr, type, count) do { void* p_ = nullptr; rc = dev(sizeof(type) * (count), &p_); if (rc != HJ_OK) return rc; ptr = static_cast<type*>(p_); } while (0)
   hipStream_t st = ctx->stream;
+  ctx->resident.release();                                  // (a tree of an earlier build that nobody took over)
+  void *keep_sp = nullptr, *keep_qd = nullptr, *keep_tr = nullptr, *keep_vx = nullptr;
   hj::lbvh::Shapes sh{};
   {
     float4* sp = nullptr; float4* qd = nullptr; hj_triangle* tr = nullptr; hj_vertex* vx = nullptr;
@@ -63,6 +66,7 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
     if (s->num_triangles) HJ_HIP(ctx, hipMemcpyAsync(tr, s->triangles, sizeof(hj_triangle) * s->num_triangles, hipMemcpyHostToDevice, st));
     if (s->num_vertices) HJ_HIP(ctx, hipMemcpyAsync(vx, s->vertices, sizeof(hj_vertex) * s->num_vertices, hipMemcpyHostToDevice, st));
     sh.spheres = sp; sh.quads = qd; sh.triangles = tr; sh.vertices = vx;
+    keep_sp = sp; keep_qd = qd; keep_tr = tr; keep_vx = vx;
     sh.ns = (uint32_t)s->num_spheres; sh.nq = (uint32_t)s->num_quads; sh.nt = (uint32_t)s->num_triangles;
   }
   hj::lbvh::Tree t{};
@@ -98,7 +102,7 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
   HJ_DEVBUF(sort_tmp, char, sort_bytes);
   // Large shapes (hj_lbvh.h) stay out of the Morton tree; HJ_LBVH_BIG_PCT = threshold in per cent of the scene's box area
   // (0 = everything goes into the Morton tree).  They sort behind everything else (bit 63 of the key).
-  float big_frac = (float)env_int("HJ_LBVH_BIG_PCT", 2, 0, 100) / 100.0f;
+  float big_frac = (float)tn.lbvh_big_pct / 100.0f;
   uint32_t nbig = 0;
   for (int attempt = 0; attempt < 2; attempt++) {
     HJ_HIP(ctx, hipMemsetAsync(d_nbig, 0, sizeof(uint32_t), st));
@@ -122,11 +126,11 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
   // ---- clusters of the Morton tree (HJ_LBVH_CLUSTER leaves at most; 0 = the whole tree is one cluster)
   // (clusters of up to 64 leaves are re-split by one thread each, k_emit_clusters_sah - rounds 2-3's default -, larger ones
   // up to 512 by one wave each, k_emit_clusters_sah_wave)
-  const uint32_t cmax_env = (uint32_t)env_int("HJ_LBVH_CLUSTER", 512, 0, 1 << 20);
+  const uint32_t cmax_env = (uint32_t)tn.lbvh_cluster;
   const uint32_t cmax = cmax_env == 0 ? m : cmax_env;
   // inside the clusters: SAH re-split (one thread per cluster, which needs no boxes of the Morton tree's internal nodes) or the
   // Morton topology as it is (HJ_LBVH_SAH=0, or clusters larger than the kernel's arrays: bottom-up refit first)
-  const bool sah_clusters = cmax <= hj::lbvh::kWaveClusterMax && env_int("HJ_LBVH_SAH", 1, 0, 1) != 0;
+  const bool sah_clusters = cmax <= hj::lbvh::kWaveClusterMax && tn.lbvh_sah != 0;
   const bool sah_wave = sah_clusters && cmax > hj::lbvh::kClusterMax;
   if (!sah_clusters) hipLaunchKernelGGL(hj::lbvh::k_refit, grid_m, blk, 0, st, t, m, idx_mask);
   hj::lbvh::Clusters cl{};
@@ -161,7 +165,7 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
     HJ_HIP(ctx, hipEventRecord(ev.a, st));
     HJ_HIP(ctx, hipStreamWaitEvent(side, ev.a, 0));
     hipLaunchKernelGGL(hj::lbvh::k_emit_clusters_sah_wave, dim3(K), dim3(64), 0, side, t, K, cl, idx_mask, d_staged,
-                       env_int("HJ_BVH_CHILD_ORDER", 3, 0, 9));
+                       tn.bvh_child_order);
     HJ_HIP(ctx, hipEventRecord(ev.b, side));
   }
   // ---- the top of the tree on the host: binned SAH over the K clusters and the nbig large shapes
@@ -413,12 +417,12 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
           st.push_back(b2); st.push_back(a);
         }
       }
-    } builder{items, {}, 0, env_int("HJ_BVH_CHILD_ORDER", 3, 0, 9), 0, {}, {}};
+    } builder{items, {}, 0, tn.bvh_child_order, 0, {}, {}};
     // Rotation passes over the top (HJ_LBVH_TOP_ROTATE; -1 = the default rule): they pay where the top IS most of the tree - the
     // 6 k-triangle box: 112 items, frame rate 0.94 -> 0.99 of the host tree's - and cost 1.5 % (and 1.7 ms) on the 1 M-triangle
     // mesh, whose 25 k cluster boxes a binned SAH already arranges well: small tops only.
     {
-      const int r = env_int("HJ_LBVH_TOP_ROTATE", -1, -1, 64);
+      const int r = tn.lbvh_top_rotate;
       builder.rotate_passes = r >= 0 ? r : (items.size() < 4096 ? 8 : 0);
     }
     builder.ids.resize(items.size());
@@ -469,14 +473,15 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
   }
   else if (sah_clusters)
     hipLaunchKernelGGL(hj::lbvh::k_emit_clusters_sah, dim3((K + hj::lbvh::kSahThreads - 1) / hj::lbvh::kSahThreads),
-                       dim3(hj::lbvh::kSahThreads), 0, st, t, K, cl, idx_mask, d_out, env_int("HJ_BVH_CHILD_ORDER", 3, 0, 9));
+                       dim3(hj::lbvh::kSahThreads), 0, st, t, K, cl, idx_mask, d_out, tn.bvh_child_order);
   else
     hipLaunchKernelGGL(hj::lbvh::k_emit_clusters, grid_sub, blk, 0, st, t, m, cl, idx_mask, d_out);
   HJ_HIP(ctx, hipGetLastError());
   mark("cluster subtrees");
   // ---- child order voted by a sample of the scene's own rays (kernels/hj_vote.h; HJ_LBVH_VOTE_PATHS camera paths, 0 = the order
   // by shape count the stages above produced): the host-built records join the others on the device first
-  const size_t vote_paths = (size_t)env_int("HJ_LBVH_VOTE_PATHS", 60000, 0, 1 << 24);
+  const size_t vote_paths = (size_t)tn.lbvh_vote_paths;
+  hj_bvh_node* final_tree = nullptr;
   if (vote_paths != 0 && total >= 3) {
     hj_bvh_node* d_voted = nullptr;
     HJ_DEVBUF(d_voted, hj_bvh_node, total);
@@ -489,17 +494,45 @@ int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* ou
     if (rc == HJ_ERR_UNSUPPORTED) put_error(ctx, error_before);      // the build succeeds without the vote: no stale message behind HJ_OK
     mark("ray-voted child order");
     // (a tree deeper than the exchange's level loop goes - thousands of shapes in a chain - keeps the order it has)
-    HJ_HIP(ctx, hipMemcpyAsync(out_nodes, rc == HJ_OK ? d_voted : d_out, sizeof(hj_bvh_node) * total, hipMemcpyDeviceToHost, st));
-    HJ_HIP(ctx, hipStreamSynchronize(st));
+    final_tree = rc == HJ_OK ? d_voted : d_out;
     rc = HJ_OK;
   } else {
-    HJ_HIP(ctx, hipMemcpyAsync(out_nodes, d_out, sizeof(hj_bvh_node) * total, hipMemcpyDeviceToHost, st));
-    HJ_HIP(ctx, hipStreamSynchronize(st));
-    for (const auto& pr : top_records) out_nodes[pr.first] = pr.second;
+    rc = put_records(ctx, top_records, d_out);               // the host-built top joins the cluster subtrees on the device
+    if (rc != HJ_OK) return rc;
+    final_tree = d_out;
   }
+  if (out_nodes) HJ_HIP(ctx, hipMemcpyAsync(out_nodes, final_tree, sizeof(hj_bvh_node) * total, hipMemcpyDeviceToHost, st));
+  HJ_HIP(ctx, hipStreamSynchronize(st));
   mark("records to the host");
+  // The tree and the shape arrays it was built over STAY on the device (hj_context::resident): hj_scene_upload with scene->bvh ==
+  // NULL derives the kernels' records from them without a trip through the host; hj_bvh_device_read copies the tree out.
+  {
+    auto take = [&](void* p, DevBuf& into) {
+      for (auto& b : bufs) if (b.p == p && p != nullptr) { into = b; b.p = nullptr; b.bytes = 0; return; }
+    };
+    hj_context::ResidentTree& rt = ctx->resident;
+    take(final_tree, rt.nodes); take(keep_sp, rt.spheres); take(keep_qd, rt.quads); take(keep_tr, rt.triangles); take(keep_vx, rt.vertices);
+    rt.total = total; rt.ns = s->num_spheres; rt.nq = s->num_quads; rt.nt = s->num_triangles; rt.nv = s->num_vertices;
+    rt.shapes_hash = shape_arrays_hash(s);
+    rt.valid = rt.nodes.p != nullptr;
+  }
 #undef HJ_DEVBUF
   if (out_num_nodes) *out_num_nodes = total;
+  return HJ_OK;
+}
+
+// The tree hj_build_bvh_device left on the device, copied to the host (for a host that wants to keep or inspect it, and for the
+// tests' oracle, which walks the same array).
+int hj_bvh_device_read(hj_context* ctx, hj_bvh_node* out_nodes, size_t capacity, size_t* out_num_nodes) {
+  if (!ctx) return HJ_ERR_INVALID;
+  HJ_NOT_BUSY(ctx);
+  HJ_NOT_PIPELINED(ctx);
+  if (!ctx->resident.valid) return set_error(ctx, HJ_ERR_STATE, "hj_bvh_device_read: no tree on the device (hj_build_bvh_device builds one; hj_scene_upload with scene->bvh == NULL consumes it)");
+  if (out_num_nodes) *out_num_nodes = ctx->resident.total;
+  if (!out_nodes) return HJ_OK;
+  if (capacity < ctx->resident.total) return set_error(ctx, HJ_ERR_INVALID, "node buffer holds %zu records, the tree has %zu", capacity, ctx->resident.total);
+  HJ_HIP(ctx, hipSetDevice(ctx->device));
+  HJ_HIP(ctx, hipMemcpy(out_nodes, ctx->resident.nodes.p, sizeof(hj_bvh_node) * ctx->resident.total, hipMemcpyDeviceToHost));
   return HJ_OK;
 }
 

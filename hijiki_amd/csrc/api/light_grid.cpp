@@ -27,6 +27,7 @@
 // (the array's own boxes are not trusted: tests upload trees with wrong boxes): every leaf whose bounds touch the shaft is
 // looked at, in any well- or ill-formed array whose exits point forward.  Shapes the array does not hold cannot be hit.
 #include "light_grid.hpp"
+#include "hj_tuning.h"
 
 #include <algorithm>
 #include <atomic>
@@ -212,7 +213,7 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
   if (!s || res < 2 || res > 256 || s->num_emitters == 0 || s->num_bvh_nodes == 0) return false;
   const Geometry g{s, s->num_spheres, s->num_quads, s->num_triangles};
   const size_t shapes = g.ns + g.nq + g.nt, N = s->num_bvh_nodes;
-  const bool timing = std::getenv("HJ_LIGHT_GRID_TIMING") != nullptr;       // wall time of the stages on stderr
+  const bool timing = Tuning::from_env().light_grid_timing;       // wall time of the stages on stderr (no context here: hj_debug_light_grid has none)
   auto t_last = std::chrono::steady_clock::now();
   auto mark = [&](const char* what) {
     if (!timing) return;

@@ -223,8 +223,7 @@ int stage_blocks(hj_context* ctx, hj_context::BatchSlot& sl, const hj_image_bloc
   st = sl.st;
   st.blocks = static_cast<const hj_image_block*>(sl.d_blocks.p);
   st.num_blocks = nb;
-  static const int xcd_env = env_int("HJ_XCD_DEAL", 0, 0, 1);
-  st.xcd_deal = (xcd_env && !all_in_flight && st.num_wg == 2048u && hj::kSlotsPerBlock / 64u == 256u) ? 1u : 0u;
+  st.xcd_deal = (ctx->tuning.xcd_deal != 0 && !all_in_flight && st.num_wg == 2048u && hj::kSlotsPerBlock / 64u == 256u) ? 1u : 0u;
   std::memcpy(sl.h_blocks, blocks, sizeof(hj_image_block) * nb);
   HJ_HIP(ctx, hipMemcpyAsync(sl.d_blocks.p, sl.h_blocks, sizeof(hj_image_block) * nb, hipMemcpyHostToDevice, sl.stream));
   return HJ_OK;
@@ -251,7 +250,7 @@ int enqueue_batch_fused(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::
   const int ev = tm.begin(EV_PATH, sl.stream);
   // HJ_LDS_PAD_KB (diagnostic): unused dynamic LDS that lowers the number of resident workgroups per CU without
   // touching the code, to measure how the frame rate scales with occupancy.
-  static const size_t lds_pad = (size_t)env_int("HJ_LDS_PAD_KB", 0, 0, 64) * 1024;
+  const size_t lds_pad = (size_t)ctx->tuning.lds_pad_kb * 1024;
   const bool pairs = ctx->scene.has_pairs != 0, nt = ctx->scene.stream_state != 0;
   const hj::DeviceScene scn = scene_for(ctx, o);
   if (!o.use_bvh) hipLaunchKernelGGL((hj::k_path_wavefront<false, false, false>), grid, blk, lds_pad, sl.stream, st, scn, o.max_bounces, o.rr_start);
@@ -287,7 +286,7 @@ int render_batch_split(hj_context* ctx, hj_context::BatchSlot& sl, hj_context::B
     for (uint32_t i = 0; i < G; i++) sum += c[i];
     return sum;
   };
-  static const bool trace_bounces = std::getenv("HJ_TRACE_BOUNCES") != nullptr;   // debugging aid: per-bounce table
+  const bool trace_bounces = ctx->tuning.trace_bounces;   // debugging aid: per-bounce table
   for (uint32_t bounce = 0; bounce < o.max_bounces; bounce++) {
     const uint32_t parity = bounce & 1u;
     const size_t ev0 = ctx->events_used;
@@ -362,6 +361,7 @@ struct RenderRun {
 int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_render_stats* stats, size_t total_blocks) {
   if (!ctx->have_scene) return set_error(ctx, HJ_ERR_STATE, "render before hj_scene_upload");
   if (!ctx->accum) return set_error(ctx, HJ_ERR_STATE, "render before hj_framebuffer_create");
+  ctx->tuning = Tuning::from_env();            // (every render call and hj_reserve start here)
   if (opts) run.o = *opts;
   else hj_default_render_opts(&run.o);
   int rc = check_opts(ctx, run.o);
@@ -391,7 +391,7 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
   // per batch beats an eighth by 3.4 / 1.6 / 0.8 / 0.8 %, a half loses 3-5 %).  Path state does not grow with the batch
   // (pool), only the sample buffers do (0.5 GB per 1024 blocks).
   const size_t n = total_blocks;
-  static const size_t batch_cap = (size_t)env_int("HJ_BATCH_CAP", 8192, 64, 32768);
+  const size_t batch_cap = (size_t)ctx->tuning.batch_cap;
   run.batch = run.o.batch_blocks ? run.o.batch_blocks
                                  : (uint32_t)std::min<size_t>(batch_cap, std::max<size_t>(256, ((n + 3) / 4 + 63) / 64 * 64));
   // Frames back to back (HJ_RENDER_NO_DRAIN): the slots overlap ACROSS frames, so a frame need not be cut into four batches for
@@ -404,7 +404,7 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
   // path state (185 B each, 217 B with tinted dielectrics).  DEFAULTS that do not fit the device's free memory (other
   // contexts on the GPU, the host application) shrink until they do: first the pool (down to 8192 positions), then the
   // batch; an explicit hj_render_opts::batch_blocks is taken as given and fails with HJ_ERR_NOMEM if it does not fit.
-  static const size_t small_blocks = (size_t)env_int("HJ_WG_SMALL_BLOCKS", 12288, 0, 1 << 30);
+  const size_t small_blocks = (size_t)ctx->tuning.wg_small_blocks;
   ctx->num_wg_eff = (!run.split && n < small_blocks) ? ctx->num_wg_small : ctx->num_wg;
   ctx->pool_eff = ctx->pool;
   ctx->slots_eff = ctx->num_slots;
@@ -412,7 +412,7 @@ int run_begin(hj_context* ctx, RenderRun& run, const hj_render_opts* opts, hj_re
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
       // HJ_MEM_LIMIT_MB (test rig): pretend that no more than this is free
-      const int limit_mb = env_int("HJ_MEM_LIMIT_MB", 0, 0, 1 << 30);
+      const int limit_mb = ctx->tuning.mem_limit_mb;
       if (limit_mb > 0) free_b = std::min<size_t>(free_b, (size_t)limit_mb << 20);
       size_t held = 0;
       for (auto& sl : ctx->slots) {

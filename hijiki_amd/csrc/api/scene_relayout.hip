@@ -271,7 +271,8 @@ __global__ void k_rl_records(RL r, float4* __restrict__ dev) {
 namespace hjapi {
 
 int relayout_on_device(hj_context* ctx, const hj_scene_desc* s, const hj_triangle* d_tris, const hj_vertex* d_verts, bool pairs_on,
-                       int node_order, float collapse_thr, bool timing, RelayoutOut& out) {
+                       int node_order, float collapse_thr, bool timing, RelayoutOut& out, const hj_bvh_node* d_tree) {
+  // d_tree: the skip-link array is on the device already (hj_build_bvh_device's tree: hj_context::resident); s->bvh is not read then
   out = RelayoutOut{};
   const size_t N = s->num_bvh_nodes;
   if (N < 3 || N >= 0x3FFFFFFFu) return HJ_ERR_UNSUPPORTED;
@@ -312,9 +313,11 @@ int relayout_on_device(hj_context* ctx, const hj_scene_desc* s, const hj_triangl
   mark("triangle records");
 
   // the skip-link array as it is
-  hj_bvh_node* d_bvh = nullptr;
-  HJ_TMP(d_bvh, hj_bvh_node, N);
-  HJ_HIP(ctx, hipMemcpyAsync(d_bvh, s->bvh, sizeof(hj_bvh_node) * N, hipMemcpyHostToDevice, st));
+  hj_bvh_node* d_bvh = const_cast<hj_bvh_node*>(d_tree);      // (the kernels only read it)
+  if (!d_bvh) {
+    HJ_TMP(d_bvh, hj_bvh_node, N);
+    HJ_HIP(ctx, hipMemcpyAsync(d_bvh, s->bvh, sizeof(hj_bvh_node) * N, hipMemcpyHostToDevice, st));
+  }
   RL r{};
   r.bvh = d_bvh; r.N = n32; r.first_tri = (uint32_t)(s->num_spheres + s->num_quads);
   r.nshapes = (uint32_t)(s->num_spheres + s->num_quads + s->num_triangles);
@@ -348,7 +351,7 @@ int relayout_on_device(hj_context* ctx, const hj_scene_desc* s, const hj_triangl
     return HJ_OK;
   };
 
-  const bool dbg = std::getenv("HJ_RL_DEBUG") != nullptr;
+  const bool dbg = ctx->tuning.relayout_debug;
   auto check = [&](const char* what) {
     if (!dbg) return;
     const hipError_t e1 = hipStreamSynchronize(st), e2 = hipGetLastError();

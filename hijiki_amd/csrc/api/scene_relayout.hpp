@@ -20,6 +20,6 @@ struct RelayoutOut {
 // HJ_ERR_UNSUPPORTED: the array is not a tree (or a node has more kept children than the kernels enumerate) - the caller takes the
 // host path; buffers this call added to ctx->scene_bufs are the caller's to drop then.
 int relayout_on_device(hj_context* ctx, const hj_scene_desc* s, const hj_triangle* d_tris, const hj_vertex* d_verts, bool pairs_on,
-                       int node_order, float collapse_thr, bool timing, RelayoutOut& out);
+                       int node_order, float collapse_thr, bool timing, RelayoutOut& out, const hj_bvh_node* d_tree = nullptr);
 
 }  // namespace hjapi

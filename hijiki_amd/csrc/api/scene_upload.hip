@@ -90,16 +90,17 @@ namespace {
 
 // What depends on the tree's size once its records exist (host and device re-layout alike): N = nodes of the uploaded array,
 // M = device records without padding.
-void finish_tree_settings(hj::DeviceScene& d, size_t N, size_t M, bool has_pairs) {
+void finish_tree_settings(hj::DeviceScene& d, const hjapi::Tuning& tn, size_t N, size_t M, bool has_pairs) {
+  using hjapi::Tuning;
   // Large trees (their nodes and triangles do not fit the caches): the path-state streams bypass the caches so that they
   // do not evict scene data (1 M triangles +4.4 %; cache-resident scenes lose 0.5 ... 3 % with it).  HJ_STREAM_STATE = 0 / 1 forces.
   {
-    const int nt_env = env_int("HJ_STREAM_STATE", -1, -1, 1);
-    d.stream_state = (nt_env == 1 || (nt_env < 0 && N >= (size_t)env_int("HJ_STREAM_MIN_NODES", 300000, 0, 1 << 30))) ? 1u : 0u;
+    const int nt_env = tn.stream_state;
+    d.stream_state = (nt_env == 1 || (nt_env < 0 && N >= (size_t)tn.stream_min_nodes)) ? 1u : 0u;
   }
   {   // camera packets of 8 x 8 pixels instead of 64 x 1 on the same large trees.  HJ_GROUP_TILE = 0 / 1 forces.
-    const int gt_env = env_int("HJ_GROUP_TILE", -1, -1, 1);
-    d.group_tile = (gt_env == 1 || (gt_env < 0 && N >= (size_t)env_int("HJ_STREAM_MIN_NODES", 300000, 0, 1 << 30))) ? 1u : 0u;
+    const int gt_env = tn.group_tile;
+    d.group_tile = (gt_env == 1 || (gt_env < 0 && N >= (size_t)tn.stream_min_nodes)) ? 1u : 0u;
   }
   // steps per round of the walk loop (the first one is the merged step that also runs the leaf tests) and free lanes at
   // which a wave fetches new rays: without pair nodes 4 / 32 (6: -0.4 %, 8: -4 % on cbox); with them 7 / 24 on small trees
@@ -108,8 +109,8 @@ void finish_tree_settings(hj::DeviceScene& d, size_t N, size_t M, bool has_pairs
   // 6 .. 10 steps the same, 24 lanes -1 %).  Round 5: with the light-shaft grid most of the short shadow rays are gone and the
   // small trees want 6 steps (c2 +2.3 %, c3 +0.8 % against 7; 5: the same; 8: -1 %; refill at 16 / 32 lanes: -0 ... -2 %)
   const bool small_tree = M < 50000;
-  d.inner_burst = (uint32_t)env_int("HJ_INNER_BURST", !has_pairs ? 4 : (small_tree ? 6 : 8), 1, 1 << 20);   // >= 1, or the walk would never advance
-  d.refill_min = (uint32_t)env_int("HJ_REFILL_MIN", has_pairs && M < 600000 ? 24 : (int)hj::kRefillMin, 1, 64);   // (20 k / 60 k / 200 k triangles: 24 lanes +2 / +3 / +1 %)
+  d.inner_burst = (uint32_t)Tuning::pick(tn.inner_burst, !has_pairs ? 4 : (small_tree ? 6 : 8));   // >= 1, or the walk would never advance
+  d.refill_min = (uint32_t)Tuning::pick(tn.refill_min, has_pairs && M < 600000 ? 24 : (int)hj::kRefillMin);   // (20 k / 60 k / 200 k triangles: 24 lanes +2 / +3 / +1 %)
 }
 
 }  // namespace
@@ -122,7 +123,8 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
   HJ_NOT_PIPELINED(ctx);
   if (!s) return set_error(ctx, HJ_ERR_INVALID, "null scene");
   // HJ_UPLOAD_TIMING=1: wall time of the stages below on stderr
-  const bool timing = env_int("HJ_UPLOAD_TIMING", 0, 0, 1) != 0;
+  const Tuning tn = ctx->tuning = Tuning::from_env();
+  const bool timing = tn.upload_timing != 0;
   auto t_last = std::chrono::steady_clock::now();
   auto mark = [&](const char* what) {
     if (!timing) return;
@@ -130,8 +132,21 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     std::fprintf(stderr, "hj_scene_upload: %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
     t_last = now;
   };
+  // scene->bvh == NULL: the tree hj_build_bvh_device left on this context's device, built over these very shape arrays
+  // (hj_context::resident) - no trip through the host for the tree, and the triangle / vertex arrays are on the device already
+  const bool resident = s->bvh == nullptr && s->num_bvh_nodes == 0;
+  hj_scene_desc with_tree;
+  if (resident) {
+    const hj_context::ResidentTree& rt = ctx->resident;
+    if (!rt.valid) return set_error(ctx, HJ_ERR_STATE, "scene->bvh is NULL and no tree is on the device: hj_build_bvh_device builds one");
+    if (rt.ns != s->num_spheres || rt.nq != s->num_quads || rt.nt != s->num_triangles || rt.nv != s->num_vertices ||
+        ((s->num_spheres == 0 || s->spheres) && (s->num_quads == 0 || s->quads) && (s->num_triangles == 0 || s->triangles) &&
+         (s->num_vertices == 0 || s->vertices) && rt.shapes_hash != shape_arrays_hash(s)))
+      return set_error(ctx, HJ_ERR_INVALID, "scene->bvh is NULL, but the tree on the device was built over other shape arrays (%zu / %zu / %zu shapes, %zu vertices)", rt.ns, rt.nq, rt.nt, rt.nv);
+  }
   int rc = validate_scene(ctx, s);
   if (rc != HJ_OK) return rc;
+  if (resident) { with_tree = *s; with_tree.num_bvh_nodes = ctx->resident.total; s = &with_tree; }   // (bvh stays NULL: nothing below reads it on this route)
   mark("validation");
   HJ_HIP(ctx, hipSetDevice(ctx->device));
   rc = sync_all(ctx);
@@ -157,23 +172,35 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
   // default: from HJ_UPLOAD_DEVICE_MIN (100 000) nodes on.  An array that is not a tree takes the host path.
   bool on_device = false;
   {
-    const int env = env_int("HJ_UPLOAD_DEVICE", -1, -1, 1);
-    const bool want = env == 1 || (env < 0 && s->num_bvh_nodes >= (size_t)env_int("HJ_UPLOAD_DEVICE_MIN", 100000, 0, 1 << 30));
+    const int env = tn.upload_device;
+    const bool want = resident || env == 1 || (env < 0 && s->num_bvh_nodes >= (size_t)tn.upload_device_min);
     if (want && s->num_bvh_nodes >= 3) {
       const size_t mark_bufs = ctx->scene_bufs.size();
-      HJ_UP(upload(ctx, s->triangles, s->num_triangles, &d.triangles));
-      HJ_UP(upload(ctx, s->vertices, s->num_vertices, &d.vertices));
+      if (resident) {                                         // the build's own copies become the scene's
+        ctx->scene_bufs.push_back(ctx->resident.triangles); d.triangles = static_cast<const hj_triangle*>(ctx->resident.triangles.p);
+        ctx->scene_bufs.push_back(ctx->resident.vertices); d.vertices = static_cast<const hj_vertex*>(ctx->resident.vertices.p);
+        ctx->resident.triangles = DevBuf{}; ctx->resident.vertices = DevBuf{};
+      } else {
+        HJ_UP(upload(ctx, s->triangles, s->num_triangles, &d.triangles));
+        HJ_UP(upload(ctx, s->vertices, s->num_vertices, &d.vertices));
+      }
       mark("triangle + vertex upload");
-      const int pair_env = env_int("HJ_PAIR_LEAVES", -1, -1, 1);
-      const bool pairs_on = pair_env == 1 || (pair_env < 0 && s->num_bvh_nodes >= (size_t)env_int("HJ_PAIR_MIN_NODES", 0, 0, 1 << 30));
+      const int pair_env = tn.pair_leaves;
+      const bool pairs_on = pair_env == 1 || (pair_env < 0 && s->num_bvh_nodes >= (size_t)tn.pair_min_nodes);
       RelayoutOut ro;
-      rc = relayout_on_device(ctx, s, d.triangles, d.vertices, pairs_on, env_int("HJ_NODE_ORDER", -1, -1, 1),
-                              (float)env_int("HJ_COLLAPSE_PCT", 50, 0, 1000) / 100.0f, timing, ro);
+      rc = relayout_on_device(ctx, s, d.triangles, d.vertices, pairs_on, tn.node_order,
+                              (float)tn.collapse_pct / 100.0f, timing, ro,
+                              resident ? static_cast<const hj_bvh_node*>(ctx->resident.nodes.p) : nullptr);
+      if (resident && rc != HJ_OK) {                          // (no host array to fall back to)
+        release_scene(ctx);
+        ctx->resident.release();
+        return rc == HJ_ERR_UNSUPPORTED ? set_error(ctx, rc, "the tree on the device cannot be re-laid out there (fewer than 3 or too many records)") : rc;
+      }
       if (rc == HJ_OK) {
         on_device = true;
         d.nodes = ro.nodes; d.tri_isect = ro.tri_isect; d.tri_shade = ro.tri_shade; d.tri_pair = ro.tri_pair;
         d.num_nodes = ro.num_nodes; d.root = ro.root; d.root2 = ro.root2; d.num_hot = ro.num_hot; d.has_pairs = ro.num_pairs ? 1u : 0u;
-        finish_tree_settings(d, s->num_bvh_nodes, ro.kept, ro.num_pairs != 0);
+        finish_tree_settings(d, tn, s->num_bvh_nodes, ro.kept, ro.num_pairs != 0);
       } else if (rc == HJ_ERR_UNSUPPORTED) {
         while (ctx->scene_bufs.size() > mark_bufs) { ctx->scene_bufs.back().release(); ctx->scene_bufs.pop_back(); }
         d.triangles = nullptr; d.vertices = nullptr;
@@ -247,7 +274,7 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     size_t N = s->num_bvh_nodes;
     // HJ_LEAF_GUARDS: 0 none; 2 (default) every triangle or quad leaf that does not become half of a pair node: +1 % on c2 and c3
     // (profiles/r05_ab_sphere_guards.txt); 1 sphere leaves only, 3 all leaves: NOT exact, see above.
-    const int guard_mode = env_int("HJ_LEAF_GUARDS", 2, 0, 3);
+    const int guard_mode = tn.leaf_guards;
     const bool guard_spheres = guard_mode == 1 || guard_mode == 3, guard_flat = guard_mode >= 2;
     if ((guard_spheres && s->num_spheres != 0) || (guard_flat && s->num_quads + s->num_triangles != 0)) {
       const size_t n0 = N, first_tri = s->num_spheres + s->num_quads;
@@ -338,7 +365,7 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     // probability p ~ area(P) / area(nearest kept ancestor), testing P costs 1 + 2p box tests against 2 without.
     std::vector<char> del(N, 0);
     {
-      const float thr = (float)env_int("HJ_COLLAPSE_PCT", 50, 0, 1000) / 100.0f;
+      const float thr = (float)tn.collapse_pct / 100.0f;
       auto inner = [&](size_t i) { return bvh[i].shape_index == HJ_BVH_INNER; };
       auto inside = [&](size_t c, size_t p) {   // false for NaN bounds
         bool ok = true;
@@ -369,8 +396,8 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     // 6 k-triangle box against +12 % at 1 M triangles); with the shape fetch riding along with the other lanes' node fetch
     // they pay everywhere: 6 k triangles +3 %, with the spheres +5 %, 60 k +7 %, 200 k +8 %.  HJ_PAIR_LEAVES = 0 / 1 forces;
     // default: trees of >= HJ_PAIR_MIN_NODES records (0: all).
-    const int pair_env = env_int("HJ_PAIR_LEAVES", -1, -1, 1);
-    if (pair_env == 1 || (pair_env < 0 && N >= (size_t)env_int("HJ_PAIR_MIN_NODES", 0, 0, 1 << 30))) {
+    const int pair_env = tn.pair_leaves;
+    if (pair_env == 1 || (pair_env < 0 && N >= (size_t)tn.pair_min_nodes)) {
       const size_t first_tri = s->num_spheres + s->num_quads;
       for (size_t i = 0; i + 2 < N; i++) {
         if (bvh[i].shape_index != HJ_BVH_INNER) continue;
@@ -406,7 +433,7 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     // scene before: within 1 % at 4, 8 and 16 records per treelet)
     mark("hot-first sort");
     uint32_t next = hot;
-    const int node_order = env_int("HJ_NODE_ORDER", -1, -1, 1);                      // -1: by tree size (with the pair nodes)
+    const int node_order = tn.node_order;                      // -1: by tree size (with the pair nodes)
     if (node_order == 0 || (node_order < 0 && pairs.empty())) {
       for (size_t i = 0; i < N; i++) if (!del[i] && !is_hot[i]) map[i] = next++;   // small trees (cache-resident): pre-order
     } else {
@@ -482,7 +509,7 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
     d.root = N ? map[0] : 0u;
     d.root2 = (uint32_t)M_all;
     d.num_hot = hot;
-    finish_tree_settings(d, s->num_bvh_nodes, M, !pairs.empty());
+    finish_tree_settings(d, tn, s->num_bvh_nodes, M, !pairs.empty());
     // The walk adds 32 * index to the low word of the array's address without a carry (kernels/hj_walk.h): the
     // array must not cross a 4 GiB boundary.  Allocate twice the size and start at the boundary if it would.
     {
@@ -558,11 +585,20 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
   // a third of the shadow rays is proven free and the frame rate does not move (they are the cheap rays: a dozen steps on
   // LDS-resident nodes against the mesh rays' seventeen cold ones), while the build costs 50 ms of start-up there.
   {
-    const int big = (int)(s->num_bvh_nodes >= (size_t)env_int("HJ_STREAM_MIN_NODES", 300000, 0, 1 << 30));
-    const int res = env_int("HJ_LIGHT_GRID", big ? 0 : 64, 0, 256);
+    const int big = (int)(s->num_bvh_nodes >= (size_t)tn.stream_min_nodes);
+    const int res = Tuning::pick(tn.light_grid, big ? 0 : 64);
     LightGrid lg;
     bool have_grid = false;
-    try { have_grid = res >= 2 && build_light_grid(s, (uint32_t)res, lg); } catch (const std::exception&) { have_grid = false; }   // (out of host memory: no grid)
+    std::vector<hj_bvh_node> host_tree;                       // (the grid is host code: a tree that lives on the device comes back for it)
+    hj_scene_desc for_grid = *s;
+    try {
+      if (res >= 2 && resident) {
+        host_tree.resize(ctx->resident.total);
+        if (hipMemcpy(host_tree.data(), ctx->resident.nodes.p, sizeof(hj_bvh_node) * host_tree.size(), hipMemcpyDeviceToHost) != hipSuccess) host_tree.clear();
+        for_grid.bvh = host_tree.data();
+      }
+      have_grid = res >= 2 && (!resident || !host_tree.empty()) && build_light_grid(&for_grid, (uint32_t)res, lg);
+    } catch (const std::exception&) { have_grid = false; }   // (out of host memory: no grid)
     if (have_grid) {
       HJ_UP(upload(ctx, lg.bits.data(), lg.bits.size(), &d.light_grid));
       d.lg_res = lg.res;
@@ -573,6 +609,7 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
   }
   mark("light-shaft grid");
 #undef HJ_UP
+  if (resident) ctx->resident.release();                     // consumed (hipFree waits for the kernels that read the tree)
   ctx->scene = d;
   ctx->have_scene = true;
   return HJ_OK;

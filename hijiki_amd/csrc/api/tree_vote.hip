@@ -53,7 +53,7 @@ int vote_on_device(hj_context* ctx, const hj_scene_desc* s, const VoteShapes& sh
   vs.cam = s->camera;
   vs.nodes = reinterpret_cast<const float4*>(d_nodes);
   vs.N = (uint32_t)N;
-  vs.w_shadow = (uint32_t)env_int("HJ_BVH_VOTE_SHADOW", N >= (size_t)env_int("HJ_STREAM_MIN_NODES", 300000, 0, 1 << 30) ? 4 : 1, 0, 16);
+  vs.w_shadow = (uint32_t)Tuning::pick(ctx->tuning.bvh_vote_shadow, N >= (size_t)ctx->tuning.stream_min_nodes ? 4 : 1);
   if (s->materials && s->num_materials == nshapes && nshapes) {
     uint32_t* m = nullptr;
     HJ_SCRATCH(sc, m, uint32_t, nshapes);
@@ -145,7 +145,8 @@ int hj_tune_bvh_device(hj_context* ctx, const hj_scene_desc* s, hj_bvh_node* out
   if (rc != HJ_OK) return rc;
   if (N == 0) return HJ_OK;
   HJ_HIP(ctx, hipSetDevice(ctx->device));
-  const bool timing = env_int("HJ_LBVH_TIMING", 0, 0, 1) != 0;
+  const Tuning tn = ctx->tuning = Tuning::from_env();
+  const bool timing = tn.lbvh_timing != 0;
   hipStream_t st = ctx->stream;
   Scratch sc(ctx);
   float4 *sp = nullptr, *qd = nullptr;

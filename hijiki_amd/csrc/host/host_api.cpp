@@ -167,6 +167,20 @@ int hjh_scene_compile(const hjh_scene* s, hjh_compiled** out) {
     return (int)HJ_OK;
   });
 }
+int hjh_scene_compile_shapes(const hjh_scene* s, hjh_compiled** out) {
+  if (!s || !out) return fail(HJ_ERR_INVALID, "null argument");
+  return guarded([&] {
+    auto* c = new hjh_compiled();
+    try {
+      c->cs = compile(s->scene, false);
+    } catch (...) {
+      delete c;
+      throw;
+    }
+    *out = c;
+    return (int)HJ_OK;
+  });
+}
 void hjh_compiled_destroy(hjh_compiled* c) { delete c; }
 
 int hjh_compiled_desc(const hjh_compiled* c, hj_scene_desc* out) {
@@ -176,7 +190,8 @@ int hjh_compiled_desc(const hjh_compiled* c, hj_scene_desc* out) {
 }
 int hjh_compiled_set_bvh(hjh_compiled* c, const hj_bvh_node* nodes, size_t n) {
   if (!c || !nodes) return fail(HJ_ERR_INVALID, "null argument");
-  if (n != c->cs.bvh.size()) return fail(HJ_ERR_INVALID, "a tree over these shapes has " + std::to_string(c->cs.bvh.size()) + " nodes");
+  const size_t shapes = c->cs.spheres.size() + c->cs.quads.size() + c->cs.triangles.size(), want = shapes ? 2 * shapes - 1 : 0;
+  if (n != want) return fail(HJ_ERR_INVALID, "a tree over these shapes has " + std::to_string(want) + " nodes");
   return guarded([&] {
     c->cs.bvh.assign(nodes, nodes + n);
     return (int)HJ_OK;

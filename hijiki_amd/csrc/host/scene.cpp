@@ -298,24 +298,42 @@ size_t order_children(std::vector<BuildNode>& nodes, int32_t nd, int mode) {
 }
 }  // namespace
 
+const BuildTuning& BuildTuning::get() {
+  static const BuildTuning t = [] {
+    auto num = [](const char* name, long dflt) { const char* e = std::getenv(name); return e ? std::atol(e) : dflt; };
+    BuildTuning b;
+    b.rotate_passes = (int)num("HJ_BVH_ROTATE", 8);
+    b.reinsert_passes = (int)num("HJ_BVH_REINSERT", -1);
+    b.reinsert_max = num("HJ_BVH_REINSERT_MAX", 0);
+    b.child_order = (int)num("HJ_BVH_CHILD_ORDER", 4);
+    b.vote_paths = num("HJ_BVH_VOTE_PATHS", 0);
+    b.vote_shadow = std::getenv("HJ_BVH_VOTE_SHADOW") ? (int)std::min(16l, std::max(0l, num("HJ_BVH_VOTE_SHADOW", 0))) : -1;
+    b.verbose = std::getenv("HJ_BVH_VERBOSE") != nullptr;
+    b.rotate_verbose = std::getenv("HJ_BVH_ROTATE_VERBOSE") != nullptr;
+    return b;
+  }();
+  return t;
+}
+
 std::vector<BuildNode> build_bvh(const std::vector<Aabb>& boxes) {
   if (boxes.empty()) return {};
   Builder b(boxes);
   b.build(0, boxes.size());
-  static const int rotate_passes = [] { const char* e = std::getenv("HJ_BVH_ROTATE"); return e ? std::atoi(e) : 8; }();
+  const BuildTuning& tn = BuildTuning::get();
+  const int rotate_passes = tn.rotate_passes;
   for (int p = 0; p < rotate_passes && b.nodes[0].shape < 0; p++) {
     Rotator r{b.nodes};
     r.visit(0);
-    if (std::getenv("HJ_BVH_ROTATE_VERBOSE")) std::fprintf(stderr, "rotation pass %d: half-area gain %.4f\n", p, r.gain);
+    if (tn.rotate_verbose) std::fprintf(stderr, "rotation pass %d: half-area gain %.4f\n", p, r.gain);
     if (r.gain <= 0) break;
   }
   // HJ_BVH_REINSERT = passes of the insertion-based optimisation (tree_opt.cpp)
   // (default: 3 passes up to 400 000 nodes; beyond that a pass over 1/16 of the nodes costs 1.5 s per 2 M nodes and no longer
   // lowers the node visits measurably, a pass over all of them +2 % frame rate for half a minute - tools/tree_probe.py)
-  static const int reinsert_passes = [] { const char* e = std::getenv("HJ_BVH_REINSERT"); return e ? std::atoi(e) : -1; }();
+  const int reinsert_passes = tn.reinsert_passes;
   const int passes = reinsert_passes >= 0 ? reinsert_passes : (b.nodes.size() <= 400000 ? 3 : 0);
   if (passes > 0) optimize_by_reinsertion(b.nodes, passes);
-  static const int child_order = [] { const char* e = std::getenv("HJ_BVH_CHILD_ORDER"); return e ? std::atoi(e) : 4; }();
+  const int child_order = tn.child_order;
   if (child_order != 0) order_children(b.nodes, 0, std::min(child_order, 3));
   return std::move(b.nodes);
 }
@@ -452,7 +470,7 @@ void directional_bvh(const CompiledScene& cs, int mode, size_t vote_paths, int f
 
 // ---------------------------------------------------------------- compile
 
-CompiledScene compile(const Scene& scene) {
+CompiledScene compile(const Scene& scene, bool with_tree) {
   CompiledScene out;
   out.camera = scene.camera;
   out.vertices = scene.vertices;
@@ -492,12 +510,14 @@ CompiledScene compile(const Scene& scene) {
   }
 
   // BVH::build (src/main.rs:199) -> depth-first flatten with skip links (src/main.rs:203-231)
-  std::vector<BuildNode> tree = build_bvh(boxes);
-  {
+  // (with_tree == false: the arrays without a tree, for a host that lets the device build it - hj_build_bvh_device)
+  std::vector<BuildNode> tree;
+  if (with_tree) tree = build_bvh(boxes);
+  if (with_tree) {
     // HJ_BVH_CHILD_ORDER = 4: on top of "fewer shapes first", the order a sample of the renderer's own rays votes for
     // (tree_opt.cpp); HJ_BVH_VOTE_PATHS = camera paths of the sample
-    static const int child_order = [] { const char* e = std::getenv("HJ_BVH_CHILD_ORDER"); return e ? std::atoi(e) : 4; }();
-    static const long vote_paths = [] { const char* e = std::getenv("HJ_BVH_VOTE_PATHS"); return e ? std::atol(e) : 0l; }();
+    const int child_order = BuildTuning::get().child_order;
+    const long vote_paths = BuildTuning::get().vote_paths;
     if (child_order >= 4) {
       const size_t paths = vote_paths > 0 ? (size_t)vote_paths : 60000;   // (more buys nothing: 8 k paths order cbox as 60 k do, 50 k the 1 M-triangle tree as 1 M do)
       order_children_by_rays(tree, scene, paths);
@@ -511,7 +531,7 @@ CompiledScene compile(const Scene& scene) {
       default: return ns + nq + index_in_kind[obj];
     }
   };
-  flatten_bvh(tree, global_index, out.bvh);
+  if (with_tree) flatten_bvh(tree, global_index, out.bvh);
 
   // material words (src/main.rs:246-287)
   std::vector<uint32_t> reprs;

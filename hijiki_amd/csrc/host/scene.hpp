@@ -68,7 +68,20 @@ struct CompiledScene {
 };
 
 // `Scene::compile` (src/main.rs:173-357).  Throws std::runtime_error.
-CompiledScene compile(const Scene& scene);
+CompiledScene compile(const Scene& scene, bool with_tree = true);
+
+// The scene compiler's environment switches (tree quality experiments; the defaults are the measured optima),
+// read in ONE place - BuildTuning::get(), once per process: a compiled tree must not depend on when a variable was set.
+struct BuildTuning {
+  int rotate_passes;        // HJ_BVH_ROTATE            rotation passes over the SAH tree (8)
+  int reinsert_passes;      // HJ_BVH_REINSERT          insertion-based optimisation passes (-1: 3 up to 400 000 nodes, none beyond)
+  long reinsert_max;        // HJ_BVH_REINSERT_MAX      candidates per pass (0: all of a small tree, 1/16 of a large one)
+  int child_order;          // HJ_BVH_CHILD_ORDER       0 as built, 3 fewer shapes first, 4 + voted by sampled rays (4)
+  long vote_paths;          // HJ_BVH_VOTE_PATHS        camera paths of the vote's sample (0: 60 000)
+  int vote_shadow;          // HJ_BVH_VOTE_SHADOW       a shadow ray's vote in quarters of a closest-hit ray's (-1: 1, 4 from 300 000 nodes on)
+  bool verbose, rotate_verbose;   // HJ_BVH_VERBOSE, HJ_BVH_ROTATE_VERBOSE
+  static const BuildTuning& get();
+};
 
 // Binary BVH with one shape per leaf, as the `bvh` crate hands it to the
 // flattening step (src/main.rs:199-231).

@@ -76,7 +76,7 @@ double optimize_by_reinsertion(std::vector<BuildNode>& nodes, int passes) {
   if (nodes.size() < 7 || passes <= 0) return 0.0;
   WorkTree t(nodes);
   const size_t n = nodes.size();
-  const bool verbose = std::getenv("HJ_BVH_VERBOSE") != nullptr;
+  const bool verbose = BuildTuning::get().verbose;
   if (verbose) std::fprintf(stderr, "reinsertion: %zu nodes, cost %.4f\n", n, t.sah());
   struct Cand { float induced; int32_t node; bool operator<(const Cand& o) const { return induced > o.induced; } };
   std::vector<Cand> heap;
@@ -87,7 +87,7 @@ double optimize_by_reinsertion(std::vector<BuildNode>& nodes, int passes) {
     size_t moved = 0, tried = 0;
     // candidates of a pass: the nodes with the largest boxes (most rays pass them, and their searches are the short ones: the bound
     // prunes with the candidate's own area); HJ_BVH_REINSERT_MAX of them, by default all of a small tree and 1/16 of a large one
-    static const long cap = [] { const char* e = std::getenv("HJ_BVH_REINSERT_MAX"); return e ? std::atol(e) : 0l; }();
+    const long cap = BuildTuning::get().reinsert_max;
     const size_t limit = cap > 0 ? (size_t)cap : std::max<size_t>(65536, n / 16);
     for (int32_t N : order) {
       if (tried++ >= limit) break;
@@ -204,8 +204,8 @@ struct Voter {
     for (size_t i = 0; i < gain_l.size(); i++) { gain_l[i].store(0, std::memory_order_relaxed); gain_r[i].store(0, std::memory_order_relaxed); }
     for (size_t i = 0; i < sc.objects.size(); i++)
       if (sc.materials[sc.objects[i].second].tag == HJ_MAT_EMISSIVE) emitters.push_back((int32_t)i);
-    const char* e = std::getenv("HJ_BVH_VOTE_SHADOW");
-    w_shadow = e ? (uint32_t)std::min(16, std::max(0, std::atoi(e))) : (nd.size() >= 300000 ? 4u : 1u);
+    const int ws = BuildTuning::get().vote_shadow;
+    w_shadow = ws >= 0 ? (uint32_t)ws : (nd.size() >= 300000 ? 4u : 1u);
   }
 
   // the reference's slab test (scene.glsl:120-131): entry distance, or +inf when the box is not entered
@@ -435,7 +435,7 @@ size_t order_children_by_rays(std::vector<BuildNode>& nodes, const Scene& scene,
       swapped++;
     }
   }
-  if (std::getenv("HJ_BVH_VERBOSE")) std::fprintf(stderr, "ray-voted child order: %zu paths, %zu of %zu inner nodes exchanged\n", num_paths, swapped, nodes.size() / 2);
+  if (BuildTuning::get().verbose) std::fprintf(stderr, "ray-voted child order: %zu paths, %zu of %zu inner nodes exchanged\n", num_paths, swapped, nodes.size() / 2);
   return swapped;
 }
 

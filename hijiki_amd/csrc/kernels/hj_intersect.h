@@ -59,22 +59,6 @@ HJ_DEV void stp(float4* p, uint32_t i, float4 v) {
 struct Ray { v3 o, d; float tmin, tmax; };
 struct RawHit { float t, u, v; int id; };
 
-// reference shader/shapes/triangle.glsl:15-52 on the pre-gathered record
-HJ_DEV bool intersect_triangle(const DeviceScene& sc, const Ray& r, uint32_t ix, RawHit& h) {
-  const float4* __restrict__ rec = sc.tri_isect + 3 * (size_t)ix;      // one address, three offsets
-  const float4 A = rec[0], B = rec[1], C = rec[2];
-  const v3 a = xyz(A), ab = xyz(B), ac = xyz(C);
-  const v3 n = cross3(ab, ac);
-  const v3 ro = r.o - a;
-  const v3 q = cross3(ro, r.d);
-  const float d = 1.0f / dot3(r.d, n);
-  const float u = d * (-dot3(q, ac));
-  const float v = d * dot3(q, ab);
-  if (u < 0.0f || v < 0.0f || u + v > 1.0f) return false;
-  const float t = d * (-dot3(n, ro));
-  if (r.tmin <= t && t <= r.tmax) { h.t = t; h.u = u; h.v = v; return true; }
-  return false;
-}
 // reference shader/shapes/sphere.glsl:18-41
 HJ_DEV bool intersect_sphere(const Ray& r, float4 sp, RawHit& h) {
   const v3 l = r.o - xyz(sp);
@@ -89,29 +73,7 @@ HJ_DEV bool intersect_sphere(const Ray& r, float4 sp, RawHit& h) {
   if (r.tmin <= t1 && t1 <= r.tmax) { h.t = t1; return true; }
   return false;
 }
-// reference shader/shapes/quad.glsl:7-25
-HJ_DEV bool intersect_quad(const DeviceScene& sc, const Ray& r, uint32_t ix, RawHit& h) {
-  const float4* __restrict__ rec = sc.quads + 3 * (size_t)ix;
-  const v3 o = xyz(rec[0]), e1 = xyz(rec[1]), e2 = xyz(rec[2]);
-  const v3 n = cross3(e1, e2);
-  const v3 ro = r.o - o;
-  const v3 q = cross3(ro, r.d);
-  const float d = 1.0f / dot3(r.d, n);
-  const float u = d * (-dot3(q, e2));
-  const float v = d * dot3(q, e1);
-  if (u < 0.0f || u > 1.0f || v < 0.0f || v > 1.0f) return false;
-  const float t = d * (-dot3(n, ro));
-  if (r.tmin <= t && t <= r.tmax) { h.t = t; h.u = u; h.v = v; return true; }
-  return false;
-}
-
-HJ_DEV bool intersect_shape(const DeviceScene& sc, const Ray& r, uint32_t shape, RawHit& h) {
-  if (shape < sc.ns) return intersect_sphere(r, sc.spheres[shape], h);
-  if (shape < sc.ns + sc.nq) return intersect_quad(sc, r, shape - sc.ns, h);
-  return intersect_triangle(sc, r, shape - sc.ns - sc.nq, h);
-}
-
-// triangle.glsl:15-52 on record values (a, b - a, c - a)
+// reference shader/shapes/triangle.glsl:15-52 on the values of the pre-gathered record (a, b - a, c - a): ONE text for every walk
 HJ_DEV bool triangle_test(const Ray& r, float4 A, float4 B, float4 C, RawHit& h) {
   const v3 ab = xyz(B), ac = xyz(C);
   const v3 n = cross3(ab, ac);
@@ -126,7 +88,7 @@ HJ_DEV bool triangle_test(const Ray& r, float4 A, float4 B, float4 C, RawHit& h)
   return false;
 }
 
-// quad.glsl:7-25 on record values (origin, edge1, edge2)
+// reference shader/shapes/quad.glsl:7-25 on record values (origin, edge1, edge2)
 HJ_DEV bool quad_test(const Ray& r, float4 O, float4 E1, float4 E2, RawHit& h) {
   const v3 e1 = xyz(E1), e2 = xyz(E2);
   const v3 n = cross3(e1, e2);
@@ -139,6 +101,16 @@ HJ_DEV bool quad_test(const Ray& r, float4 O, float4 E1, float4 E2, RawHit& h) {
   const float t = d * (-dot3(n, ro));
   if (r.tmin <= t && t <= r.tmax) { h.t = t; h.u = u; h.v = v; return true; }
   return false;
+}
+
+HJ_DEV bool intersect_shape(const DeviceScene& sc, const Ray& r, uint32_t shape, RawHit& h) {
+  if (shape < sc.ns) return intersect_sphere(r, sc.spheres[shape], h);
+  if (shape < sc.ns + sc.nq) {
+    const float4* __restrict__ rec = sc.quads + 3 * (size_t)(shape - sc.ns);
+    return quad_test(r, rec[0], rec[1], rec[2], h);
+  }
+  const float4* __restrict__ rec = sc.tri_isect + 3 * (size_t)(shape - sc.ns - sc.nq);      // one address, three offsets
+  return triangle_test(r, rec[0], rec[1], rec[2], h);
 }
 
 // What the walk does when it stands on a leaf: `a` is the first word of the node the lane stopped at.

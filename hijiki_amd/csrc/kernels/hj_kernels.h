@@ -19,8 +19,9 @@
 // hj_shade.h (populate, emitters) <- hj_stages.h (the stages + their call wrappers) <- this file (the kernels).
 //
 // k_path_wavefront runs all stages of a batch in ONE persistent launch (workgroup barriers only): the kernel's own code
-// is the walk (trace_persistent: in-wave ray replacement, merged first step, bounded burst), the other three stages are
-// CALLED device functions (stage_*_call: register-allocated on their own, so the walk stays free of spills);
+// is the walk (trace_persistent: in-wave ray replacement, merged first step, bounded burst), the other stages are
+// CALLED device functions (stage_*_call: register-allocated on their own, so the walk stays free of spills; inlined they
+// made the walk spill - rounds 2-3, profiles/NOTES.md); `rp` = the round timing of the statistics build (hj_walk_probe.h);
 // k_gen_camera / k_trace_closest / k_shade / k_trace_shadow launch the stages one by one (diagnostic path).
 // No stage uses a global atomic: appends are wave ballot + one LDS atomic.
 //
@@ -60,12 +61,12 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
   // NT (large trees): the path state is streamed past the caches (ldp / stp)
   __shared__ WgShared sh;
   const uint32_t g = blockIdx.x;
-#if HJ_SHADE_CALL
+  // (the called stages read the batch and scene descriptions from this kernel's argument segment and reach `sh` through its LDS address)
   const uint64_t ka_ = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
   const uint32_t ka_lo = (uint32_t)ka_, ka_hi = (uint32_t)(ka_ >> 32), sh_lds = (uint32_t)(uintptr_t)(WgSharedLds)&sh;
-#endif
-  // Camera paths without records: kernels that have the packet stage (BVH walk over a tree with pair nodes, stages called)
-  constexpr bool IMPLICIT = HJ_CAMERA_PACKETS && HJ_SHADE_CALL >= 2 && USE_BVH && PAIRS;
+  // Camera paths without records: kernels that have the packet stage (BVH walk over a tree with pair nodes)
+  constexpr bool IMPLICIT = USE_BVH && PAIRS;
+  RoundProbe rp;
   uint32_t groups_left = wg_num_groups(st, g);
   uint32_t total_closest = 0, total_shadow = 0, total_hits = 0, total_unocc = 0, total_direct = 0;   // (thread 0's copies are published)
   if (groups_left != 0) {
@@ -83,18 +84,10 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
       const uint32_t k0 = k_next;
       if (ngen != 0) {
         if (!IMPLICIT) {
-#ifdef HJ_WALK_STATS
-          const unsigned long long gen_t0 = wall_clock64();
-#endif
-#if HJ_SHADE_CALL >= 2
+          rp.gen_begin();
           stage_gen_camera_call<NT>(ka_lo, ka_hi, g, sh_lds, parity, n0, k_next, ngen, waves);
-#else
-          stage_gen_camera<NT>(st, sc, g, sh, parity, n0, k_next, ngen, waves);
-#endif
           wg_sync(waves);
-#ifdef HJ_WALK_STATS
-          if (threadIdx.x == 0) atomicAdd(&g_round_stats[24], (wall_clock64() - gen_t0) * waves);
-#endif
+          rp.gen_end(waves);
         }
         k_next += ngen;
         groups_left -= ngen;
@@ -117,10 +110,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
         if (threadIdx.x >= 64u) return;
         waves = 1u;
       }
-#ifdef HJ_WALK_STATS
-      const unsigned long long round_t0 = wall_clock64();
-      const uint32_t round_rays = n + ns;
-#endif
+      rp.round_begin(n + ns);
       wg_sync(waves);                        // everyone has read the counts before they are reset
       if (threadIdx.x == 0) {
         sh.head = 0; sh.head_cam = 0; sh.n_ray[parity ^ 1u] = 0; sh.n_gen = 0; sh.n_shadow = 0; sh.n_unocc = 0; sh.n_direct = 0;
@@ -128,58 +118,26 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(H
       }
       if (threadIdx.x < kNumTags) sh.cnt_hit[threadIdx.x] = 0;
       wg_sync(waves);
-#ifdef HJ_WALK_STATS
-      const unsigned long long st_t0 = wall_clock64();
-#endif
+      rp.walk_begin();
       // the round's new camera rays are the LAST entries of the closest-hit queue: they are walked as packets of 64
       // (stage_camera_packets: one group of a block row each), the merged walk takes the continuing paths and the shadow rays
       uint32_t cam = 0;
-#if HJ_CAMERA_PACKETS && HJ_SHADE_CALL >= 2
       if (IMPLICIT && ngen != 0) {
         cam = 64u * ngen;
         stage_camera_packets_call<NT>(ka_lo, ka_hi, g, parity, n0, ngen, k0, sh_lds);
       }
-#endif
       stage_trace_merged<USE_BVH, PAIRS, NT>(st, sc, g, parity, n - cam, ns, sh);
-#ifdef HJ_WALK_STATS
-      const unsigned long long st_tw = wall_clock64();       // this wave has no ray left
-      wg_sync(waves);                        // (diagnostic build only: the walk ends for all waves before the compaction is timed)
-      const unsigned long long st_t1 = wall_clock64();
-      if ((threadIdx.x & 63u) == 0) atomicAdd(&g_round_stats[29], st_t1 - st_tw);   // [29] wave time spent waiting for the workgroup's slowest wave
-#endif
-#if HJ_SHADE_CALL >= 2
+      rp.walk_end(waves);
       compact_hits_call<NT, 4u>(ka_lo, ka_hi, g, n, sh_lds, waves);
-#else
-      compact_hits_by_tag<NT, 4u>(st, sc, g, n, sh, waves);
-#endif
       wg_sync(waves);
-#ifdef HJ_WALK_STATS
-      const unsigned long long st_t2 = wall_clock64();
-#endif
-#if HJ_SHADE_CALL
+      rp.compact_end();
       if (n != 0) stage_shade_call<NT>(ka_lo, ka_hi, g, parity, max_bounces, rr_start, sh_lds, waves);
-#else
-      if (n != 0) stage_shade<NT>(st, sc, g, parity, max_bounces, rr_start, sh, waves);
-#endif
       total_closest += n - uni(sh.n_cam_dead);   // (positions of ragged blocks' groups that hold no sample are not rays)
       total_shadow += ns;
       for (uint32_t k = 0; k < kNumTags; k++) total_hits += uni(sh.cnt_hit[k]);
       total_unocc += uni(sh.n_unocc);
       wg_sync(waves);
-#ifdef HJ_WALK_STATS
-      if (threadIdx.x == 0) {
-        uint32_t b = 0;
-        while (b < 7u && round_rays >= (16u << (2u * b))) b++;      // 16, 64, 256, 1024, 4096, 16384, 65536
-        atomicAdd(&g_round_stats[b], 1ull);
-        atomicAdd(&g_round_stats[8 + b], (unsigned long long)round_rays);
-        const unsigned long long st_t3 = wall_clock64();
-        atomicAdd(&g_round_stats[16 + b], (st_t3 - round_t0) * waves);
-        atomicAdd(&g_round_stats[25], (st_t1 - st_t0) * waves);
-        atomicAdd(&g_round_stats[26], (st_t2 - st_t1) * waves);
-        atomicAdd(&g_round_stats[27], (st_t3 - st_t2) * waves);
-        atomicAdd(&g_round_stats[28], (st_t0 - round_t0) * waves);
-      }
-#endif
+      rp.round_end(waves);
     }
   }
   if (threadIdx.x == 0) {

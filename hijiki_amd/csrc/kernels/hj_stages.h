@@ -175,32 +175,19 @@ HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint
   const float4* __restrict__ ro = st.ray_o[parity] + seg;
   const float4* __restrict__ rd = st.ray_d[parity] + seg;
   uint32_t unocc = 0;                                               // wave-uniform count (statistics)
-  // HJ_SHADOW_CARRY: a shadow ray brings its pending NEE contribution along in the registers a closest-hit ray uses for
-  // (t, u, v) - an accepted hit ends a shadow ray, so nothing overwrites them while they matter - and its SAMPLE index in
-  // `slot`: the finish of an unoccluded shadow ray is then one read-modify-write of the sample instead of two dependent trips.
-  // HJ_FETCH_SELECT: loads from selected addresses instead of loads in the two arms of a branch.
+  // A shadow ray brings its pending NEE contribution along in the registers a closest-hit ray uses for (t, u, v) - an accepted
+  // hit ends a shadow ray, so nothing overwrites them while they matter - and its SAMPLE index in `slot`: the finish of an
+  // unoccluded shadow ray is then one read-modify-write of the sample instead of two dependent trips.  The loads come from
+  // SELECTED addresses instead of the two arms of a branch (both measured in round 2: profiles/NOTES.md).
   auto fetch = [&](uint32_t i, uint32_t& slot, Ray& r, bool& any, RawHit& h) {
     any = i >= n;
     const uint32_t pos = any ? i - n : i;                           // position in the path / shadow arrays
     slot = pos;
     float4 o, d;
-#if HJ_FETCH_SELECT
     o = ldp<NT>(any ? st.sh_o + seg : ro, pos); d = ldp<NT>(any ? st.sh_d + seg : rd, pos);
-#if HJ_SHADOW_CARRY
     const float4 cc = ldp<NT>(st.sh_c + seg, any ? pos : 0u);       // (a closest-hit ray's third load is a dummy)
     h.t = any ? cc.x : 0.f; h.u = any ? cc.y : 0.f; h.v = any ? cc.z : 0.f;
     slot = any ? __float_as_uint(cc.w) : pos;
-#endif
-#else
-    if (any) {
-      o = ldp<NT>(st.sh_o + seg, pos); d = ldp<NT>(st.sh_d + seg, pos);
-#if HJ_SHADOW_CARRY
-      const float4 cc = ldp<NT>(st.sh_c + seg, pos);
-      h.t = cc.x; h.u = cc.y; h.v = cc.z;
-      slot = __float_as_uint(cc.w);
-#endif
-    } else { o = ldp<NT>(ro, pos); d = ldp<NT>(rd, pos); }
-#endif
     h.id = -1;
     r.o = xyz(o); r.d = xyz(d);
     r.tmin = (!any && (__float_as_uint(o.w) & kCameraFlag) != 0u) ? kEps : 2.0f * kEps;   // render.glsl:33,132; scene.glsl:85
@@ -210,17 +197,9 @@ HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint
     if (done && !any) stp<NT>(st.hit + seg, slot, make_float4(h.t, __int_as_float(h.id), h.u, h.v));
     const bool add = done && any && h.id < 0;       // unoccluded shadow ray: render.glsl:123
     if (add) {
-#if HJ_SHADOW_CARRY
       float4 s = ldp<NT>(st.smp_rgb, slot);
       s.x += h.t; s.y += h.u; s.z += h.v;
       stp<NT>(st.smp_rgb, slot, s);
-#else
-      const float4 cc = ldp<NT>(st.sh_c + seg, slot);
-      const uint32_t smp = __float_as_uint(cc.w);
-      float4 s = ldp<NT>(st.smp_rgb, smp);
-      s.x += cc.x; s.y += cc.y; s.z += cc.z;
-      stp<NT>(st.smp_rgb, smp, s);
-#endif
     }
     unocc += (uint32_t)__popcll(__ballot(add));
   };
@@ -258,9 +237,6 @@ HJ_DEV void stage_trace_merged(const BatchState& st, const DeviceScene& sc, uint
 // form a packet.
 //   first / chunks: positions [first, first + 64 * chunks) of the path arrays of `parity`; results = hit records, as the
 //   merged walk writes them.  Needs sh.head_cam == 0 and the hot nodes loaded.
-#ifndef HJ_CAMERA_PACKETS
-#define HJ_CAMERA_PACKETS 1
-#endif
 typedef const __attribute__((address_space(4))) f4s* ScalarF4;        // constant address space: a uniform index gives an s_load
 HJ_DEV float4 lds4(ScalarF4 p, uint32_t i) { const f4s v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
 template <bool NT>
@@ -277,9 +253,7 @@ HJ_DEV void stage_camera_packets(const BatchState& st, const DeviceScene& sc, ui
   const uint32_t nn = sc.num_nodes, nhot = sc.num_hot;
   constexpr uint32_t kAwake = 0xFFFFFFFFu, kNever = 0xFFFFFFFEu;
   uint32_t dead = 0;                         // wave-uniform: positions without a sample
-#ifdef HJ_WALK_STATS
-  unsigned long long pk_steps = 0, pk_lanes = 0, pk_cold = 0;   // (wave-uniform) node steps of the packets, live lanes in them, steps on nodes outside the LDS copy
-#endif
+  PacketProbe pp;
   for (;;) {
     const uint32_t c = lds_fetch_chunk(&sh.head_cam);
     if (c >= 64u * chunks) break;
@@ -319,9 +293,7 @@ HJ_DEV void stage_camera_packets(const BatchState& st, const DeviceScene& sc, ui
       const uint32_t a = __float_as_uint(n0.w), ex = __float_as_uint(n1.w);
       if (wake == cur) wake = kAwake;
       const bool live = wake == kAwake;
-#ifdef HJ_WALK_STATS
-      pk_steps += 1; pk_lanes += (unsigned long long)__popcll(__ballot(live)); pk_cold += cur >= nhot ? 1u : 0u;
-#endif
+      pp.step(wake, cur, sc);
       uint32_t nxt = ex;
       if ((a & kInnerFlag) == 0u) {          // a leaf: its shape is tested by every lane that got here (scene.glsl:105-119)
         if (live) {
@@ -365,11 +337,7 @@ HJ_DEV void stage_camera_packets(const BatchState& st, const DeviceScene& sc, ui
     stp<NT>(st.hit, pos, make_float4(h.t, __int_as_float(h.id), h.u, h.v));
   }
   if (lane == 0 && dead != 0) atomicAdd(&sh.n_cam_dead, dead);
-#ifdef HJ_WALK_STATS
-  // [8] wave-steps of the camera packets, [9] live lanes in them (beside [1], [2] of the merged walk); their cold steps are scalar
-  // loads, not lane fetches: counted per wave in g_round_stats[30]
-  if (lane == 0 && pk_steps != 0) { atomicAdd(&g_walk_stats[8], pk_steps); atomicAdd(&g_walk_stats[9], pk_lanes); atomicAdd(&g_round_stats[30], pk_cold); }
-#endif
+  pp.end();
 }
 
 // Ordered compaction of the hits of this workgroup's n closest-hit rays by material tag (divergent-BSDF sort): every
@@ -634,15 +602,12 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
   }
 }
 
-// The shade stage as a CALLED function (HJ_SHADE_CALL): shade needs about twice the registers of the walk, and inlined into
+// The stages as CALLED functions: shade needs about twice the registers of the walk, and inlined into
 // the fused kernel it makes the register allocator of that kernel spill - where, is decided globally, and a single reload
 // inside the walk loop costs a memory trip per round of the loop.  As a function of its own it is allocated on its own
 // (same register budget: the waves-per-SIMD attribute of the calling kernel is propagated to it), and its spills stay
 // inside it.  The batch and scene descriptions are read from the calling kernel's argument segment (every kernel that
 // calls this starts with (BatchState, DeviceScene)): scalar loads, as in the kernel itself.
-#ifndef HJ_SHADE_CALL
-#define HJ_SHADE_CALL 2      // 0: every stage inlined into the fused kernel, 1: shade called, 2: top-up, hit compaction and shade called
-#endif
 typedef __attribute__((address_space(3))) WgShared* WgSharedLds;
 constexpr size_t kSceneArgOffset = (sizeof(BatchState) + alignof(DeviceScene) - 1) / alignof(DeviceScene) * alignof(DeviceScene);
 struct KernelArgsHead { BatchState st; DeviceScene sc; };      // how the argument segment of those kernels starts

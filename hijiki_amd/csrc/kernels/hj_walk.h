@@ -1,7 +1,9 @@
 // The persistent BVH walk of the path kernel: in-wave ray replacement, merged first step, bounded burst
-// (reference shader/scene.glsl:97-133 per ray), and its diagnostic probes.
+// (reference shader/scene.glsl:97-133 per ray).  Its diagnostic probes live in hj_walk_probe.h behind one
+// hook struct (`pb`): in the shipped build every hook is an empty inline function.
 #pragma once
 #include "hj_intersect.h"
+#include "hj_walk_probe.h"
 
 #pragma clang fp contract(off)
 
@@ -18,35 +20,13 @@ namespace hj {
 // A round of the loop: service phase (only when enough lanes are free) -> merged first step (leaf lanes fetch their shape
 // record, the others their node, in one trip) -> up to inner_burst - 1 plain box steps for the lanes not standing on a leaf.
 
-#ifdef HJ_WALK_STATS
-// Diagnostic build only (tools/build_variant.sh stats -DHJ_WALK_STATS): wave-level occupancy of the walk's phases.
-// [0] outer iterations [1] inner wave-steps [2] lanes in them [3] leaf phases [4] lanes in them [5] refills
-// [6] lanes refilled [7] lanes active at the start of an outer iteration; [29] of g_round_stats: wave time at the barrier behind the walk
-__device__ unsigned long long g_walk_stats[16];   // [10..12] wave cycles by phase, [13] total, [14] lane-steps on nodes outside the LDS copy
-// rounds of the fused kernel by size bucket b (rays of the round in [64 * 4^b / 4, 64 * 4^b), b = 0..7):
-// [b] rounds, [8 + b] rays, [16 + b] wave-cycles (wall clock of the round x waves of the workgroup still alive)
-__device__ unsigned long long g_round_stats[32];   // [0..23] rounds by size; [24..28] wall cycles x waves of top-up, walk, hit compaction, shade, the rest of a round
-#define HJ_STAT(i, v) do { const long long v_ = (long long)(v); if (__lane_id() == 0) ws[i] += (unsigned long long)v_; } while (0)
-#else
-#define HJ_STAT(i, v) do { } while (0)
-#endif
-
 // MODE 0: closest-hit rays, 1: any-hit (shadow) rays, 2: both kinds in one queue (fetch says which per ray).
-// PAIRS: the scene has pair nodes (leaf_test); without them the code for them is not even compiled in (it costs 4 % on
-// a scene that has none).
-#ifndef HJ_MERGE_LEAF
-#define HJ_MERGE_LEAF 2      // 0: separate leaf phase everywhere, 1: merged first step on trees without pair nodes only, 2: everywhere
-#endif
-#ifndef HJ_SHADOW_CARRY
-#define HJ_SHADOW_CARRY 1
-#endif
-#ifndef HJ_FETCH_SELECT
-#define HJ_FETCH_SELECT 1
-#endif
+// PAIRS: the scene has pair nodes; without them the code for them is not even compiled in (it costs 4 % on a scene that has none).
+// (A separate leaf phase behind the box steps instead of the merged first step was the walk of rounds 1-2: -4 % ... -8 %,
+// profiles/NOTES.md; the kernels that need no queue - hj_debug_trace - still walk that way: traverse() in hj_intersect.h.)
 template <int MODE, bool PAIRS, class Fetch, class Finish>
 HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head, const float4* s_nodes,
                              Fetch fetch, Finish finish) {
-  constexpr bool MERGE = HJ_MERGE_LEAF == 2 || (HJ_MERGE_LEAF == 1 && !PAIRS);
   const uint32_t lane = __lane_id();
   const uint32_t nn = sc.num_nodes, nhot = sc.num_hot;
   bool active = false, pending = false, exhausted = false, any = (MODE == 1);
@@ -63,16 +43,11 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     asm volatile("v_mov_b32 %0, %1" : "=v"(nb_lhi) : "s"((uint32_t)(lb >> 32)));
   }
   RawHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.id = -1;
-#if defined(HJ_VALU_PROBE) || defined(HJ_LOAD_PROBE) || defined(HJ_LEAF_VALU_PROBE) || defined(HJ_WIDE_PROBE)
-  float valu_probe = 1.0f;
-#endif
   uint32_t shape = 0, ex = 0;
-  bool at_leaf = false;                  // (MERGE: a leaf reached in one round is tested in the first step of the next)
-#ifdef HJ_WALK_STATS
-  unsigned long long ws[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const unsigned long long t_begin = clock64();
-#endif
-  // Merged first step of a round (MERGE): a lane that reached a leaf in the previous round fetches its SHAPE record in the
+  bool at_leaf = false;                  // (a leaf reached in one round is tested in the first step of the next)
+  WalkProbe pb;
+  pb.begin();
+  // Merged first step of a round: a lane that reached a leaf in the previous round fetches its SHAPE record in the
   // same memory trip in which the other lanes fetch their next node (one address select, the same load instructions), then
   // each kind computes its own test.  The leaf tests of a round so cost no memory round trip of their own, and the lane goes
   // on with the box steps of this round.  Per ray the sequence of box tests, shape tests and tMax updates is unchanged
@@ -125,10 +100,6 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
           else hit = triangle_test(r, x0, x1, x2, h);
           if (hit) { h.id = (int)shape; if (anyhit) done = true; else r.tmax = h.t - kEps; }
         }
-#ifdef HJ_LEAF_VALU_PROBE   // diagnostic: extra VALU instructions in the leaf branch of the merged step (a pair test has ~130)
-#pragma unroll
-        for (int k_ = 0; k_ < HJ_LEAF_VALU_PROBE; k_++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(valu_probe));
-#endif
         if (done) { active = false; pending = true; }   // occluded shadow ray (h.id >= 0 tells finish)
         cur = ex; at_leaf = false;
       } else {
@@ -137,22 +108,15 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     }
   };
   for (;;) {
-#ifdef HJ_WALK_STATS
-    const unsigned long long t_a = clock64();   // [10] service, [11] box steps, [12] leaf tests: wave cycles by phase
-#endif
+    pb.round_begin();
     // Service phase: only when enough lanes are free.  Finished lanes keep their result in registers until
     // then, so that result STORES and new-ray LOADS are issued together, once per phase: vmcnt counts loads and
     // stores in one in-order counter on gfx950, and a store between two node fetches would stall the walk for
     // a full write acknowledgement.
-#ifdef HJ_LANE_LIMIT   // diagnostic: only the first HJ_LANE_LIMIT lanes of a wave ever hold a ray - how the cost of a wave-step depends on its active lanes
-    const unsigned long long idle = __ballot(!active && lane < (uint32_t)(HJ_LANE_LIMIT));
+    // (WalkProbe::kLanes: 64; fewer only in the lane-limit diagnostic build - constant expressions, folded by the front end)
+    const unsigned long long idle = __ballot(!active && (WalkProbe::kLanes == 64u || lane < WalkProbe::kLanes));
     const uint32_t nidle = (uint32_t)__popcll(idle);
-    const bool service = nidle >= (sc.refill_min * (uint32_t)(HJ_LANE_LIMIT) + 63u) / 64u || nidle == (uint32_t)(HJ_LANE_LIMIT);
-#else
-    const unsigned long long idle = __ballot(!active);
-    const uint32_t nidle = (uint32_t)__popcll(idle);
-    const bool service = nidle >= sc.refill_min || nidle == 64u;
-#endif
+    const bool service = nidle >= (WalkProbe::kLanes == 64u ? sc.refill_min : (sc.refill_min * WalkProbe::kLanes + 63u) / 64u) || nidle == WalkProbe::kLanes;
     // The loads of the NEW rays are issued first, the results of the finished ones are written (and, for an unoccluded
     // shadow ray, its sample read, added to and written) after them: both memory round trips are then in flight
     // together, and the wait for the new rays does not include the stores (vmcnt retires in order: only what was
@@ -165,11 +129,7 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
       uint32_t base = 0;
       if (lane == 0) base = atomicAdd(s_head, nidle);
       base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-#ifdef HJ_LANE_LIMIT
-      if (!active && lane < (uint32_t)(HJ_LANE_LIMIT)) {
-#else
-      if (!active) {
-#endif
+      if (!active && (WalkProbe::kLanes == 64u || lane < WalkProbe::kLanes)) {
         const uint32_t my = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
         if (my < n) { fetch(my, slot2, r2, any2, h2); got = true; }
       }
@@ -178,7 +138,7 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
     if (service) {
       if (__ballot(pending) != 0) finish(pending, slot, h, any);
       pending = false;
-      HJ_STAT(5, 1); HJ_STAT(6, __popcll(__ballot(got)));
+      pb.refilled(got);
     }
     if (got) {
       slot = slot2; any = any2; r = r2; h = h2;
@@ -187,56 +147,13 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
       cur = general_position(inv, off) ? sc.root : sc.root2; active = true;
     }
     if (__ballot(active || pending) == 0) break;   // (a lane can finish in the merged first step: its result is written by the next service phase)
-#ifdef HJ_LDS_RT_PROBE
-    // What ONE re-grouping of the wave's rays through LDS costs at the very least: a queue push (ballot + LDS atomic) and the
-    // ray's state (12 dwords here; a design needs 14 or more) written to a slot and read back - here to the lane's own slot
-    // (conflict-free; slots picked from a queue would be scattered).  HJ_LDS_RT_PROBE = how many of them per round of the walk loop.
-    {
-      // (WgShared is declared further down: rt_ctr and rt follow its node copy, which is what s_nodes points to)
-      char* rt_base = reinterpret_cast<char*>(const_cast<float4*>(s_nodes)) + 32u * kHotNodes;
-      uint32_t* rt_ctr = reinterpret_cast<uint32_t*>(rt_base);
-      float4* rt = reinterpret_cast<float4*>(rt_base + 16);
-      const uint32_t a0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)(rt + 3u * threadIdx.x);
-#pragma unroll
-      for (int k_ = 0; k_ < HJ_LDS_RT_PROBE; k_++) {
-        const uint32_t qpos = lds_push(&rt_ctr[k_ & 1], active);
-        f4s w0, w1, w2;
-        w0.x = r.o.x; w0.y = r.o.y; w0.z = r.o.z; w0.w = r.tmax;
-        w1.x = r.d.x; w1.y = r.d.y; w1.z = r.d.z; w1.w = r.tmin;
-        w2.x = h.t; w2.y = __int_as_float(h.id); w2.z = __uint_as_float(cur); w2.w = __uint_as_float(slot + (qpos & 0u));
-        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\tds_write_b128 %0, %3 offset:32"
-                     :: "v"(a0), "v"(w0), "v"(w1), "v"(w2) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(w0), "=&v"(w1), "=&v"(w2) : "v"(a0) : "memory");
-        r.o = V(w0.x, w0.y, w0.z); r.tmax = w0.w; r.d = V(w1.x, w1.y, w1.z); r.tmin = w1.w;
-        h.t = w2.x; h.id = __float_as_int(w2.y); cur = __float_as_uint(w2.z); slot = __float_as_uint(w2.w);
-      }
-    }
-#endif
-    HJ_STAT(0, 1); HJ_STAT(7, __popcll(__ballot(active)));
-#ifdef HJ_WALK_STATS
-    const unsigned long long t_b = clock64();
-    HJ_STAT(10, t_b - t_a);
-#endif
-    if (!MERGE) at_leaf = false;
+    pb.regroup(s_nodes, r, h, cur, slot, active);
+    pb.service_end(active);
     uint32_t burst = sc.inner_burst;       // lanes standing on a leaf wait at most this many box steps of the others
-    if (MERGE) {
-#ifdef HJ_WALK_STATS
-      // the merged step: its node lanes count as a box step, its leaf lanes as a leaf phase; its wave cycles go to [12]
-      { const unsigned long long mn = __ballot(active && !at_leaf && cur < nn), mc = __ballot(active && !at_leaf && cur < nn && cur >= nhot);
-        const unsigned long long ml = __ballot(active && at_leaf), mp = __ballot(active && at_leaf && (shape & kInnerFlag) != 0u);
-        if (lane == 0) {
-          if (mn) { ws[1] += 1; ws[2] += __popcll(mn); ws[14] += __popcll(mc); }
-          if (ml) { ws[3] += 1; ws[4] += __popcll(ml); ws[15] += __popcll(ml) + __popcll(mp); }
-        } }
-#endif
-      step0_issue(); step0_compute();
-      burst--;
-#ifdef HJ_WALK_STATS
-      HJ_STAT(12, clock64() - t_b);
-#endif
-    }
+    pb.merged_begin(active, at_leaf, cur, nn, nhot, shape);
+    step0_issue(); step0_compute();
+    burst--;
+    pb.merged_end();
     while (active && cur < nn && !at_leaf && burst != 0) {
       // hot node: LDS copy, same 32-byte record layout as in HBM, so that ONE address select feeds both 16-byte
       // loads (FLAT loads of base + 32*cur and +16; a per-array `if` compiled to two exec-masked address blocks).
@@ -245,68 +162,19 @@ HJ_DEV void trace_persistent(const DeviceScene& sc, uint32_t n, uint32_t* s_head
       // Neither array crosses a 4 GiB boundary (hj_scene_upload places the node array so; the LDS aperture cannot),
       // so the low word never carries into the high one: cmp + 2 cndmask + 1 shift-add instead of ten instructions.
       const bool hot = cur < nhot;
-#ifdef HJ_WALK_STATS
-      { const unsigned long long m = __ballot(true), mc = __ballot(cur >= nhot);     // [14] lane-steps on nodes outside the LDS copy
-        if (lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[1] += 1; ws[2] += __popcll(m); ws[14] += __popcll(mc); } }
-#endif
+      pb.box_step(cur, nhot);
       const uint32_t a_lo = (hot ? nb_llo : nb_glo) + (cur << 5), a_hi = hot ? nb_lhi : nb_ghi;
       const float4* __restrict__ nd = reinterpret_cast<const float4*>(((uint64_t)a_hi << 32) | (uint64_t)a_lo);
       const float4 n0 = nd[0], n1 = nd[1];
-#ifdef HJ_LOAD_PROBE   // diagnostic: one more 16-byte load per box step; 1: every lane the same address, 2: the lane's own node again, 3: a global (never LDS) address per lane
-      {
-        const float4* pp = HJ_LOAD_PROBE == 1 ? sc.nodes : HJ_LOAD_PROBE == 2 ? nd : sc.nodes + 2 * cur;
-        float4 pv;
-        asm volatile("flat_load_dwordx4 %0, %1" : "=v"(pv) : "v"(pp) : "memory");
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        valu_probe += pv.x * 0.0f;
-      }
-#endif
-#ifdef HJ_WIDE_PROBE   // diagnostic: what a 128-byte node would cost per step - the six other 16-byte parts of the node's 128-byte line
-      {
-        const uint32_t own = (cur & 3u) * 2u;             // the node's own two parts within its group of four records
-        const float4* gp = reinterpret_cast<const float4*>((((uint64_t)a_hi << 32) | (uint64_t)a_lo) & ~127ull);
-        float4 pv[6];
-#pragma unroll
-        for (int k_ = 0; k_ < 6; k_++) {
-          const float4* pp = gp + ((own + 2u + (uint32_t)k_) & 7u);
-          asm volatile("flat_load_dwordx4 %0, %1" : "=v"(pv[k_]) : "v"(pp) : "memory");
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int k_ = 0; k_ < 6; k_++) valu_probe += pv[k_].x * 0.0f;
-        // the destinations must stay live until the wait: a register the compiler considers dead is handed to the next
-        // address computation while the load that will overwrite it is still in flight (a build without this faulted)
-        asm volatile("" :: "v"(valu_probe));
-      }
-#endif
+      pb.box_loads(sc, nd, cur, a_lo, a_hi);
       at_leaf = node_step<PAIRS>(n0, n1, inv, off, r, cur, shape, ex);
       burst--;
-#ifdef HJ_VALU_PROBE   // diagnostic: HJ_VALU_PROBE extra VALU instructions per box step (is the walk VALU-bound?)
-#pragma unroll
-      for (int k_ = 0; k_ < HJ_VALU_PROBE; k_++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(valu_probe));
-#endif
+      pb.box_valu();
     }
     if (active && !at_leaf && cur >= nn) { active = false; pending = true; }   // walked off the end of the tree
-#ifdef HJ_WALK_STATS
-    const unsigned long long t_c = clock64();
-    HJ_STAT(11, t_c - t_b);      // (MERGE: includes the merged step, also counted in [12])
-    if (!MERGE) { const unsigned long long m = __ballot(at_leaf), mp = __ballot(at_leaf && (shape & kInnerFlag) != 0u);   // [15] shape records fetched (a pair: two)
-      if (m && lane == (uint32_t)__ffsll((long long)m) - 1u) { ws[3] += 1; ws[4] += __popcll(m); ws[15] += __popcll(m) + __popcll(mp); } }
-#endif
-    if (!MERGE && at_leaf) {
-      if (leaf_test<PAIRS>(sc, r, shape, h, MODE == 1 || (MODE == 2 && any))) { active = false; pending = true; }   // occluded shadow ray (h.id >= 0 tells finish)
-      cur = ex;
-    }
-    if (!MERGE) HJ_STAT(12, clock64() - t_c);
+    pb.steps_end();
   }
-#ifdef HJ_WALK_STATS
-  HJ_STAT(13, clock64() - t_begin);
-  for (int i = 0; i < 16; i++) {      // ws[] lives in whichever lane did the counting: sum over the wave
-    unsigned long long v = ws[i];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    if (lane == 0 && v) atomicAdd(&g_walk_stats[i], v);
-  }
-#endif
+  pb.end();
 }
 
 }  // namespace hj

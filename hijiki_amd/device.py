@@ -22,7 +22,7 @@ EXPORTS = ("hj_context_create", "hj_context_destroy", "hj_last_error", "hj_versi
            "hj_pass_offset", "hj_block_owner", "hj_debug_trace", "hj_debug_samples", "hj_reduce_framebuffers",
            "hj_build_bvh_device", "hj_render_frame_async", "hj_sync", "hj_set_progress_callback", "hj_device_count",
            "hj_comm_create", "hj_comm_destroy", "hj_comm_reduce_framebuffers", "hj_reserve", "hj_framebuffer_bind",
-           "hj_pipeline_wait", "hj_debug_light_grid", "hj_tune_bvh_device")
+           "hj_pipeline_wait", "hj_debug_light_grid", "hj_tune_bvh_device", "hj_bvh_device_read")
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
 
@@ -72,6 +72,7 @@ def lib():
         L.hj_debug_samples.argtypes = [vp, C.POINTER(abi.ImageBlock), C.POINTER(abi.RenderOpts), C.POINTER(C.c_float)]
         L.hj_build_bvh_device.argtypes = [vp, C.POINTER(abi.SceneDesc), C.POINTER(abi.BvhNode), C.c_size_t, C.POINTER(C.c_size_t)]
         L.hj_tune_bvh_device.argtypes = [vp, C.POINTER(abi.SceneDesc), C.POINTER(abi.BvhNode), C.c_size_t, C.c_size_t]
+        L.hj_bvh_device_read.argtypes = [vp, C.POINTER(abi.BvhNode), C.c_size_t, C.POINTER(C.c_size_t)]
         L.hj_block_seed.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         L.hj_block_seed.restype = C.c_uint32
         L.hj_pass_offset.argtypes = [C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]
@@ -159,8 +160,15 @@ class Renderer:
         if rc != abi.HJ_OK:
             raise abi.HijikiError(rc, lib().hj_last_error(self._h).decode())
 
-    def upload_scene(self, compiled):
+    def upload_scene(self, compiled, device_tree=False):
+        """hj_scene_upload.  device_tree: scene->bvh = NULL - the tree `build_bvh(compiled, keep_on_device=True)` left on the device."""
         desc = compiled.desc if hasattr(compiled, "desc") else compiled
+        if device_tree:
+            d2 = abi.SceneDesc()
+            C.memmove(C.byref(d2), C.byref(desc), C.sizeof(abi.SceneDesc))
+            d2.bvh = None
+            d2.num_bvh_nodes = 0
+            desc = d2
         self._check(lib().hj_scene_upload(self._h, C.byref(desc)))
 
     def create_framebuffer(self, width, height, external_device_ptr=None):
@@ -228,14 +236,27 @@ class Renderer:
         self._progress = PROGRESS_FN(lambda _u, d, t: fn(d, t)) if fn else PROGRESS_FN()
         lib().hj_set_progress_callback(self._h, self._progress, None, interval_blocks)
 
-    def build_bvh(self, compiled):
+    def build_bvh(self, compiled, keep_on_device=False):
         """LBVH over the shapes of `compiled`, built on the device (hj_build_bvh_device): (2 * shapes - 1, 8) uint32
-        records in the reference's layout.  `compiled.set_bvh(nodes)` installs it."""
+        records in the reference's layout.  `compiled.set_bvh(nodes)` installs it.  keep_on_device: nothing comes back to the host
+        (returns the record count): `upload_scene(compiled, device_tree=True)` takes the tree over, `read_device_bvh()` copies it out."""
+        if keep_on_device:
+            got = C.c_size_t(0)
+            self._check(lib().hj_build_bvh_device(self._h, C.byref(compiled.desc), None, 0, C.byref(got)))
+            return got.value
         n = 2 * compiled.num_shapes - 1
         nodes = np.zeros((max(n, 1), 8), np.uint32)
         got = C.c_size_t(0)
         self._check(lib().hj_build_bvh_device(self._h, C.byref(compiled.desc), nodes.ctypes.data_as(C.POINTER(abi.BvhNode)),
                                               len(nodes), C.byref(got)))
+        return nodes[:got.value]
+
+    def read_device_bvh(self):
+        """hj_bvh_device_read: the tree the last build left on the device, (nodes, 8) uint32."""
+        got = C.c_size_t(0)
+        self._check(lib().hj_bvh_device_read(self._h, None, 0, C.byref(got)))
+        nodes = np.zeros((max(got.value, 1), 8), np.uint32)
+        self._check(lib().hj_bvh_device_read(self._h, nodes.ctypes.data_as(C.POINTER(abi.BvhNode)), len(nodes), C.byref(got)))
         return nodes[:got.value]
 
     def tune_bvh_device(self, compiled, vote_paths=60000):

@@ -45,6 +45,7 @@ def lib():
         L.hjh_scene_num_shapes.argtypes = [vp]
         L.hjh_scene_num_shapes.restype = C.c_size_t
         L.hjh_scene_compile.argtypes = [vp, C.POINTER(vp)]
+        L.hjh_scene_compile_shapes.argtypes = [vp, C.POINTER(vp)]
         L.hjh_compiled_destroy.argtypes = [vp]
         L.hjh_compiled_destroy.restype = None
         L.hjh_compiled_desc.argtypes = [vp, C.POINTER(abi.SceneDesc)]
@@ -176,10 +177,11 @@ class Scene:
     def num_shapes(self):
         return lib().hjh_scene_num_shapes(self._h)
 
-    def compile(self):
-        """`Scene::compile` (src/main.rs:173-357)."""
+    def compile(self, with_tree=True):
+        """`Scene::compile` (src/main.rs:173-357).  with_tree=False: the arrays without a tree (hjh_scene_compile_shapes), for
+        `device.Renderer.build_bvh` to build it on the device."""
         h = C.c_void_p()
-        _check(lib().hjh_scene_compile(self._h, C.byref(h)))
+        _check((lib().hjh_scene_compile if with_tree else lib().hjh_scene_compile_shapes)(self._h, C.byref(h)))
         return CompiledScene(h)
 
 

@@ -232,7 +232,7 @@ void hj_default_render_opts(hj_render_opts* opts);
  * and the bind-group plumbing (src/main.rs:808-855).  Validates the same
  * invariants the reference asserts (src/main.rs:562-565) plus index ranges,
  * copies, and re-lays the data out for the kernels (same boxes, same leaves, same visiting order per ray: DESIGN.md 4).
- * scene->bvh must be what Scene::compile flattens (src/main.rs:203-231): a binary tree in pre-order with skip links (left child =
+ * scene->bvh (NULL with num_bvh_nodes == 0: the tree hj_build_bvh_device left on the device, see there) must be what Scene::compile flattens (src/main.rs:203-231): a binary tree in pre-order with skip links (left child =
  * next record, its exit = the right child, a node's exit = the record behind its subtree or, on the right spine, any index >= the
  * node count); the boxes may be anything (a box that does not bound its subtree just culls what the reference would cull), other
  * link structures return HJ_ERR_INVALID.
@@ -305,8 +305,18 @@ int hj_render_frame(hj_context* ctx, uint32_t spp, uint64_t master_seed,
  * holding the bounds of its own subtree, 2 * shapes - 1 records.  Start-up path for large meshes (1 M triangles
  * in milliseconds); its topology is not the host builder's, which changes images only through epsilon-ties and
  * traversal cost.  Put the result into scene->bvh before hj_scene_upload. */
-int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* scene, hj_bvh_node* out_nodes, size_t capacity,
+int hj_build_bvh_device(hj_context* ctx, const hj_scene_desc* scene, hj_bvh_node* out_nodes /* may be NULL */, size_t capacity,
                         size_t* out_num_nodes /* may be NULL */);
+/* The device route without the host in the middle: the tree hj_build_bvh_device builds also STAYS on the device, with the shape
+ * arrays it was built over, until the next build, until an upload takes it over, or until the context ends.
+ *   hj_build_bvh_device(ctx, scene, NULL, 0, &n)      builds; nothing is copied to the host
+ *   hj_scene_upload(ctx, scene) with scene->bvh == NULL and scene->num_bvh_nodes == 0
+ *                                                     derives the kernels' records from that tree on the device (the same shape
+ *                                                     counts as at the build: HJ_ERR_INVALID otherwise; no tree: HJ_ERR_STATE)
+ *   hj_bvh_device_read(ctx, out_nodes, capacity, &n)  a copy of the tree for a host that wants one (out_nodes NULL: only n)
+ * 1 M triangles: build + upload in tens of milliseconds (profiles/r06_startup_1M_triangles.txt).  Results are those of the same
+ * tree handed over through the host, bit for bit. */
+int hj_bvh_device_read(hj_context* ctx, hj_bvh_node* out_nodes, size_t capacity, size_t* out_num_nodes /* may be NULL */);
 
 /* The child order of a flattened tree, voted by a sample of the scene's own rays - on the device (no counterpart upstream: the
  * reference walks the tree the `bvh` crate hands it, src/main.rs:199-231, children in array order, shader/scene.glsl:97-133; host

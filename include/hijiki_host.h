@@ -60,6 +60,9 @@ size_t hjh_scene_num_shapes(const hjh_scene* s);
  * words (:246-287) and the uniform emitter table (:289-307).  Scenes with
  * fewer than 2 shapes are rejected (the reference panics at :230). */
 int  hjh_scene_compile(const hjh_scene* s, hjh_compiled** out);
+/* The same without the tree (desc.bvh == NULL, num_bvh_nodes == 0): per-kind shape lists, material words, emitter table - for a
+ * host that lets the device build the tree (hj_build_bvh_device, then hj_scene_upload with bvh == NULL or hjh_compiled_set_bvh). */
+int  hjh_scene_compile_shapes(const hjh_scene* s, hjh_compiled** out);
 void hjh_compiled_destroy(hjh_compiled* c);
 /* Borrowed view; valid while `c` lives. */
 int  hjh_compiled_desc(const hjh_compiled* c, hj_scene_desc* out);

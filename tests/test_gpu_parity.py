@@ -405,6 +405,47 @@ def test_device_built_bvh(gpu_renderer, oracle, kind):
     cs.set_bvh(sah_nodes)
 
 
+@pytest.mark.parametrize("kind,tris", [(host.SYNTH_CBOX_SPHERES, 1280), (host.SYNTH_CBOX_MESH, 150000)])
+def test_device_tree_stays_on_the_device(oracle, kind, tris):
+    """The device route without the host in the middle (VERDICT r5 task 6a): shapes compiled WITHOUT a tree, hj_build_bvh_device
+    with out_nodes == NULL, hj_scene_upload with scene->bvh == NULL - the tree never visits the host.  The frame is the one of
+    the same tree handed over through the host, bit for bit, and the oracle's on the read-back copy (hj_bvh_device_read); the
+    small scene takes the grid's route back (the light-shaft grid is host code), the large one none at all.  Misuse is refused."""
+    gpu_renderer = device.Renderer(0)                                        # (a context of its own: no tree of an earlier test on it)
+    scene = host.Scene.synthetic(kind, mesh_triangles=tris)
+    cs = scene.compile(with_tree=False)
+    assert cs.desc.num_bvh_nodes == 0 and not cs.desc.bvh
+    with pytest.raises(abi.HijikiError):                                     # no tree anywhere yet
+        gpu_renderer.upload_scene(cs, device_tree=True)
+    n = gpu_renderer.build_bvh(cs, keep_on_device=True)
+    assert n == 2 * cs.num_shapes - 1
+    nodes = gpu_renderer.read_device_bvh()
+    _check_skip_link_tree(nodes, _shape_boxes(cs))
+    other = host.Scene.synthetic(kind, mesh_triangles=tris // 2).compile(with_tree=False)
+    with pytest.raises(abi.HijikiError):                                     # a tree over OTHER shape arrays
+        gpu_renderer.upload_scene(other, device_tree=True)
+    moved = host.Scene.synthetic(kind, mesh_triangles=tris, gen_seed=5).compile(with_tree=False)
+    if moved.num_shapes == cs.num_shapes:                                    # ... also when only their CONTENT differs (sampled fingerprint)
+        with pytest.raises(abi.HijikiError):
+            gpu_renderer.upload_scene(moved, device_tree=True)
+    W, H = 160, 96
+    blocks = host.make_blocks(W, H, 3, 23)
+    gpu_renderer.upload_scene(cs, device_tree=True)
+    gpu_renderer.create_framebuffer(W, H)
+    st = gpu_renderer.render_blocks(blocks)
+    got = gpu_renderer.read().copy()
+    with pytest.raises(abi.HijikiError):                                     # consumed: the next upload needs a new build
+        gpu_renderer.upload_scene(cs, device_tree=True)
+    cs.set_bvh(nodes)                                                        # the same tree through the host
+    want, ctr, _ = oracle.render_blocks(cs, blocks, W, H)
+    assert_same(got, want, "tree that stayed on the device")
+    assert st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"] and st["hits"] == ctr["hits"]
+    through_host, st2 = render(gpu_renderer, cs, W, H, blocks)
+    assert_same(through_host, got, "device route against the host route")
+    assert st2["shadow_rays_proven_free"] == st["shadow_rays_proven_free"]    # (the same light grid, or none, on both routes)
+    gpu_renderer.close()
+
+
 def _record_multiset(nodes):
     """The records of a flattened tree without their links: (box, shape word), sorted."""
     n = np.asarray(nodes, np.uint32).reshape(-1, 8)
