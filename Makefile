@@ -52,6 +52,7 @@ hijiki_amd/lib/libhijiki_hip.so: $(HIP_OBJ)
 	@mkdir -p hijiki_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJ) -ldl -o $@
 	@strings $@ | grep -q 'amdgcn-amd-amdhsa--$(ARCH)' || (echo 'ERROR: no $(ARCH) code object in $@'; rm -f $@; false)
+	@python3 tools/build_stamp.py
 
 oracle/_build/libhj_oracle.so: oracle/hj_oracle.c include/hijiki_hip.h
 	@mkdir -p oracle/_build

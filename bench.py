@@ -127,6 +127,17 @@ def roofline_inputs(config):
         return None, None
 
 
+def build_stamp(config):
+    """hijiki_amd/lib/build_stamp.json (tools/build_stamp.py, written by the build in the container, where .git is): the commit of
+    this build and, for `config`, of the profile whose counters the roofline block replays, whether the path kernel's text is
+    still the profiled one, and how many commits lie between the two."""
+    try:
+        st = json.load(open(os.path.join(ROOT, "hijiki_amd", "lib", "build_stamp.json")))
+    except (OSError, ValueError):
+        return None, None
+    return st, (st.get("profiles") or {}).get(config)
+
+
 def host_cores():
     """Threads the CPU baseline may really use: the cgroup CPU quota when there is one, else the CPU count."""
     n = os.cpu_count() or 1
@@ -322,11 +333,34 @@ def roofline_block(config, agg, elapsed, steps, world, standard, oracle_counters
     sc_ = oracle_counters or survey_8d_counters(config)
     b8d = None if sc_ is None else reference_bytes_per_path(sc_)
     frac_8d = None if b8d is None else round(b8d * agg["paths"] * world / elapsed / 1e9 / HBM_PEAK_GBS, 4)
+    roofs = roofs_block(inputs, agg, busy_ms * 1e-3, traffic)
+    # ONE figure for `frac` (VERDICT r5 task 4): the HBM traffic the counters saw over the peak - where counters exist (the replayed
+    # profile); the bytes of the implemented-algorithm MODEL over the same kernel time stay beside it under their own name.
+    model_gbs, model_frac = round(achieved, 1), round(achieved / HBM_PEAK_GBS, 4)
+    frac_source = "implemented-bytes model (no counters for this run)"
+    if traffic is not None:
+        achieved, frac_source = traffic, "pmc_traffic"
+    # the highest of the roofs the kernel's bytes and instructions meet
+    top = None
+    for name, r_ in (roofs or {}).items():
+        if r_ and r_.get("frac") is not None and (top is None or r_["frac"] > top["frac"]):
+            top = {"name": name, "frac": r_["frac"]}
+    stamp, pstamp = build_stamp(config)
     return {
+        "frac_source": frac_source,
+        "top_roof": top,
+        "model_implemented_bytes": {"achieved": model_gbs, "frac": model_frac, "unit": "GB/s",
+                                    "what": "bytes the implemented wavefront algorithm streams (path / hit / shadow records, samples) over the kernel's exclusive time"},
+        # which kernel text the replayed counters describe (tools/build_stamp.py): commit of the profile, commits since, and whether
+        # kernels/*.h + api/render.hip are still what was profiled
+        "profile_commit": None if not (inputs and pstamp) else pstamp.get("commit"),
+        "profile_age_commits": None if not (inputs and pstamp) else pstamp.get("age_commits"),
+        "profile_kernels_match": None if not (inputs and pstamp) else pstamp.get("kernels_match"),
+        "build_commit": None if not stamp else stamp.get("commit"),
         "frac_survey_8d": frac_8d,
         "survey_8d_note": "SURVEY 8(d)'s algorithmic bytes per path (reference_algorithm_bytes_per_path) x paths/s / 8 TB/s; above 1 = served "
                           "by LDS / scalar cache / L1 / L2, not by HBM",
-        "roofs": roofs_block(inputs, agg, busy_ms * 1e-3, traffic),
+        "roofs": roofs,
         "valu_probe": probe,
         # `bound` names the roof `frac` is measured against (the contract's vocabulary: this path has no MFMA work, its
         # roof is HBM); `limited_by` names what the counters say actually binds the kernel today.
@@ -352,11 +386,11 @@ def roofline_block(config, agg, elapsed, steps, world, standard, oracle_counters
         "achieved_wall": round(alg * world / elapsed / 1e9, 1),
         "reference_algorithm_bytes_per_path": b8d,
         "limiter": lim or None,
-        "note": "`achieved` / `frac` = HBM UTILISATION: bytes of the implemented wavefront algorithm (path/hit/shadow records and "
-                "samples - queue traffic SURVEY 8(d) calls implementation overhead; scene data only where it is neither LDS- nor "
-                "L2-resident; never more than the PMC traffic) over the kernel's exclusive time.  The algorithm's compulsory HBM "
-                "bytes are `compulsory_bytes_per_path`; `overhead_ratio` = traffic / compulsory.  `limited_by` is derived from "
-                "the replayed counters (`limited_by_shares`; DESIGN.md 6, profiles/)"}
+        "note": "`achieved` / `frac` = HBM traffic of the kernel per launch (rocprofv3 FETCH_SIZE corrected + WRITE_SIZE, replayed from "
+                "`traffic_source` and scaled by this run's path count) over its exclusive time, against the 8 TB/s peak; the same as "
+                "`traffic` and roofs.hbm.  Most of those bytes are queue traffic of the wavefront design (`model_implemented_bytes`); the "
+                "algorithm's compulsory HBM bytes are `compulsory_bytes_per_path`, `overhead_ratio` = traffic / compulsory.  HBM is not what "
+                "binds this kernel: `top_roof` is the highest of the roofs it meets, `limited_by` what the counters and the VALU probe say"}
 
 
 def limited_by_counters(lim, hbm_frac, probe=None):

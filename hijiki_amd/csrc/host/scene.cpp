@@ -305,6 +305,7 @@ const BuildTuning& BuildTuning::get() {
     b.rotate_passes = (int)num("HJ_BVH_ROTATE", 8);
     b.reinsert_passes = (int)num("HJ_BVH_REINSERT", -1);
     b.reinsert_max = num("HJ_BVH_REINSERT_MAX", 0);
+    b.reinsert_large = (int)num("HJ_BVH_REINSERT_LARGE", 4);
     b.child_order = (int)num("HJ_BVH_CHILD_ORDER", 4);
     b.vote_paths = num("HJ_BVH_VOTE_PATHS", 0);
     b.vote_shadow = std::getenv("HJ_BVH_VOTE_SHADOW") ? (int)std::min(16l, std::max(0l, num("HJ_BVH_VOTE_SHADOW", 0))) : -1;
@@ -331,8 +332,11 @@ std::vector<BuildNode> build_bvh(const std::vector<Aabb>& boxes) {
   // (default: 3 passes up to 400 000 nodes; beyond that a pass over 1/16 of the nodes costs 1.5 s per 2 M nodes and no longer
   // lowers the node visits measurably, a pass over all of them +2 % frame rate for half a minute - tools/tree_probe.py)
   const int reinsert_passes = tn.reinsert_passes;
-  const int passes = reinsert_passes >= 0 ? reinsert_passes : (b.nodes.size() <= 400000 ? 3 : 0);
-  if (passes > 0) optimize_by_reinsertion(b.nodes, passes);
+  const bool large = b.nodes.size() > 400000;
+  const int passes = reinsert_passes >= 0 ? reinsert_passes : (large ? tn.reinsert_large : 3);
+  // (large trees: the batched form - parallel searches, serial moves - over ALL nodes; the serial pass over a sixteenth of them that
+  // round 5 tried there bought nothing, the serial pass over all of them +1 ... 3 % frame rate for 25 s: profiles/r05_c4_reinsert_all_nodes.txt)
+  if (passes > 0) { if (large) optimize_by_reinsertion_batched(b.nodes, passes); else optimize_by_reinsertion(b.nodes, passes); }
   const int child_order = tn.child_order;
   if (child_order != 0) order_children(b.nodes, 0, std::min(child_order, 3));
   return std::move(b.nodes);
@@ -445,7 +449,7 @@ Scene scene_of(const CompiledScene& cs) {
 // then the ray-voted child order.  The image changes at most in epsilon ties, like with any other tree.
 void tune_bvh(CompiledScene& cs, int reinsert_passes, size_t vote_paths) {
   std::vector<BuildNode> tree = unflatten_bvh(cs.bvh);
-  if (reinsert_passes > 0) optimize_by_reinsertion(tree, reinsert_passes);
+  if (reinsert_passes > 0) { if (tree.size() > 400000) optimize_by_reinsertion_batched(tree, reinsert_passes); else optimize_by_reinsertion(tree, reinsert_passes); }
   if (vote_paths > 0) order_children_by_rays(tree, scene_of(cs), vote_paths);
   flatten_bvh(tree, [](int32_t shape) { return (uint32_t)shape; }, cs.bvh);
 }

@@ -76,6 +76,7 @@ struct BuildTuning {
   int rotate_passes;        // HJ_BVH_ROTATE            rotation passes over the SAH tree (8)
   int reinsert_passes;      // HJ_BVH_REINSERT          insertion-based optimisation passes (-1: 3 up to 400 000 nodes, none beyond)
   long reinsert_max;        // HJ_BVH_REINSERT_MAX      candidates per pass (0: all of a small tree, 1/16 of a large one)
+  int reinsert_large;       // HJ_BVH_REINSERT_LARGE    batched passes over ALL nodes of a tree beyond 400 000 nodes (4: c4 +4 ... 5 %, 1.5 s per pass on 8 cores; 0 for a fast start)
   int child_order;          // HJ_BVH_CHILD_ORDER       0 as built, 3 fewer shapes first, 4 + voted by sampled rays (4)
   long vote_paths;          // HJ_BVH_VOTE_PATHS        camera paths of the vote's sample (0: 60 000)
   int vote_shadow;          // HJ_BVH_VOTE_SHADOW       a shadow ray's vote in quarters of a closest-hit ray's (-1: 1, 4 from 300 000 nodes on)
@@ -94,6 +95,7 @@ std::vector<BuildNode> build_bvh(const std::vector<Aabb>& boxes);  // node 0 is 
 // Optimisation passes over the finished tree (tree_opt.cpp): insertion-based optimisation of the surface-area cost, and the
 // order of every node's two children voted by a sample of the rays the renderer will trace through `scene`.
 double optimize_by_reinsertion(std::vector<BuildNode>& nodes, int passes);
+double optimize_by_reinsertion_batched(std::vector<BuildNode>& nodes, int passes);   // large trees: parallel searches, serial moves
 size_t order_children_by_rays(std::vector<BuildNode>& nodes, const Scene& scene, size_t num_paths);
 // Flattening (src/main.rs:203-231) and its inverse; the tree passes on an installed tree (scene.cpp).
 void flatten_bvh(const std::vector<BuildNode>& tree, const std::function<uint32_t(int32_t)>& global_index, std::vector<hj_bvh_node>& out_bvh);

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -132,6 +133,128 @@ double optimize_by_reinsertion(std::vector<BuildNode>& nodes, int passes) {
       if (X != S) moved++;
     }
     if (verbose) std::fprintf(stderr, "reinsertion pass %d: %zu subtrees moved, cost %.4f\n", pass, moved, t.sah());
+    if (moved == 0) break;
+  }
+  t.store(nodes);
+  return t.sah();
+}
+
+// The same optimisation for LARGE trees (beyond 400 000 nodes the serial pass over all nodes takes half a minute: round 5 ran none
+// there).  Candidates are taken in the same order, in batches: phase 1 - every candidate of a batch searches its best place on the
+// tree AS IT STANDS at the start of the batch, in parallel, read-only, with its own removal emulated on the fly (its parent P is
+// skipped, the sibling S stands in P's place, the ancestors' boxes are refitted along the path) - exactly the serial search;
+// phase 2 - the moves are applied one after the other in candidate order, each checked against what the earlier moves of the
+// batch did (the target must not have moved under the candidate, nor be the parent that leaves with it).  Batches start small
+// (the largest boxes, whose moves interact most) and grow.  The result depends on the batch sizes, NOT on the thread count.
+double optimize_by_reinsertion_batched(std::vector<BuildNode>& nodes, int passes) {
+  if (nodes.size() < 7 || passes <= 0) return 0.0;
+  WorkTree t(nodes);
+  const size_t n = nodes.size();
+  const bool verbose = BuildTuning::get().verbose;
+  if (verbose) std::fprintf(stderr, "batched reinsertion: %zu nodes, cost %.4f\n", n, t.sah());
+  std::vector<int32_t> order(n), target(n);
+  const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  // one candidate's search: the best sibling X for N on the tree without N and its parent; -1: stay.  (Per thread: the heap.  The
+  // path - the ancestors whose boxes shrink when N leaves - is a handful of nodes: a linear look-up beats a stamp per node, whose
+  // 8 MB per thread cost more cache misses than the look-up costs compares.)
+  struct Cand { float induced; int32_t node; bool operator<(const Cand& o) const { return induced > o.induced; } };
+  struct alignas(128) Scratch { std::vector<Cand> heap; };      // (a cache line of its own: the vector's end pointer moves with every push)
+  auto search = [&t](int32_t N, Scratch& sc) -> int32_t {
+    const int32_t P = t.parent[N];
+    if (P <= 0) return -1;
+    const int32_t G = t.parent[P], S = t.c0[P] == N ? t.c1[P] : t.c0[P];
+    // boxes of the ancestors of P once N is gone (the serial pass refits them before it searches)
+    int32_t path_node[192];
+    Aabb path_box[192];
+    int np = 0;
+    {
+      int32_t below = P;
+      Aabb below_box = t.box[S];
+      for (int32_t a = G; a >= 0 && np < 192; a = t.parent[a]) {
+        const int32_t other = t.c0[a] == below ? t.c1[a] : t.c0[a];
+        const Aabb b = join2(below_box, t.box[other]);
+        if (same_box(b, t.box[a])) break;                      // nothing changes from here up
+        path_node[np] = a; path_box[np] = b; np++;
+        below = a; below_box = b;
+      }
+    }
+    auto box_of = [&](int32_t x) -> const Aabb& { for (int k = 0; k < np; k++) if (path_node[k] == x) return path_box[k]; return t.box[x]; };
+    auto child = [&](int32_t x, int which) { const int32_t c = which ? t.c1[x] : t.c0[x]; return c == P ? S : c; };
+    const Aabb nb = t.box[N];
+    const float area_n = nb.half_area();
+    float best_cost = std::numeric_limits<float>::infinity();
+    int32_t best = S;
+    std::vector<Cand>& heap = sc.heap;
+    heap.clear();
+    heap.push_back({0.f, 0});
+    while (!heap.empty()) {
+      std::pop_heap(heap.begin(), heap.end());
+      const Cand c = heap.back();
+      heap.pop_back();
+      if (c.induced + area_n >= best_cost) break;
+      const int32_t X = c.node;
+      const Aabb& xb = box_of(X);
+      const float direct = join2(xb, nb).half_area();
+      const float total = c.induced + direct;
+      if (X != 0 && total < best_cost) { best_cost = total; best = X; }
+      const float down = total - xb.half_area();
+      if (t.shape[X] < 0 && down + area_n < best_cost) {
+        heap.push_back({down, child(X, 0)}); std::push_heap(heap.begin(), heap.end());
+        heap.push_back({down, child(X, 1)}); std::push_heap(heap.begin(), heap.end());
+      }
+    }
+    return best == S ? -1 : best;
+  };
+  std::vector<Scratch> scratch(hw);
+  for (int pass = 0; pass < passes; pass++) {
+    for (size_t i = 0; i < n; i++) order[i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return t.box[a].half_area() > t.box[b].half_area(); });
+    const long cap = BuildTuning::get().reinsert_max;
+    const size_t limit = cap > 0 ? std::min<size_t>((size_t)cap, n) : n;
+    size_t moved = 0, stale = 0;
+    const auto pass_t0 = std::chrono::steady_clock::now();
+    for (size_t begin = 0; begin < limit;) {
+      const size_t batch = std::min(limit - begin, std::min<size_t>(8192, std::max<size_t>(64, begin / 4)));
+      // phase 1
+      std::atomic<size_t> next{begin};
+      auto run = [&](unsigned me) {
+        for (;;) {
+          const size_t i0 = next.fetch_add(16);
+          if (i0 >= begin + batch) break;
+          for (size_t i = i0; i < std::min(begin + batch, i0 + 16); i++) target[i] = search(order[i], scratch[me]);
+        }
+      };
+      std::vector<std::thread> pool;
+      if (batch >= 512) { try { for (unsigned k = 1; k < hw; k++) pool.emplace_back(run, k); } catch (const std::system_error&) {} }
+      run(0);
+      for (auto& th : pool) th.join();
+      // phase 2
+      for (size_t i = begin; i < begin + batch; i++) {
+        const int32_t N = order[i], X = target[i];
+        if (X < 0) continue;
+        const int32_t P = t.parent[N];
+        if (P <= 0 || X == P || X == 0) { stale++; continue; }
+        bool inside = false;                                   // an earlier move of this batch may have put X under N
+        for (int32_t a = X; a >= 0; a = t.parent[a]) if (a == N) { inside = true; break; }
+        if (inside) { stale++; continue; }
+        const int32_t G = t.parent[P], S = t.c0[P] == N ? t.c1[P] : t.c0[P];
+        if (X == S) continue;
+        (t.c0[G] == P ? t.c0[G] : t.c1[G]) = S;
+        t.parent[S] = G;
+        t.refit_from(G);
+        const int32_t XP = t.parent[X];
+        (t.c0[XP] == X ? t.c0[XP] : t.c1[XP]) = P;
+        t.parent[P] = XP;
+        t.c0[P] = X; t.c1[P] = N;
+        t.parent[X] = P; t.parent[N] = P;
+        t.box[P] = join2(t.box[X], t.box[N]);
+        t.refit_from(XP);
+        moved++;
+      }
+      begin += batch;
+    }
+    if (verbose) std::fprintf(stderr, "batched reinsertion pass %d: %zu subtrees moved (%zu targets gone stale), cost %.4f, %.2f s on %u threads\n", pass, moved, stale, t.sah(),
+                              std::chrono::duration<double>(std::chrono::steady_clock::now() - pass_t0).count(), hw);
     if (moved == 0) break;
   }
   t.store(nodes);

@@ -20,10 +20,10 @@ SEED = F.source_seed()
 
 
 def test_fuzzed_render_frames_against_the_oracle(gpu_renderer):
-    """200 cases of tools/fuzz_render.py (random scene, tree, size, pass range, rank, options) or as many as fit 30 s."""
+    """400 cases of tools/fuzz_render.py (random scene, tree, size, pass range, rank, options) or as many as fit 30 s (200 take 14 s)."""
     first = SEED % 1_000_000_000
     t0, done, fails = time.time(), 0, []
-    while done < 200 and (time.time() - t0 < 30.0 or done < 40):
+    while done < 400 and (time.time() - t0 < 30.0 or done < 40):
         ok, line = F.fuzz_case(gpu_renderer, first + done)
         if not ok:
             fails.append(line)
@@ -33,13 +33,13 @@ def test_fuzzed_render_frames_against_the_oracle(gpu_renderer):
 
 
 def test_oracle_rays_replayed_through_uploaded_trees(gpu_renderer, monkeypatch):
-    """20 scenes of tools/replay_oracle_rays.py: every ray of the oracle's log plus 20 k crafted degenerate rays per scene through
+    """60 scenes of tools/replay_oracle_rays.py (20 take 1.5 s): every ray of the oracle's log plus 20 k crafted degenerate rays per scene through
     hj_debug_trace, closest-hit and any-hit - on the compiled tree, on the device-built tree and on the tree re-laid out on the
     device (api/scene_relayout.hip) - random, cluster and degenerate scenes."""
     rng = np.random.default_rng(SEED)
     W, H, spp = 96, 64, 2
     t0, total, scenes_done = time.time(), 0, 0
-    for k in range(20):
+    for k in range(60):
         s = int(rng.integers(0, 1_000_000))
         gen = (scenes.random_scene, scenes.random_cluster_scene, scenes.nasty_scene, scenes.random_cluster_scene)[k % 4]
         cs = gen(s)
@@ -54,18 +54,18 @@ def test_oracle_rays_replayed_through_uploaded_trees(gpu_renderer, monkeypatch):
         total += n
         scenes_done += 1
         assert bad == 0, f"HJ_FUZZ_SEED={SEED}: scene {k} ({gen.__name__}({s}), {tree} tree): {bad} of {n} rays differ"
-        if time.time() - t0 > 25.0 and scenes_done >= 8:
+        if time.time() - t0 > 15.0 and scenes_done >= 8:
             break
     print(f"replay: seed {SEED}, {scenes_done} scenes, {total} rays, 0 mismatches, {time.time() - t0:.1f} s")
 
 
 def test_light_grid_never_frees_an_occluded_ray(gpu_renderer, cbox, cbox_spheres):
-    """The light-shaft grid attacked on the GPU: c2's and c3's scenes at 1024 x 1024 (a few passes) and 50 random scenes (as many
-    as fit the budget), each rendered with the grid and with HJ_RENDER_NO_LIGHT_GRID - the proven-free rays walked after all.
+    """The light-shaft grid attacked on the GPU: c2's and c3's scenes at 1024 x 1024 (16 passes) and 200 random scenes (as many
+    as fit the budget: 50 take 2 s), each rendered with the grid and with HJ_RENDER_NO_LIGHT_GRID - the proven-free rays walked after all.
     Disagreements (proven free, found occluded) must be 0 and the frames identical."""
     t0 = time.time()
     proven_total = shadow_total = 0
-    for name, cs, spp in (("c2 scene", cbox, 4), ("c3 scene", cbox_spheres, 4)):
+    for name, cs, spp in (("c2 scene", cbox, 16), ("c3 scene", cbox_spheres, 16)):
         proven, shadow, dis, diff = F.light_grid_disagreements(gpu_renderer, cs, 1024, 1024, spp, SEED % 1000 + 1)
         assert dis == 0 and diff == 0, f"HJ_FUZZ_SEED={SEED}: {name}: {dis} proven-free rays are occluded, {diff} pixels differ"
         assert proven > 0.5 * shadow                      # (the grid is in use: 78 % / 69 % of the shadow rays on these scenes)
@@ -73,7 +73,7 @@ def test_light_grid_never_frees_an_occluded_ray(gpu_renderer, cbox, cbox_spheres
         shadow_total += shadow
     rng = np.random.default_rng(SEED + 1)
     done = 0
-    while done < 50 and (time.time() - t0 < 20.0 or done < 10):
+    while done < 200 and (time.time() - t0 < 12.0 or done < 10):
         s = int(rng.integers(0, 1_000_000))
         scale = float(rng.choice([1.0, 1.0, 0.1, 7.0]))
         cs = scenes.random_cluster_scene(s, scale=scale) if done % 2 else scenes.random_scene(s)

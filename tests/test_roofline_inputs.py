@@ -59,6 +59,13 @@ def test_roofline_block_never_quotes_more_than_the_counters_saw():
     assert r["traffic"] is not None and r["achieved"] <= r["traffic"] * 1.001
     assert 0 < r["valu_issue_frac"] < 1 and 0 < r["lane_fill"] < 1
     assert abs(r["frac"] - r["achieved"] / 8000.0) < 2e-4
+    # ONE figure (VERDICT r5 task 4): `frac` is the counters' HBM traffic over the peak = roofs.hbm; the implemented-bytes model
+    # keeps its own name; the highest roof is lifted beside `limited_by`
+    assert r["frac_source"] == "pmc_traffic" and r["achieved"] == r["traffic"] and abs(r["frac"] - roofs["hbm"]["frac"]) < 2e-4
+    assert 0 < r["model_implemented_bytes"]["frac"] <= r["frac"] + 1e-9
+    assert r["top_roof"]["name"] in roofs and r["top_roof"]["frac"] == max(v["frac"] for v in roofs.values() if v)
+    for key in ("profile_commit", "profile_age_commits", "profile_kernels_match", "build_commit"):
+        assert key in r
 
 
 def test_limited_by_follows_the_counters():
@@ -84,3 +91,23 @@ def test_survey_8d_fraction_uses_the_full_frame_oracle_counters():
         c = bench.survey_8d_counters(cfg)
         assert c is not None and c["paths"] > 0
         assert 3000 < bench.reference_bytes_per_path(c) < 20000
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3", "c4"])
+def test_replayed_profile_describes_the_current_kernels(cfg):
+    """bench.py replays counters from the newest profiles/rNN_<cfg>_roofline_inputs.json.  Its stamp (tools/build_stamp.py
+    --profile, written when the profile was collected) holds the hash of the path kernel's device code at that time: when
+    kernels/*.h or api/render.hip changed afterwards, the counters describe another kernel - profile again
+    (tools/profile_config.sh rNN <cfg>; tools/collect_profiles.sh rNN)."""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import build_stamp
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{cfg}_roofline_inputs.json")))[-1]
+    tag = os.path.basename(newest).split("_")[0]
+    stamp_file = newest[:-len("roofline_inputs.json")] + "profile_stamp.json"
+    if not os.path.exists(stamp_file):
+        assert tag < "r06", f"{os.path.basename(newest)} has no profile stamp"
+        pytest.skip("profiles of rounds 1-5 predate the stamp")
+    stamp = json.load(open(stamp_file))
+    assert stamp["kernels_sha256"] == build_stamp.kernels_sha256(), \
+        f"the path kernel changed after {os.path.basename(newest)} was taken (commit {stamp.get('commit')}): profile {cfg} again"

@@ -9,6 +9,7 @@ for c in $cfgs; do
   for f in bench.json bench_under_rocprof.json kernel_stats.csv kernel_trace_summary.txt roofline_inputs.json walk_stats.json walk_stats.txt; do
     [ -s $d/$f ] && cp $d/$f profiles/${tag}_${c}_$f
   done
+  [ -s $d/roofline_inputs.json ] && python3 tools/build_stamp.py --profile $tag $c > /dev/null
   ls $d/pmc_pass*.csv >/dev/null 2>&1 && ( echo "kernel,launches,counters (one block per --pmc pass)"; cat $d/pmc_pass*.csv ) > profiles/${tag}_${c}_pmc_passes.csv
 done
 [ -s gpurun_out/${tag}_c5_bench.json ] && cp gpurun_out/${tag}_c5_bench.json profiles/${tag}_c5_bench.json

@@ -9,7 +9,11 @@ global per function), so run this after touching any stage.
 Per function: total scratch instructions; scratch instructions in loops of depth >= HOT (kernel: 2 = trace_persistent's
 for(;;), its box-step loop is depth 3; packet stage: 2 = the node loop inside the chunk loop); for the kernel also the older,
 stricter figure: scratch instructions anywhere between the two s_barrier that bracket the walk's node fetch.
-`scan()` returns the same as a dict (tests/test_abi.py asserts the hot-loop figures are 0).
+`scan()` returns the same as a dict (tests/test_abi.py asserts the hot-loop figures are 0).  For the kernels it also accounts for what
+-Rpass-analysis=kernel-resource-usage reports (hijiki_amd/lib/resource_usage.txt: "SGPRs Spill: 42, VGPRs Spill: 1, ScratchSize 88"):
+the SGPR spills are lanes of ONE VGPR (v_writelane / v_readlane, counted per loop depth: depth 2 = once per round of the walk's
+outer loop, depth 3 = the box-step loop), the one spilled VGPR is that lane register saved around the calls, and the 88 bytes per
+lane are the frames of the CALLED stage functions (stage_shade_call's 34 scratch instructions), not the walk's.
 """
 import os, re, subprocess, sys, tempfile
 
@@ -65,7 +69,16 @@ def scan(extra=()):
         depth = loop_depths(body)
         scratch = [(k, l.strip().split(";")[0].strip()) for k, l in enumerate(body) if "scratch_" in l]
         in_hot = [(k, l) for k, l in scratch if depth[k] >= hot]
+        # SGPR spills do not go to memory: the allocator parks them in lanes of a VGPR (v_writelane_b32 / v_readlane_b32); by loop depth
+        lanes = {}
+        for k, l in enumerate(body):
+            t = l.strip().split(" ")[0] if l.strip() else ""
+            if t in ("v_writelane_b32", "v_readlane_b32"):
+                lanes.setdefault(t, {}).setdefault(depth[k], 0)
+                lanes[t][depth[k]] += 1
+        calls = sum(1 for l in body if l.strip().startswith("s_swappc_b64"))
         entry = {"name": label.format(*m.groups()[1:]), "lines": len(body), "scratch": len(scratch), "hot_depth": hot,
+                 "sgpr_spill_lanes": lanes, "calls": calls, "scratch_list": [(k, l, depth[k]) for k, l in scratch],
                  "scratch_in_hot_loops": len(in_hot), "hot_list": in_hot, "between_barriers": None,
                  "max_loop_depth": max(depth) if depth else 0}
         if label.startswith("k_path_wavefront"):
@@ -88,3 +101,9 @@ if __name__ == "__main__":
             print(f"  scratch instructions in loops of depth >= {e['hot_depth']}: {e['scratch_in_hot_loops']}{extra}")
             for k, l in e["hot_list"]:
                 print(f"    {k:6d}  {l}")
+        if e["name"].startswith("k_path_wavefront"):
+            wl, rl = e["sgpr_spill_lanes"].get("v_writelane_b32", {}), e["sgpr_spill_lanes"].get("v_readlane_b32", {})
+            fmt = lambda d: ", ".join(f"depth {k}: {v}" for k, v in sorted(d.items())) or "none"
+            print(f"  SGPR spills (lanes of a VGPR, no memory): v_writelane_b32 {fmt(wl)}; v_readlane_b32 {fmt(rl)}; {e['calls']} calls of stage functions")
+            for k, l, d in e["scratch_list"]:
+                print(f"    scratch at line {k} (loop depth {d}): {l}")
