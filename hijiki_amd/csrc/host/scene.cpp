@@ -305,7 +305,7 @@ const BuildTuning& BuildTuning::get() {
     b.rotate_passes = (int)num("HJ_BVH_ROTATE", 8);
     b.reinsert_passes = (int)num("HJ_BVH_REINSERT", -1);
     b.reinsert_max = num("HJ_BVH_REINSERT_MAX", 0);
-    b.reinsert_large = (int)num("HJ_BVH_REINSERT_LARGE", 4);
+    b.reinsert_large = (int)num("HJ_BVH_REINSERT_LARGE", 6);
     b.child_order = (int)num("HJ_BVH_CHILD_ORDER", 4);
     b.vote_paths = num("HJ_BVH_VOTE_PATHS", 0);
     b.vote_shadow = std::getenv("HJ_BVH_VOTE_SHADOW") ? (int)std::min(16l, std::max(0l, num("HJ_BVH_VOTE_SHADOW", 0))) : -1;

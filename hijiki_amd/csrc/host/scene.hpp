@@ -76,7 +76,7 @@ struct BuildTuning {
   int rotate_passes;        // HJ_BVH_ROTATE            rotation passes over the SAH tree (8)
   int reinsert_passes;      // HJ_BVH_REINSERT          insertion-based optimisation passes (-1: 3 up to 400 000 nodes, none beyond)
   long reinsert_max;        // HJ_BVH_REINSERT_MAX      candidates per pass (0: all of a small tree, 1/16 of a large one)
-  int reinsert_large;       // HJ_BVH_REINSERT_LARGE    batched passes over ALL nodes of a tree beyond 400 000 nodes (4: c4 +4 ... 5 %, 1.5 s per pass on 8 cores; 0 for a fast start)
+  int reinsert_large;       // HJ_BVH_REINSERT_LARGE    batched passes over a tree beyond 400 000 nodes (6: c4 +4 ... 5 %; the first pass searches all nodes, 1.6 s on 8 cores at 1 M triangles, the others the neighbourhood of what moved: 1 s together; 0 for a fast start)
   int child_order;          // HJ_BVH_CHILD_ORDER       0 as built, 3 fewer shapes first, 4 + voted by sampled rays (4)
   long vote_paths;          // HJ_BVH_VOTE_PATHS        camera paths of the vote's sample (0: 60 000)
   int vote_shadow;          // HJ_BVH_VOTE_SHADOW       a shadow ray's vote in quarters of a closest-hit ray's (-1: 1, 4 from 300 000 nodes on)

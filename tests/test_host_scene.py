@@ -276,6 +276,46 @@ def test_batched_reinsertion_on_a_large_tree(tmp_path):
     assert run(1, one_core=True)["tree"] == one["tree"]                         # batch sizes decide, not threads
 
 
+def test_directional_link_orderings(oracle):
+    """hjh_compiled_directional_bvh + hjo_set_directional_bvh (round 6's measurement of a direction-dependent child order; CPU only,
+    the kernels know nothing of it): K = hj_direction_classes(mode) link orderings of the installed tree are K valid pre-order
+    skip-link trees over the same boxes and leaves; a ray walks the array of its direction class (one text in C and numpy:
+    hj_ray_direction_class); the frame is the static order's except at epsilon ties, at fewer node visits; mode 0 is the installed
+    tree itself."""
+    from hijiki_amd import abi
+    from test_gpu_parity import _check_skip_link_tree, _shape_boxes, _record_multiset
+    cs = host.Scene.synthetic(host.SYNTH_CBOX_SPHERES, mesh_triangles=1280).compile()
+    assert [abi.direction_classes(m) for m in range(0, 9)] == [1, 2, 2, 4, 2, 4, 4, 8, 6]
+    d = np.array([[1, 2, -3], [-1, 0.5, 0.25], [-0.0, 0.0, 5], [3, -3, 3]], np.float32)
+    assert abi.ray_direction_class(7, d).tolist() == [4, 1, 1, 2] and abi.ray_direction_class(8, d).tolist() == [5, 1, 4, 0]
+    assert abi.ray_direction_class(5, d).tolist() == [2, 1, 1, 0]
+    same = cs.directional_bvh(0)
+    assert same.shape == (1, len(cs.bvh), 8) and (same[0] == np.asarray(cs.bvh)).all()
+    W, H = 96, 64
+    blocks = host.make_blocks(W, H, 2, 9)
+    L = oracle.lib()
+    L.hjo_set_shadow_anyhit(1)
+    try:
+        want, ctr, _ = oracle.render_blocks(cs, blocks, W, H)
+        for mode in (4, 7, 8):
+            arrays = cs.directional_bvh(mode, vote_paths=8000 * abi.direction_classes(mode))
+            assert arrays.shape[0] == abi.direction_classes(mode)
+            for k in range(arrays.shape[0]):
+                _check_skip_link_tree(arrays[k], _shape_boxes(cs))
+                assert _record_multiset(arrays[k]) == _record_multiset(cs.bvh)
+            L.hjo_set_directional_bvh(mode, arrays.ctypes.data)
+            try:
+                got, c2, _ = oracle.render_blocks(cs, blocks, W, H)
+            finally:
+                L.hjo_set_directional_bvh(0, None)
+            differ = float((got.view(np.uint32) != want.view(np.uint32)).any(axis=-1).mean())
+            assert differ < 0.02 and abs(c2["hits"] - ctr["hits"]) <= 0.001 * ctr["hits"], (mode, differ)
+            if mode == 7:
+                assert c2["nodes"] < 0.99 * ctr["nodes"], (c2["nodes"], ctr["nodes"])          # (measured on c3: -4.5 %)
+    finally:
+        L.hjo_set_shadow_anyhit(0)
+
+
 def test_tune_bvh_on_an_installed_tree(oracle):
     """hjh_compiled_tune_bvh: compile()'s tree passes on a tree that came from elsewhere (here: compile's own tree with every
     inner node's children exchanged - a valid tree in a poor order).  The result is a valid flattened tree over the same shapes,
