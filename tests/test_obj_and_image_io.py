@@ -317,6 +317,22 @@ def test_cli_renders_like_the_library(tmp_path, obj_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "Built BVH with" in r.stdout and open(out3, "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+    # --device-bvh is the fast-start route (shapes only on the host, the tree built and left on the device, hj_scene_upload with
+    # bvh == NULL): the same frame as that route through the library, bit for bit
+    out4 = str(tmp_path / "o4.pfm")
+    r = subprocess.run([exe, "--use-bvh", "--device-bvh", "-w", "96", "-h", "64", "-s", "2", "--seed", "4", "-o", out4, obj_path],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    head4 = b"PF\n96 64\n-1.0\n"
+    got4 = np.frombuffer(open(out4, "rb").read(), np.float32, offset=len(head4)).reshape(64, 96, 3)[::-1]
+    cs4 = host.Scene.from_obj(obj_path).compile(with_tree=False)
+    with device.Renderer(0) as rr:
+        nodes = rr.build_bvh(cs4, keep_on_device=True)
+        assert f"Built BVH with {nodes} nodes" in r.stdout
+        rr.upload_scene(cs4, device_tree=True)
+        rr.create_framebuffer(96, 64)
+        rr.render_frame(2, 4)
+        assert (got4.view(np.uint32) == rr.resolve().view(np.uint32)).all()
 
 
 @pytest.mark.gpu
