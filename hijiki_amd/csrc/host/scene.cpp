@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <functional>
@@ -231,10 +232,20 @@ struct Rotator {
   std::vector<BuildNode>& nodes;
   double gain = 0;
   static Aabb join(const Aabb& a, const Aabb& b) { Aabb r = a; r.join(b); return r; }
-  void visit(int32_t nd) {
+  // bottom-up: the children's subtrees first, then this node's own exchange.  The two subtrees are disjoint, so at the top of a large
+  // tree they go to two threads (parallel_depth levels: up to 16 tasks); the result is the serial pass's, node for node.
+  void visit(int32_t nd, int parallel_depth = 0) {
     BuildNode& n = nodes[nd];
     if (n.shape >= 0) return;
-    visit(n.left); visit(n.right);
+    if (parallel_depth > 0) {
+      Rotator l{nodes}, r{nodes};
+      auto left = std::async(std::launch::async, [&] { l.visit(n.left, parallel_depth - 1); });
+      r.visit(n.right, parallel_depth - 1);
+      left.get();
+      gain += l.gain + r.gain;
+    } else {
+      visit(n.left); visit(n.right);
+    }
     // candidates: (which child of n keeps its place and is opened: 0 left, 1 right) x (which grandchild goes up: 0 left, 1 right)
     float best = 0.f; int bo = -1, bg = -1;
     for (int o = 0; o < 2; o++) {
@@ -318,16 +329,25 @@ const BuildTuning& BuildTuning::get() {
 
 std::vector<BuildNode> build_bvh(const std::vector<Aabb>& boxes) {
   if (boxes.empty()) return {};
+  const BuildTuning& tn = BuildTuning::get();
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {          // HJ_BVH_VERBOSE: wall time of the compiler's stages
+    if (!tn.verbose) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "build_bvh: %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   Builder b(boxes);
   b.build(0, boxes.size());
-  const BuildTuning& tn = BuildTuning::get();
+  mark("binned SAH");
   const int rotate_passes = tn.rotate_passes;
   for (int p = 0; p < rotate_passes && b.nodes[0].shape < 0; p++) {
     Rotator r{b.nodes};
-    r.visit(0);
+    r.visit(0, b.nodes.size() > 400000 ? 4 : 0);
     if (tn.rotate_verbose) std::fprintf(stderr, "rotation pass %d: half-area gain %.4f\n", p, r.gain);
     if (r.gain <= 0) break;
   }
+  mark("rotation passes");
   // HJ_BVH_REINSERT = passes of the insertion-based optimisation (tree_opt.cpp)
   // (default: 3 passes up to 400 000 nodes; beyond that a pass over 1/16 of the nodes costs 1.5 s per 2 M nodes and no longer
   // lowers the node visits measurably, a pass over all of them +2 % frame rate for half a minute - tools/tree_probe.py)
@@ -337,8 +357,10 @@ std::vector<BuildNode> build_bvh(const std::vector<Aabb>& boxes) {
   // (large trees: the batched form - parallel searches, serial moves - over ALL nodes; the serial pass over a sixteenth of them that
   // round 5 tried there bought nothing, the serial pass over all of them +1 ... 3 % frame rate for 25 s: profiles/r05_c4_reinsert_all_nodes.txt)
   if (passes > 0) { if (large) optimize_by_reinsertion_batched(b.nodes, passes); else optimize_by_reinsertion(b.nodes, passes); }
+  mark("reinsertion");
   const int child_order = tn.child_order;
   if (child_order != 0) order_children(b.nodes, 0, std::min(child_order, 3));
+  mark("children by shape count");
   return std::move(b.nodes);
 }
 

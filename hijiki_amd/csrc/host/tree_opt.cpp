@@ -139,6 +139,36 @@ double optimize_by_reinsertion(std::vector<BuildNode>& nodes, int passes) {
   return t.sah();
 }
 
+namespace {
+// std::stable_sort over `parts` threads: the parts sorted side by side, then merged pairwise (std::inplace_merge keeps equal keys
+// in order): the same permutation as the serial call.
+template <class It, class Cmp>
+void stable_sort_parallel(It first, It last, Cmp cmp, unsigned parts) {
+  const size_t n = (size_t)(last - first);
+  if (parts < 2 || n < 65536) { std::stable_sort(first, last, cmp); return; }
+  std::vector<size_t> cut(parts + 1);
+  for (unsigned k = 0; k <= parts; k++) cut[k] = n * k / parts;
+  {
+    std::vector<std::thread> th;
+    try { for (unsigned k = 1; k < parts; k++) th.emplace_back([&, k] { std::stable_sort(first + (long)cut[k], first + (long)cut[k + 1], cmp); }); }
+    catch (const std::system_error&) {}
+    const unsigned started = (unsigned)th.size() + 1;
+    std::stable_sort(first, first + (long)cut[1], cmp);
+    for (unsigned k = started; k < parts; k++) std::stable_sort(first + (long)cut[k], first + (long)cut[k + 1], cmp);   // (threads that could not be started)
+    for (auto& t : th) t.join();
+  }
+  for (unsigned width = 1; width < parts; width *= 2) {
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k + width < parts; k += 2 * width) {
+      const size_t a = cut[k], m = cut[k + width], b = cut[std::min(parts, k + 2 * width)];
+      auto job = [=] { std::inplace_merge(first + (long)a, first + (long)m, first + (long)b, cmp); };
+      try { th.emplace_back(job); } catch (const std::system_error&) { job(); }
+    }
+    for (auto& t : th) t.join();
+  }
+}
+}  // namespace
+
 // The same optimisation for LARGE trees (beyond 400 000 nodes the serial pass over all nodes takes half a minute: round 5 ran none
 // there).  Candidates are taken in the same order, in batches: phase 1 - every candidate of a batch searches its best place on the
 // tree AS IT STANDS at the start of the batch, in parallel, read-only, with its own removal emulated on the fly (its parent P is
@@ -238,7 +268,7 @@ double optimize_by_reinsertion_batched(std::vector<BuildNode>& nodes, int passes
     }
     std::fill(touched.begin(), touched.end(), 0);
     for (size_t i = 0; i < count; i++) area[order[i]] = t.box[order[i]].half_area();      // (the sort's key, once per candidate instead of once per compare)
-    std::stable_sort(order.begin(), order.begin() + (long)count, [&](int32_t a, int32_t b) { return area[a] > area[b]; });
+    stable_sort_parallel(order.begin(), order.begin() + (long)count, [&](int32_t a, int32_t b) { return area[a] > area[b]; }, std::min(8u, hw));
     const long cap = BuildTuning::get().reinsert_max;
     const size_t limit = cap > 0 ? std::min<size_t>((size_t)cap, count) : count;
     size_t moved = 0, stale = 0;
