@@ -45,19 +45,26 @@ def fuzz_scene(r, rng):
         cs = host.Scene.synthetic(host.SYNTH_CBOX_MESH, mesh_triangles=int(rng.choice([2000, 20000]))).compile()
     else:
         cs = scenes.nasty_scene(int(rng.integers(0, 10000)))
+    on_device = False
     if rng.random() < 0.25 and cs.num_shapes >= 2:
-        cs.set_bvh(r.build_bvh(cs))
-    return kind, cs
+        if rng.random() < 0.5:                      # the tree STAYS on the device: hj_scene_upload takes it over (scene->bvh == NULL) ...
+            r.build_bvh(cs, keep_on_device=True)
+            cs.set_bvh(r.read_device_bvh())         # ... and the oracle walks the copy hj_bvh_device_read hands out
+            on_device = True
+        else:
+            cs.set_bvh(r.build_bvh(cs))
+    return kind, cs, on_device
 
 
 def fuzz_case(r, it, big=False):
     """Differential fuzz of hj_render_frame: random scene (random_scene / random_cluster_scene / nasty_scene - degenerate geometry
-    on purpose - / the synthetic box with a small mesh), compiled or device-built tree, random image size (not multiples of the
+    on purpose - / the synthetic box with a small mesh), compiled or device-built tree (handed over through the host or left on
+    the device), random image size (not multiples of the
     block size), samples per pixel, master seed, pass range, rank of a random world size, options (bounce limit, roulette start,
     batch size, light-shaft grid on / off, split kernels, static deal) - against the oracle's render of the same ImageBlocks with
     the same options, bit for bit, counters included.  Returns (ok, one line that reproduces and describes the case)."""
     rng = np.random.default_rng(90000 + it)
-    kind, cs = fuzz_scene(r, rng)
+    kind, cs, on_device = fuzz_scene(r, rng)
     W, H = int(rng.integers(16, 1700 if big else 420)), int(rng.integers(16, 1200 if big else 300))
     spp = int(rng.integers(1, 10 if big else 6))
     seed = int(rng.integers(0, 2 ** 40))
@@ -70,7 +77,7 @@ def fuzz_case(r, it, big=False):
     o.rr_start = int(rng.choice([1, 2, 4, 9]))
     o.batch_blocks = int(rng.choice([0, 0, 1, 3, 64]))
     o.flags = int(rng.choice([0, 0, 16, 2, 4]))                    # NO_LIGHT_GRID, SPLIT_KERNELS, STATIC_DEAL
-    r.upload_scene(cs)
+    r.upload_scene(cs, device_tree=on_device)
     r.create_framebuffer(W, H)
     st = r.render_frame(spp, seed, pass_begin=p0, pass_end=p1, rank=rank, world=world, opts=o)
     got = r.read()
@@ -90,7 +97,7 @@ def fuzz_case(r, it, big=False):
     bad = int((got.view(np.uint32) != want.view(np.uint32)).any(axis=-1).sum())
     ok = bad == 0 and st["closest_rays"] == ctr["closest_calls"] and st["shadow_rays"] == ctr["shadow_calls"] \
         and st["hits"] == ctr["hits"] and st["paths"] == ctr["paths"]
-    line = (f"{it}: {'ok ' if ok else 'FAIL'} kind {kind} {W}x{H} spp {spp} passes [{p0},{p1}) rank {rank}/{world} bounces {o.max_bounces} "
+    line = (f"{it}: {'ok ' if ok else 'FAIL'} kind {kind}{' (tree left on the device)' if on_device else ''} {W}x{H} spp {spp} passes [{p0},{p1}) rank {rank}/{world} bounces {o.max_bounces} "
             f"rr {o.rr_start} batch {o.batch_blocks} flags {o.flags} blocks {len(keep)} differing pixels {bad} paths {st['paths']} {ctr['paths']}")
     return ok, line
 
