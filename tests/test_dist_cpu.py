@@ -53,11 +53,12 @@ def _worker(rank, world, port, W, H, spp, seed, static, out_path):
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 4], ids=["2-ranks", "4-ranks"])
 @pytest.mark.parametrize("static", [False, True], ids=["rotating-deal", "static-deal"])
-def test_two_rank_tile_sharding_gloo(tmp_path, oracle, static):
+def test_two_rank_tile_sharding_gloo(tmp_path, oracle, static, world):
     import torch.multiprocessing as mp
     from hijiki_amd import host
-    W, H, spp, seed, world = 256, 256, 2, 5, 2
+    W, H, spp, seed = 256, 256, 2 if world == 2 else 4, 5
     out = str(tmp_path / "reduced.npy")
     mp.spawn(_worker, args=(world, _free_port(), W, H, spp, seed, static, out), nprocs=world, join=True)
     reduced = np.load(out)
