@@ -348,14 +348,13 @@ std::vector<BuildNode> build_bvh(const std::vector<Aabb>& boxes) {
     if (r.gain <= 0) break;
   }
   mark("rotation passes");
-  // HJ_BVH_REINSERT = passes of the insertion-based optimisation (tree_opt.cpp)
-  // (default: 3 passes up to 400 000 nodes; beyond that a pass over 1/16 of the nodes costs 1.5 s per 2 M nodes and no longer
-  // lowers the node visits measurably, a pass over all of them +2 % frame rate for half a minute - tools/tree_probe.py)
+  // Insertion-based optimisation (tree_opt.cpp).  HJ_BVH_REINSERT = passes, whatever the size; by default 3 serial passes over all
+  // nodes up to 400 000 nodes and HJ_BVH_REINSERT_LARGE (6) batched passes beyond: parallel searches, serial moves, the later passes
+  // from a work list - 1 M triangles: oracle node visits per ray -6.4 %, c4 +4 ... 5 %, 1 s on 16 cores (round 5 ran none there: its
+  // serial pass over a sixteenth of the nodes bought nothing, over all of them +1 ... 3 % for 25 s).
   const int reinsert_passes = tn.reinsert_passes;
   const bool large = b.nodes.size() > 400000;
   const int passes = reinsert_passes >= 0 ? reinsert_passes : (large ? tn.reinsert_large : 3);
-  // (large trees: the batched form - parallel searches, serial moves - over ALL nodes; the serial pass over a sixteenth of them that
-  // round 5 tried there bought nothing, the serial pass over all of them +1 ... 3 % frame rate for 25 s: profiles/r05_c4_reinsert_all_nodes.txt)
   if (passes > 0) { if (large) optimize_by_reinsertion_batched(b.nodes, passes); else optimize_by_reinsertion(b.nodes, passes); }
   mark("reinsertion");
   const int child_order = tn.child_order;
