@@ -29,7 +29,7 @@ def main():
     rays = cc + sc
     print(f"{name} compile {tc:.2f}s  closest: nodes/ray {c['nodes'] / cc:.2f} tri {c['tri_tests'] / cc:.3f} | shadow(any-hit): nodes/ray "
           f"{c['shadow_nodes'] / sc:.2f} tri {c['shadow_tri_tests'] / sc:.3f} | all rays: nodes {(c['nodes'] + c['shadow_nodes']) / rays:.2f} "
-          f"tri {(c['tri_tests'] + c['shadow_tri_tests']) / rays:.3f}  occluded {c['shadow_hits'] / sc:.3f}")
+          f"tri {(c['tri_tests'] + c['shadow_tri_tests']) / rays:.3f} sphere {(c['sphere_tests'] + c['shadow_sphere_tests']) / rays:.3f}  occluded {c['shadow_hits'] / sc:.3f}")
 
 
 if __name__ == "__main__":
