@@ -129,8 +129,10 @@ def main_inproc(args, cfg):
     for _ in range(args.warmup):
         step()
     t0 = time.perf_counter()
+    per = [[0.0, 0.0, 0, 0] for _ in rs]                # per context: host time of its frames, exclusive GPU time of its path kernels, paths, rays
     for _ in range(args.steps):
-        step()
+        for i, st in enumerate(step()):
+            per[i][0] += st["total_ms"]; per[i][1] += st["path_busy_ms"]; per[i][2] += st["paths"]; per[i][3] += st["closest_rays"] + st["shadow_rays"]
     elapsed = time.perf_counter() - t0                   # comm.reduce returns after every stream has been synchronised
     paths = W * H * spp * args.steps
     out = {"metric": f"Mrays/s (camera paths/s) at {spp}spp, {cfg['short']} {W}x{H}", "value": round(paths / elapsed / 1e6, 3),
@@ -140,6 +142,15 @@ def main_inproc(args, cfg):
            "config": {"workload": f"{args.config}: {cfg['name'].format(W=W, H=H, spp=spp)}, BVH, block 128, seed {args.seed}",
                       "partition": f"ImageBlock (bx, by) of pass p -> GPU (bx + by + p) mod {n}; one process, hj_render_frame_async per "
                                    f"context, hj_comm_reduce_framebuffers (RCCL sum of the {W}x{H} RGBA32F framebuffers)"}}
+    # the same self-explaining fields as the one-process-per-GPU line (per step): a context's frame time as its worker thread saw it, its
+    # path kernels' exclusive GPU time, what it was dealt; reduce_ms = what a step takes beyond the slowest context's frame (join + RCCL sum)
+    k = 1.0 / args.steps
+    busy = [p[1] * k for p in per]
+    out["deal"] = "rotating"
+    out["per_rank"] = {"render_ms": [round(p[0] * k, 3) for p in per], "kernel_busy_ms": [round(b, 3) for b in busy],
+                       "paths": [int(p[2]) for p in per], "rays": [int(p[3]) for p in per], "unit": "ms per step (frame)"}
+    out["imbalance"] = None if sum(busy) <= 0 else round(max(busy) / (sum(busy) / len(busy)), 4)
+    out["reduce_ms"] = round(max(0.0, 1e3 * elapsed * k - max(p[0] for p in per) * k), 3)
     print(json.dumps(out), flush=True)
     comm.close()
     for r in rs:

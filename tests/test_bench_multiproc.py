@@ -127,3 +127,6 @@ def test_bench_eight_way_deal_in_one_process(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and "mod 8" in out["config"]["partition"] and "c5:" in out["config"]["workload"]
     assert "4096x4096 8spp" in out["config"]["workload"] and out["value"] > 0 and out["scaling"] == "strong"
+    pr = out["per_rank"]
+    assert len(pr["render_ms"]) == len(pr["kernel_busy_ms"]) == len(pr["paths"]) == 8 and sum(pr["paths"]) == 4096 * 4096 * 8
+    assert min(pr["paths"]) > 0.8 * max(pr["paths"]) and out["imbalance"] >= 1.0 and out["reduce_ms"] >= 0 and out["deal"] == "rotating"
