@@ -40,6 +40,7 @@ struct Tuning {
   X(inner_burst, "HJ_INNER_BURST", kUnset, 1, 1 << 20)     /* box steps per round of the walk loop: 6 (8 on large trees) */            \
   X(refill_min, "HJ_REFILL_MIN", kUnset, 1, 64)            /* idle lanes that trigger a refill: 24 (32) */                              \
   X(light_grid, "HJ_LIGHT_GRID", kUnset, 0, 256)           /* cells per axis of the light-shaft grid: 64, none on large trees */        \
+  X(light_grid_mesh, "HJ_LIGHT_GRID_MESH", 1, 0, 1)        /* also cells on meshes and in corners (flat shapes, not coplanar): bundle proofs */ \
   /* multi-GPU test rigs */                                                                                                            \
   X(comm_shared_gpu, "HJ_COMM_SHARED_GPU", 0, 0, 1)        /* several contexts of a communicator on one GPU (kernel sum) */             \
   X(comm_force_rccl, "HJ_COMM_FORCE_RCCL", 0, 0, 1)        /* RCCL also for a one-rank communicator */                                  \

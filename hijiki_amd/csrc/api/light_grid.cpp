@@ -135,6 +135,13 @@ struct Geometry {
     p.ok = true;
     return p;
   }
+  int polygon(size_t shape, double v[8][3]) const {            // the corners in cyclic order (a quad: origin, +e1, +e1+e2, +e2); 0 for a sphere
+    double q[4][3];
+    const int n = vertices(shape, q);
+    static const int quad_order[4] = {0, 1, 3, 2};
+    for (int c = 0; c < n; c++) for (int k = 0; k < 3; k++) v[c][k] = q[n == 4 ? quad_order[c] : c][k];
+    return n;
+  }
   bool coplanar(size_t shape, const Plane& p, double tol) const {
     double v[4][3];
     const int n = vertices(shape, v);
@@ -205,6 +212,129 @@ struct Shaft {
     return false;
   }
 };
+
+// ---- cells on MESHES (round 6; HJ_LIGHT_GRID_MESH) -------------------------------------------------------------------------------
+// A cell whose shapes are flat (triangles, quads) but not coplanar.  A hit point p of such a cell lies on one of its shapes T;
+// emitter e is a flat polygon E.  For one flat shape B that touches the shaft, `bundle_misses` proves that NO shadow ray from a
+// point of T to a point of E can be a hit of B for the reference's test - with B's plane oriented so that E lies on its positive
+// side (E on both sides: nothing is proven), f = signed distance to that plane, sin >= h_E / d_max the least sine at which any ray
+// of the bundle meets the plane:
+//   A.  every point of T has f >= tau_pos: the ray starts above B's plane and climbs: it never meets the plane (in float the
+//       reference's t comes out negative, or beyond tMax when d.n rounds the wrong way: tau_pos / rounding > the shaft's length);
+//   B.  sin >= 0.25 (as for planar cells) and every point of T has f >= -f0, f0 = half of tMin x sin: the ray meets the plane before
+//       tMin / 2, far enough below tMin = 2e-4 (scene.glsl:85) for the rounding of t;
+//   C.  otherwise the part of T below -f0 is cut out (a convex polygon), and every segment from one of its corners to a corner of E
+//       is cut with B's plane: the convex hull of those points holds every point where a ray of the bundle can meet the plane
+//       (the crossing point is a projective image of the segment's ends, and the hull of T- and E is spanned by those segments);
+//       in the plane's own 2-D frame that hull has to stay clear of B by kappa - a separating axis among the edges of both
+//       polygons - which is two orders of magnitude above what rounding does to the reference's (u, v).
+// Everything errs towards "not proven".  T itself is one of the B's (f = 0: case B: the emitter must be seen steeply from T's
+// own plane, which is condition 2 of the planar cells).
+struct Poly { double v[8][3]; int n; };
+
+inline int clip_below(const Poly& in, const double nrm[3], double d, double off, Poly& out) {   // the part with n.x - d <= off
+  out.n = 0;
+  for (int i = 0; i < in.n; i++) {
+    const double* a = in.v[i];
+    const double* b = in.v[(i + 1) % in.n];
+    const double fa = nrm[0] * a[0] + nrm[1] * a[1] + nrm[2] * a[2] - d - off, fb = nrm[0] * b[0] + nrm[1] * b[1] + nrm[2] * b[2] - d - off;
+    if (fa <= 0 && out.n < 8) { for (int k = 0; k < 3; k++) out.v[out.n][k] = a[k]; out.n++; }
+    if ((fa < 0) != (fb < 0) && fa != fb && out.n < 8) {
+      const double t = fa / (fa - fb);
+      for (int k = 0; k < 3; k++) out.v[out.n][k] = a[k] + t * (b[k] - a[k]);
+      out.n++;
+    }
+  }
+  return out.n;
+}
+
+// 2-D: is the convex hull of pts (n points) further than `margin` from the convex polygon q (m corners, in order)?
+inline bool hull_clear_of_polygon(const double (*pts)[2], int n, const double (*q)[2], int m, double margin) {
+  if (n == 0) return true;
+  // monotone chain
+  int idx[64];
+  for (int i = 0; i < n; i++) idx[i] = i;
+  std::sort(idx, idx + n, [&](int a, int b) { return pts[a][0] < pts[b][0] || (pts[a][0] == pts[b][0] && pts[a][1] < pts[b][1]); });
+  auto crs = [&](int o, int a, int b) { return (pts[a][0] - pts[o][0]) * (pts[b][1] - pts[o][1]) - (pts[a][1] - pts[o][1]) * (pts[b][0] - pts[o][0]); };
+  int hull[130], h = 0;
+  for (int i = 0; i < n; i++) { while (h >= 2 && crs(hull[h - 2], hull[h - 1], idx[i]) <= 0) h--; hull[h++] = idx[i]; }
+  for (int i = n - 2, lower = h + 1; i >= 0; i--) { while (h >= lower && crs(hull[h - 2], hull[h - 1], idx[i]) <= 0) h--; hull[h++] = idx[i]; }
+  if (h > 1) h--;                                                   // (the first point again)
+  auto separates = [&](double ax, double ay) {
+    const double l = std::sqrt(ax * ax + ay * ay);
+    if (!(l > 0)) return false;
+    ax /= l; ay /= l;
+    double a0 = INFINITY, a1 = -INFINITY, b0 = INFINITY, b1 = -INFINITY;
+    for (int i = 0; i < n; i++) { const double t = pts[i][0] * ax + pts[i][1] * ay; a0 = std::min(a0, t); a1 = std::max(a1, t); }
+    for (int i = 0; i < m; i++) { const double t = q[i][0] * ax + q[i][1] * ay; b0 = std::min(b0, t); b1 = std::max(b1, t); }
+    return a0 > b1 + margin || b0 > a1 + margin;
+  };
+  for (int i = 0; i < m; i++) { const double* a = q[i]; const double* b = q[(i + 1) % m]; if (separates(-(b[1] - a[1]), b[0] - a[0])) return true; }
+  for (int i = 0; i < h; i++) {
+    const double* a = pts[hull[i]];
+    const double* b = pts[hull[(i + 1) % h]];
+    if (separates(-(b[1] - a[1]), b[0] - a[0])) return true;
+  }
+  return false;
+}
+
+struct BundleTol { double tol_in, tau_pos, kappa, sin_cell, t_min; };
+
+// B's plane as the bundle of rays towards E sees it: oriented so that E lies on its positive side, the least sine at which a ray
+// of the bundle meets it, and f0 (case B's threshold) - computed once per (B, E, cell), used for every T of the cell.
+struct BundleSide { double nrm[3], d, f0; bool usable, steep; };
+inline BundleSide bundle_side(const Poly& E, const Plane& bp, double dmax, const BundleTol& tl) {
+  BundleSide r{};
+  double fe_min = INFINITY, fe_max = -INFINITY;
+  for (int i = 0; i < E.n; i++) { const double f = bp.n[0] * E.v[i][0] + bp.n[1] * E.v[i][1] + bp.n[2] * E.v[i][2] - bp.d; fe_min = std::min(fe_min, f); fe_max = std::max(fe_max, f); }
+  double sgn;
+  if (fe_min > tl.tau_pos) sgn = 1.0; else if (fe_max < -tl.tau_pos) sgn = -1.0; else return r;          // E on both sides of (or in) B's plane: nothing is proven
+  r.usable = true;
+  for (int k = 0; k < 3; k++) r.nrm[k] = sgn * bp.n[k];
+  r.d = sgn * bp.d;
+  const double sin_min = (sgn > 0 ? fe_min : -fe_max) / dmax;
+  // a hit point with f >= -(tMin / 2) sin meets the plane before tMin / 2; the points of T whose hit points all satisfy that: f >= -f0
+  r.f0 = 0.5 * tl.t_min * std::min(sin_min, 1.0) - tl.tol_in;
+  r.steep = sin_min >= tl.sin_cell && r.f0 > 0;
+  return r;
+}
+
+// true: no ray from a point of T (within tol_in of it) to a point of E can be a hit of B
+inline bool bundle_misses(const Poly& T, const Poly& E, const Poly& B, const BundleSide& bs, const BundleTol& tl) {
+  if (!bs.usable) return false;
+  const double* nrm = bs.nrm;
+  const double d = bs.d, f0 = bs.f0;
+  double f_min = INFINITY;                                                                                // over T itself; a hit point: tol_in lower at most
+  for (int i = 0; i < T.n; i++) f_min = std::min(f_min, nrm[0] * T.v[i][0] + nrm[1] * T.v[i][1] + nrm[2] * T.v[i][2] - d);
+  if (f_min - tl.tol_in >= tl.tau_pos) return true;                                                       // A
+  if (!bs.steep) return false;
+  if (f_min >= -f0) return true;                                                                          // B
+  Poly below;                                                                                             // C
+  if (clip_below(T, nrm, d, -f0, below) == 0) return true;
+  double pts[64][2], q[8][2];
+  // a 2-D frame in B's plane
+  double ax[3] = {std::fabs(nrm[0]) < 0.9 ? 1.0 : 0.0, std::fabs(nrm[0]) < 0.9 ? 0.0 : 1.0, 0.0};
+  double u[3] = {nrm[1] * ax[2] - nrm[2] * ax[1], nrm[2] * ax[0] - nrm[0] * ax[2], nrm[0] * ax[1] - nrm[1] * ax[0]};
+  const double ul = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+  for (int k = 0; k < 3; k++) u[k] /= ul;
+  const double w[3] = {nrm[1] * u[2] - nrm[2] * u[1], nrm[2] * u[0] - nrm[0] * u[2], nrm[0] * u[1] - nrm[1] * u[0]};
+  int np = 0;
+  for (int i = 0; i < below.n; i++) {
+    const double fa = nrm[0] * below.v[i][0] + nrm[1] * below.v[i][1] + nrm[2] * below.v[i][2] - d;
+    for (int j = 0; j < E.n; j++) {
+      const double fb = nrm[0] * E.v[j][0] + nrm[1] * E.v[j][1] + nrm[2] * E.v[j][2] - d;
+      if (!(fa < 0 && fb > 0)) return false;
+      const double t = fa / (fa - fb);
+      double x[3];
+      for (int k = 0; k < 3; k++) x[k] = below.v[i][k] + t * (E.v[j][k] - below.v[i][k]);
+      if (np >= 64) return false;
+      pts[np][0] = x[0] * u[0] + x[1] * u[1] + x[2] * u[2]; pts[np][1] = x[0] * w[0] + x[1] * w[1] + x[2] * w[2];
+      np++;
+    }
+  }
+  for (int i = 0; i < B.n; i++) { q[i][0] = B.v[i][0] * u[0] + B.v[i][1] * u[1] + B.v[i][2] * u[2]; q[i][1] = B.v[i][0] * w[0] + B.v[i][1] * w[1] + B.v[i][2] * w[2]; }
+  return hull_clear_of_polygon(pts, np, q, B.n, tl.kappa);
+}
 
 }  // namespace
 
@@ -343,6 +473,15 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
   // the shapes that reach into it: the same grid whatever the thread count.
   std::vector<uint32_t> first(ncell, 0xFFFFFFFFu);
   std::vector<uint8_t> bad(ncell, 0);
+  // cells on meshes (HJ_LIGHT_GRID_MESH): a cell that is not planar can still be proven when everything in it is FLAT - `hard` marks
+  // the cells that hold a sphere or a shape without a usable plane; `flat_ok` per shape.  Scenes of more than 200 000 shapes: not tried.
+  const bool mesh_cells = Tuning::from_env().light_grid_mesh != 0 && shapes <= 200000;
+  std::vector<uint8_t> hard(mesh_cells ? ncell : 0, 0), flat_ok(mesh_cells ? shapes : 0, 0);
+  struct Flat { Plane pl; Poly poly; };
+  std::vector<Flat> flat(mesh_cells ? shapes : 0);                 // plane and corners of every flat shape, once
+  if (mesh_cells) parallel_pieces(shapes, 65536, [&](size_t a, size_t b, unsigned) {
+    for (size_t i = a; i < b; i++) { flat[i].pl = g.plane(i); flat[i].poly.n = g.polygon(i, flat[i].poly.v); flat_ok[i] = flat[i].pl.ok && flat[i].poly.n >= 3 ? 1 : 0; }
+  });
   auto cell_range = [&](const Box& b, int lo[3], int hi[3]) {
     for (int k = 0; k < 3; k++) {
       lo[k] = std::max(0, (int)std::floor((b.lo[k] - gb.lo[k]) / cell[k]));
@@ -370,6 +509,7 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
       bool have_pi = false;
       for (size_t z = std::max<size_t>(r.lo[2], z0); z <= r.hi[2] && z < z1; z++) for (int y = r.lo[1]; y <= r.hi[1]; y++) for (int x = r.lo[0]; x <= r.hi[0]; x++) {
         const size_t c = (z * res + (size_t)y) * res + (size_t)x;
+        if (mesh_cells && !flat_ok[i]) hard[c] = 1;
         if (bad[c]) continue;
         if (first[c] == 0xFFFFFFFFu) {
           first[c] = (uint32_t)i;
@@ -420,6 +560,30 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
   std::vector<uint32_t> work;                              // cells that hold a planar surface
   for (size_t c = 0; c < ncell; c++) { if (first[c] != 0xFFFFFFFFu) out.cells_surface++; if (first[c] != 0xFFFFFFFFu && !bad[c]) work.push_back((uint32_t)c); }
   out.cells_planar = work.size();
+  // mesh cells and their shapes (in shape order: the same lists whatever the thread count)
+  const size_t planar_cells = work.size();
+  std::vector<uint32_t> cell_first(mesh_cells ? ncell + 1 : 0, 0), cell_shapes;
+  if (mesh_cells) {
+    for (size_t c = 0; c < ncell; c++) if (first[c] != 0xFFFFFFFFu && bad[c] && !hard[c]) work.push_back((uint32_t)c);
+    auto each_cell = [&](size_t i, auto fn) {
+      const Range& r = range[i];
+      if (r.lo[2] > r.hi[2]) return;
+      for (size_t z = r.lo[2]; z <= r.hi[2]; z++) for (int y = r.lo[1]; y <= r.hi[1]; y++) for (int x = r.lo[0]; x <= r.hi[0]; x++) {
+        const size_t c = (z * res + (size_t)y) * res + (size_t)x;
+        if (first[c] != 0xFFFFFFFFu && bad[c] && !hard[c]) fn(c);
+      }
+    };
+    for (size_t i = 0; i < shapes; i++) each_cell(i, [&](size_t c) { cell_first[c + 1]++; });
+    for (size_t c = 0; c < ncell; c++) cell_first[c + 1] += cell_first[c];
+    cell_shapes.resize(cell_first[ncell]);
+    std::vector<uint32_t> fill(cell_first.begin(), cell_first.end() - 1);
+    for (size_t i = 0; i < shapes; i++) each_cell(i, [&](size_t c) { cell_shapes[fill[c]++] = (uint32_t)i; });
+  }
+  // kappa: how far a computed crossing point - and the reference's own (u, v) test - can be off in B's plane: the hit point's tol_p
+  // carried along a ray that meets the plane at sin >= 0.25, plus the rounding of (u, v) (3 ulp x |ro| / sin, |ro| <= the scene's diagonal,
+  // taken sixteen-fold), times 1.5
+  const double kappa = 1.5 * ((tol_p + tol_s) / kSinCell + 16.0 * 5.97e-8 * (scene_diag + scene_maxabs) / kSinCell);
+  const BundleTol btol{tol_p + tol_s, 1e-5 * std::max(1.0, scale), kappa, kSinCell, kTMin};
 
   std::atomic<size_t> next{0}, clear{0};
   auto run = [&] {
@@ -432,9 +596,54 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
         Box cb;
         const int xyz[3] = {x, y, z};
         for (int k = 0; k < 3; k++) { cb.lo[k] = gb.lo[k] + xyz[k] * cell[k] - m; cb.hi[k] = gb.lo[k] + (xyz[k] + 1) * cell[k] + m; }
-        const Plane P = g.plane(first[c]);
+        const bool on_mesh = wi >= planar_cells;
+
+        const Plane P = on_mesh ? Plane{} : g.plane(first[c]);
         uint8_t bits = 0;
-        for (size_t e = 0; e < ems.size(); e++) {
+        for (size_t e = 0; e < ems.size() && on_mesh; e++) {
+          // A cell on a mesh: the emitter side as for a planar cell; then every flat shape that touches the shaft - the cell's own
+          // shapes among them - must be missed by the whole bundle of rays from EVERY shape of the cell to the emitter (bundle_misses)
+          const Em& em = ems[e];
+          if (!em.ok) continue;
+          double dmax = 0;
+          { double d2 = 0; for (int k = 0; k < 3; k++) { const double a = std::max(std::fabs(em.box.hi[k] - cb.lo[k]), std::fabs(cb.hi[k] - em.box.lo[k])); d2 += a * a; } dmax = std::sqrt(d2); }
+          double lo_d = -em.q.d, hi_d = -em.q.d;
+          for (int k = 0; k < 3; k++) { lo_d += em.q.n[k] * (em.q.n[k] > 0 ? cb.lo[k] : cb.hi[k]); hi_d += em.q.n[k] * (em.q.n[k] > 0 ? cb.hi[k] : cb.lo[k]); }
+          const double near_q = lo_d > 0 ? lo_d : (hi_d < 0 ? -hi_d : 0.0);
+          if (!(near_q - std::max(tol_s, em.slack) >= em.sin_min * dmax)) continue;
+          const Poly& E = flat[em.shape].poly;
+          if (E.n < 3) continue;
+          bool blocked = false;
+          // the cell's own shapes first (they touch the shaft by construction and fail most often: a facet that faces away from the
+          // light, a light seen at a grazing angle): most unprovable cells end here, before the tree is walked
+          for (uint32_t b = cell_first[c]; b < cell_first[c + 1] && !blocked; b++) {
+            const uint32_t shp = cell_shapes[b];
+            if (g.coplanar(shp, em.q, tol_s)) continue;
+            const BundleSide bs = bundle_side(E, flat[shp].pl, dmax, btol);
+            for (uint32_t k = cell_first[c]; k < cell_first[c + 1] && !blocked; k++)
+              if (!bundle_misses(flat[cell_shapes[k]].poly, E, flat[shp].poly, bs, btol)) blocked = true;
+          }
+          if (blocked) continue;
+          const Shaft sh(cb, em.box);
+          for (size_t i = 0; i < N && !blocked;) {
+            const hj_bvh_node& nd = s->bvh[i];
+            if (sh.outside(pad(widen(sub[i]), m))) { i = std::min<size_t>(nd.exit_index, N); continue; }
+            if (nd.shape_index != HJ_BVH_INNER) {
+              const size_t shp = nd.shape_index;
+              if (shp < g.ns) { blocked = true; break; }                         // (a sphere near a mesh cell's shaft: not tried)
+              if (!g.coplanar(shp, em.q, tol_s)) {                               // (shapes in the emitter's plane: the emitter-side argument)
+                if (!flat_ok[shp]) { blocked = true; break; }
+                // (the cell's shapes as they are: cut to the cell they prove 5 % more cells and no more rays)
+                const BundleSide bs = bundle_side(E, flat[shp].pl, dmax, btol);
+                for (uint32_t k = cell_first[c]; k < cell_first[c + 1] && !blocked; k++)
+                  if (!bundle_misses(flat[cell_shapes[k]].poly, E, flat[shp].poly, bs, btol)) blocked = true;
+              }
+            }
+            i++;
+          }
+          if (!blocked) { bits |= (uint8_t)(1u << e); clear.fetch_add(1, std::memory_order_relaxed); }
+        }
+        for (size_t e = 0; e < ems.size() && !on_mesh; e++) {
           const Em& em = ems[e];
           if (!em.ok) continue;
           // 2. angles: the emitter's padded box on one side of P, steeply; the padded cell on one side of Q, not grazing
@@ -485,6 +694,7 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
   run();
   for (auto& t : pool) t.join();
   mark("shafts");
+  if (timing) std::fprintf(stderr, "light grid: %zu planar cells, %zu cells on meshes\n", planar_cells, work.size() - planar_cells);
   out.pairs_clear = clear.load();
   if (out.pairs_clear == 0) { out = LightGrid{}; return false; }
   return true;

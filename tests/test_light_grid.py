@@ -86,13 +86,38 @@ def emitter_points(cs, e_shape, rng, n):
     return (o + e1 * u[:, None] + e2 * v[:, None]).astype(np.float32)
 
 
-def attack(cs, oracle, rng, n=60000, res=RES):
+def shape_points(cs, rng, per_shape):
+    """per_shape points on EVERY flat shape (uniform per shape, not by area: the small triangles of a mesh count as much as the
+    walls), a hair across the edges (a hit point is accepted by a float test), with the shape's unit normal."""
+    tri, pos, quad, _, ns, nq = scene_arrays(cs)
+    pts, nrm = [], []
+    if len(tri):
+        t = np.repeat(tri, per_shape, axis=0)
+        a, b, c = pos[t[:, 0]], pos[t[:, 1]], pos[t[:, 2]]
+        u, v = rng.uniform(-2e-6, 1 + 2e-6, (2, len(t)))
+        f = u + v > 1
+        u, v = np.where(f, 1 - u, u), np.where(f, 1 - v, v)
+        pts.append(a + (b - a) * u[:, None] + (c - a) * v[:, None])
+        nrm.append(np.cross(b - a, c - a))
+    if len(quad):
+        q = np.repeat(quad, per_shape * 4, axis=0)
+        o, e1, e2 = q[:, 0:3], q[:, 4:7], q[:, 8:11]
+        u, v = rng.uniform(-2e-6, 1 + 2e-6, (2, len(q)))
+        pts.append(o + e1 * u[:, None] + e2 * v[:, None])
+        nrm.append(np.cross(e1, e2))
+    p, m = np.concatenate(pts), np.concatenate(nrm)
+    ln = np.linalg.norm(m, axis=1)
+    keep = ln > 0
+    return p[keep], m[keep] / ln[keep, None]
+
+
+def attack(cs, oracle, rng, n=60000, res=RES, per_shape=0):
     """Number of shadow rays tried from cells whose bit is set, and how many the oracle found occluded (must be 0)."""
     got, bits, lo, inv, st = build_grid(cs, res)
     if got == 0:
         return 0, 0, st
     _, _, _, em, _, _ = scene_arrays(cs)
-    p, nrm = planar_points(cs, rng, n)
+    p, nrm = shape_points(cs, rng, per_shape) if per_shape else planar_points(cs, rng, n)
     # a computed hit point is not exactly on its shape: move it by up to +-1e-5 along the normal (the grid allows 2e-6 x scale)
     p = (p + nrm * rng.uniform(-1e-5, 1e-5, (len(p), 1))).astype(np.float32)
     f = (p - lo) * inv
@@ -210,3 +235,61 @@ def test_grid_against_the_oracles_own_shadow_rays(name):
     assert not (proven & occluded).any(), (name, int((proven & occluded).sum()), sh[proven & occluded][:3])
     if name in ("cbox", "cbox + spheres"):
         assert proven.mean() > 0.5                                        # (not vacuous: most of the box scenes' shadow rays are proven)
+
+
+@pytest.mark.parametrize("kind,tris", [(host.SYNTH_CBOX, 1280), (host.SYNTH_CBOX, 6320), (host.SYNTH_CBOX_SPHERES, 6320), (host.SYNTH_CBOX_MESH, 6000)])
+def test_cells_on_meshes_and_in_corners(oracle, kind, tris, monkeypatch):
+    """Round 6: a cell whose shapes are flat but NOT coplanar - the facets of a mesh, the corner of two walls - is proven when the
+    whole bundle of rays from every shape of the cell to the emitter misses every flat shape that touches the shaft
+    (api/light_grid.cpp bundle_misses).  More (cell, emitter) pairs than without (HJ_LIGHT_GRID_MESH=0), and not one crafted ray -
+    points on EVERY shape, uniform per shape, off their planes by +-1e-5, towards corners, edges and random points of the light -
+    that the oracle finds occluded."""
+    cs = host.Scene.synthetic(kind, mesh_triangles=tris).compile()
+    monkeypatch.setenv("HJ_LIGHT_GRID_MESH", "0")
+    _, bits0, _, _, st0 = build_grid(cs)
+    monkeypatch.setenv("HJ_LIGHT_GRID_MESH", "1")
+    got, bits1, _, _, st1 = build_grid(cs)
+    assert got == RES and st1[2] > st0[2] and ((bits1 & bits0) == bits0).all()          # nothing that was proven is lost
+    rng = np.random.default_rng(tris)
+    tried, bad, _ = attack(cs, oracle, rng, per_shape=12 if tris > 2000 else 60)
+    assert tried > (50 if kind == host.SYNTH_CBOX_MESH else 1000) and bad == 0, (tried, bad)      # (the dense mesh's own cells are rarely provable)
+
+
+def test_a_mesh_cell_under_an_occluder_is_not_proven(oracle):
+    """A shallow faceted dome on the floor under the light (a 6 x 6 height field, neighbouring facets a few degrees apart): the cells
+    on it are proven - also those that hold a vertex where six facets meet; with a small quad hung between dome and light the cells
+    under it are not (the quad touches their shafts and the bundle's crossing points reach it).  Creases sharper than the
+    tolerances allow (tens of degrees) stay unproven by design."""
+    def scene(with_occluder):
+        s = host.Scene()
+        s.set_camera_cbox()
+        white, lamp = s.add_diffuse((0.7, 0.7, 0.7)), s.add_emissive((10, 10, 10))
+        s.add_quad((-1, 0, 1), (2, 0, 0), (0, 0, -2), white)
+        s.add_quad((-0.25, 1.58, 0.2), (0.5, 0, 0), (0, 0, -0.4), lamp)
+        n = 7
+        xs = np.linspace(-0.3, 0.3, n)
+        pos = np.array([(x, 0.2 - 0.25 * (x * x + z * z), z) for z in xs for x in xs], np.float32)
+        v0 = s.add_vertices(pos, np.tile(np.array([[0, 1, 0]], np.float32), (n * n, 1)), np.zeros((n * n, 2), np.float32))
+        for j in range(n - 1):
+            for i in range(n - 1):
+                a, b, c, d = v0 + j * n + i, v0 + j * n + i + 1, v0 + (j + 1) * n + i, v0 + (j + 1) * n + i + 1
+                s.add_triangle(a, c, b, white)
+                s.add_triangle(b, c, d, white)
+        if with_occluder:
+            s.add_quad((-0.06, 0.8, 0.06), (0.12, 0, 0), (0, 0, -0.12), white)
+        return s.compile()
+    free, blocked = scene(False), scene(True)
+    got, bits, lo, inv, st = build_grid(free)
+    got2, bits2, lo2, inv2, st2 = build_grid(blocked)
+    assert got == RES and got2 == RES
+    def cell_of(p, lo_, inv_):
+        c = ((np.array(p, np.float32) - lo_) * inv_).astype(np.int64)
+        return (c[2] * RES + c[1]) * RES + c[0]
+    apex = (0.0, 0.2 - 1e-5, 0.0)                                   # the middle vertex: six facets in one cell
+    assert bits[cell_of(apex, lo, inv)] & 1
+    assert not (bits2[cell_of(apex, lo2, inv2)] & 1)
+    assert st2[2] < st[2]
+    rng = np.random.default_rng(5)
+    for cs in (free, blocked):
+        tried, bad, _ = attack(cs, oracle, rng, per_shape=300)
+        assert tried > 1000 and bad == 0
