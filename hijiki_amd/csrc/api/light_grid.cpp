@@ -28,6 +28,7 @@
 // looked at, in any well- or ill-formed array whose exits point forward.  Shapes the array does not hold cannot be hit.
 #include "light_grid.hpp"
 #include "hj_tuning.h"
+#include "../kernels/hj_light_grid_const.h"
 
 #include <algorithm>
 #include <atomic>
@@ -49,7 +50,10 @@ inline void join(Box& b, const Box& o) { for (int k = 0; k < 3; k++) { b.lo[k] =
 inline Box pad(Box b, double m) { for (int k = 0; k < 3; k++) { b.lo[k] -= m; b.hi[k] += m; } return b; }
 inline bool finite_box(const Box& b) { for (int k = 0; k < 3; k++) if (!(std::isfinite(b.lo[k]) && std::isfinite(b.hi[k]) && b.lo[k] <= b.hi[k])) return false; return true; }
 
-struct Plane { double n[3], d; bool ok; };        // n.x - d = signed distance, |n| = 1
+// n.x - d = signed distance, |n| = 1; cond = 1 / sin of the angle between the two edges the reference's test takes its normal
+// from (triangle.glsl / quad.glsl: cross(b - a, c - a), cross(e1, e2)) - what that float cross product's direction, and with it
+// every t and (u, v) the test computes, loses to cancellation (a needle: cond >> 1)
+struct Plane { double n[3], d, cond; bool ok; };
 
 // Bounds as the scene's own floats (min / max of float coordinates are exact): half the memory of the double boxes in the two
 // passes over a million shapes and two million nodes.
@@ -132,6 +136,7 @@ struct Geometry {
     if (!(l > 1e-9 * la * lb) || !std::isfinite(l) || l == 0.0) return p;        // (needle triangles have no usable plane)
     for (int k = 0; k < 3; k++) p.n[k] = n[k] / l;
     p.d = p.n[0] * v[0][0] + p.n[1] * v[0][1] + p.n[2] * v[0][2];
+    p.cond = la * lb / l;
     p.ok = true;
     return p;
   }
@@ -230,6 +235,12 @@ struct Shaft {
 //       polygons - which is two orders of magnitude above what rounding does to the reference's (u, v).
 // Everything errs towards "not proven".  T itself is one of the B's (f = 0: case B: the emitter must be seen steeply from T's
 // own plane, which is condition 2 of the planar cells).
+// Where the hit point is: o + t d with the float t of T's test.  Off T's PLANE it is tol_p x cond(T) at most, but ALONG the ray t is
+// wrong by about (6 + 4 cond) ulp x |ro| / |cos(d, n)|, so a hit at a grazing angle leaves the point off T sideways by any amount,
+// and the float (u, v) test lets rays pass that miss T's edge by as much.  The shade stage therefore uses these proofs only after it
+// has CHECKED the hit point against T (kernels/hj_light_grid_const.h; the records come from here: shape_recs): then it is within
+// sigma = 5e-6 of T, in any direction, and that is what "a point of T" means below.  B's own plane is uncertain by
+// tol_p x cond(B) for the reference's arithmetic, its (u, v) by uv x cond(B) in the plane.
 struct Poly { double v[8][3]; int n; };
 
 inline int clip_below(const Poly& in, const double nrm[3], double d, double off, Poly& out) {   // the part with n.x - d <= off
@@ -278,36 +289,43 @@ inline bool hull_clear_of_polygon(const double (*pts)[2], int n, const double (*
   return false;
 }
 
-struct BundleTol { double tol_in, tau_pos, kappa, sin_cell, t_min; };
+struct BundleTol {
+  double tol_p, tol_s, tau_pos, sin_cell, t_min, sigma, uv_k;
+  double at() const { return sigma + tol_s; }               // how far a (checked) hit point of T can be from T
+};
 
 // B's plane as the bundle of rays towards E sees it: oriented so that E lies on its positive side, the least sine at which a ray
 // of the bundle meets it, and f0 (case B's threshold) - computed once per (B, E, cell), used for every T of the cell.
-struct BundleSide { double nrm[3], d, f0; bool usable, steep; };
-inline BundleSide bundle_side(const Poly& E, const Plane& bp, double dmax, const BundleTol& tl) {
+struct BundleSide { double nrm[3], d, f0, own, uv; bool usable, steep; };
+inline BundleSide bundle_side(const Poly& E, const Plane& bp, double dmax, const BundleTol& tl) {   // (f0 still lacks the hit point's share: per T)
   BundleSide r{};
   double fe_min = INFINITY, fe_max = -INFINITY;
   for (int i = 0; i < E.n; i++) { const double f = bp.n[0] * E.v[i][0] + bp.n[1] * E.v[i][1] + bp.n[2] * E.v[i][2] - bp.d; fe_min = std::min(fe_min, f); fe_max = std::max(fe_max, f); }
   double sgn;
-  if (fe_min > tl.tau_pos) sgn = 1.0; else if (fe_max < -tl.tau_pos) sgn = -1.0; else return r;          // E on both sides of (or in) B's plane: nothing is proven
+  const double own = tl.tol_p * bp.cond;                                                                  // what B's plane is uncertain by
+  if (fe_min > tl.tau_pos + own) sgn = 1.0; else if (fe_max < -(tl.tau_pos + own)) sgn = -1.0; else return r;   // E on both sides of (or in) B's plane: nothing is proven
   r.usable = true;
   for (int k = 0; k < 3; k++) r.nrm[k] = sgn * bp.n[k];
   r.d = sgn * bp.d;
   const double sin_min = (sgn > 0 ? fe_min : -fe_max) / dmax;
   // a hit point with f >= -(tMin / 2) sin meets the plane before tMin / 2; the points of T whose hit points all satisfy that: f >= -f0
-  r.f0 = 0.5 * tl.t_min * std::min(sin_min, 1.0) - tl.tol_in;
+  r.f0 = 0.5 * tl.t_min * std::min(sin_min, 1.0) - own - tl.tol_s;
   r.steep = sin_min >= tl.sin_cell && r.f0 > 0;
+  r.own = own;
+  r.uv = tl.uv_k * bp.cond;
   return r;
 }
 
-// true: no ray from a point of T (within tol_in of it) to a point of E can be a hit of B
+// true: no ray from a hit point of T (within tl.at() of it) to a point of E can be a hit of B
 inline bool bundle_misses(const Poly& T, const Poly& E, const Poly& B, const BundleSide& bs, const BundleTol& tl) {
   if (!bs.usable) return false;
   const double* nrm = bs.nrm;
-  const double d = bs.d, f0 = bs.f0;
+  const double tin = tl.at();
+  const double d = bs.d, f0 = bs.f0 - tin;
   double f_min = INFINITY;                                                                                // over T itself; a hit point: tol_in lower at most
   for (int i = 0; i < T.n; i++) f_min = std::min(f_min, nrm[0] * T.v[i][0] + nrm[1] * T.v[i][1] + nrm[2] * T.v[i][2] - d);
-  if (f_min - tl.tol_in >= tl.tau_pos) return true;                                                       // A
-  if (!bs.steep) return false;
+  if (f_min - tin - bs.own >= tl.tau_pos) return true;                                                    // A
+  if (!bs.steep || !(f0 > 0)) return false;
   if (f_min >= -f0) return true;                                                                          // B
   Poly below;                                                                                             // C
   if (clip_below(T, nrm, d, -f0, below) == 0) return true;
@@ -333,7 +351,7 @@ inline bool bundle_misses(const Poly& T, const Poly& E, const Poly& B, const Bun
     }
   }
   for (int i = 0; i < B.n; i++) { q[i][0] = B.v[i][0] * u[0] + B.v[i][1] * u[1] + B.v[i][2] * u[2]; q[i][1] = B.v[i][0] * w[0] + B.v[i][1] * w[1] + B.v[i][2] * w[2]; }
-  return hull_clear_of_polygon(pts, np, q, B.n, tl.kappa);
+  return hull_clear_of_polygon(pts, np, q, B.n, 1.5 * (tin / tl.sin_cell + bs.uv));
 }
 
 }  // namespace
@@ -395,6 +413,18 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
     scene_maxabs = std::max(scene_maxabs, std::max(std::fabs(scene.lo[k]), std::fabs(scene.hi[k])));
   }
   scene_diag = std::sqrt(scene_diag);
+  // Every flat shape's plane and conditioning, once.  `tame`: the reference's float test of this shape is accurate enough to reason
+  // about - its t for a ray from anywhere in the scene (|ro| <= S) meeting the plane at sin >= 0.25 is off by 4 ulp x cond x S / 0.25,
+  // and that has to stay below a quarter of tMin (the escape arguments leave half of tMin).  A needle triangle is not tame: a cell or
+  // a shaft that holds one proves nothing.
+  constexpr double kUlp = 5.97e-8;
+  const double S = scene_diag + scene_maxabs;
+  const double cond_limit = std::min(16.0, 5e-5 * kSinCell / (4.0 * kUlp * S));
+  constexpr double kCondPlanar = 2.0;                      // shapes of a PLANAR cell (tol_p doubles for them)
+  constexpr double kSigma = 5e-6;                          // a hit point the shade stage has checked is this close to its shape
+  std::vector<Plane> planes(shapes);
+  parallel_pieces(shapes, 65536, [&](size_t a, size_t b, unsigned) { for (size_t i = a; i < b; i++) planes[i] = g.plane(i); });
+  auto tame = [&](size_t i) { return planes[i].ok && planes[i].cond <= cond_limit; };
 
   // subtree bounds from the shapes: sub[i] covers every leaf with an index in [i, exit(i)).  One reverse pass; on large
   // arrays the pass is cut at the top of the tree: the ranges [a, exit(a)) of a frontier of nodes are disjoint blocks of the
@@ -480,7 +510,14 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
   struct Flat { Plane pl; Poly poly; };
   std::vector<Flat> flat(mesh_cells ? shapes : 0);                 // plane and corners of every flat shape, once
   if (mesh_cells) parallel_pieces(shapes, 65536, [&](size_t a, size_t b, unsigned) {
-    for (size_t i = a; i < b; i++) { flat[i].pl = g.plane(i); flat[i].poly.n = g.polygon(i, flat[i].poly.v); flat_ok[i] = flat[i].pl.ok && flat[i].poly.n >= 3 ? 1 : 0; }
+    for (size_t i = a; i < b; i++) {
+      flat[i].pl = planes[i];
+      flat[i].poly.n = g.polygon(i, flat[i].poly.v);
+      // (the shade stage evaluates n.(p - a) in float: 4 ulp of the shape's diameter have to fit between its bound and sigma)
+      double diam = 0;
+      for (int c = 1; c < flat[i].poly.n; c++) { double d2 = 0; for (int k = 0; k < 3; k++) d2 += (flat[i].poly.v[c][k] - flat[i].poly.v[0][k]) * (flat[i].poly.v[c][k] - flat[i].poly.v[0][k]); diam = std::max(diam, std::sqrt(d2)); }
+      flat_ok[i] = tame(i) && flat[i].poly.n >= 3 && 4.0 * kUlp * diam <= kSigma - (double)hj::kLightGridSlide ? 1 : 0;
+    }
   });
   auto cell_range = [&](const Box& b, int lo[3], int hi[3]) {
     for (int k = 0; k < 3; k++) {
@@ -500,25 +537,18 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
     }
   });
   parallel_pieces(res, 1, [&](size_t z0, size_t z1, unsigned) {
-    uint32_t cached = 0xFFFFFFFFu;               // the plane of the cell's first shape, kept while consecutive cells share it
-    Plane cp{};
     for (size_t i = 0; i < shapes; i++) {
       const Range& r = range[i];
       if (r.lo[2] > r.hi[2] || r.hi[2] < z0 || r.lo[2] >= z1) continue;
-      Plane pi{};
-      bool have_pi = false;
+      const bool planar_ok = planes[i].ok && planes[i].cond <= kCondPlanar && planes[i].cond <= cond_limit;
       for (size_t z = std::max<size_t>(r.lo[2], z0); z <= r.hi[2] && z < z1; z++) for (int y = r.lo[1]; y <= r.hi[1]; y++) for (int x = r.lo[0]; x <= r.hi[0]; x++) {
         const size_t c = (z * res + (size_t)y) * res + (size_t)x;
         if (mesh_cells && !flat_ok[i]) hard[c] = 1;
         if (bad[c]) continue;
         if (first[c] == 0xFFFFFFFFu) {
           first[c] = (uint32_t)i;
-          if (!have_pi) { pi = g.plane(i); have_pi = true; }
-          if (!pi.ok) bad[c] = 1;
-        } else {
-          if (cached != first[c]) { cached = first[c]; cp = g.plane(cached); }
-          if (!g.coplanar(i, cp, tol_s)) bad[c] = 1;
-        }
+          if (!planar_ok) bad[c] = 1;
+        } else if (!planar_ok || !g.coplanar(i, planes[first[c]], tol_s)) bad[c] = 1;
       }
     }
   });
@@ -530,16 +560,18 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
     Em em{};
     em.shape = s->emitters[e].shape;
     em.ok = em.shape < shapes;
-    if (em.ok) { em.q = g.plane(em.shape); em.ok = em.q.ok; em.box = pad(widen(sb[em.shape]), m); }
+    if (em.ok) { em.q = planes[em.shape]; em.ok = tame(em.shape); em.box = pad(widen(sb[em.shape]), m); }
     if (em.ok) {
       // How steeply the emitter has to be seen: shapes "in Q" (the emitter, its neighbour triangle) are met at
       // t >= dist - slack / sin, and that has to stay behind tMax = dist - 1e-4 with room for the rounding of either side
       // (a quarter of eps for the geometry, the rest for the arithmetic: about 1e-5 at sin = 0.03).  slack = how far such shapes
       // really are from Q (measured; exactly 0 for an axis-aligned light) + how far a sampled point can be (4 ulp of the
       // emitter's largest coordinate).  0.1 as before when the measured figures give nothing better.
-      double dev = 0.0, big = 0.0;
+      double dev = 0.0, big = 0.0, cond_q = em.q.cond;       // (cond_q: the worst-conditioned shape in Q)
       for (size_t i = g.ns; i < shapes; i++) {
         if (!g.coplanar(i, em.q, tol_s)) continue;
+        if (!tame(i)) { em.ok = false; break; }              // (a needle in the emitter's plane: its t is anybody's guess)
+        cond_q = std::max(cond_q, planes[i].cond);
         double v[4][3];
         const int nv = g.vertices(i, v);
         for (int c = 0; c < nv; c++) dev = std::max(dev, std::fabs(em.q.n[0] * v[c][0] + em.q.n[1] * v[c][1] + em.q.n[2] * v[c][2] - em.q.d));
@@ -550,9 +582,10 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
       // cancellation in both dot products, about 6 ulp x |ro| / sin, and the rounding of ro = o - a another ulp of the largest
       // coordinate / sin (|ro| <= the scene's diagonal).  Half of eps for that, a quarter for the geometry: the view has to be
       // steeper in a larger scene, and where even 0.1 does not keep the sum inside eps this emitter proves nothing.
-      const double arith = 5.97e-8 * (6.0 * scene_diag + 2.0 * std::max(big, scene_maxabs));
+      // (of the 6 ulp, 4 are the normal's own cancellation: they grow with the conditioning of the shapes in Q)
+      const double arith = 5.97e-8 * ((2.0 + 4.0 * cond_q) * scene_diag + 2.0 * std::max(big, scene_maxabs));
       em.sin_min = std::min(kSinEmitter, std::max(0.03, std::max(em.slack / (0.25 * kEps), arith / (0.5 * kEps))));
-      if (!(em.slack / em.sin_min <= 0.25 * kEps && arith / em.sin_min <= 0.5 * kEps)) em.ok = false;
+      if (!(em.ok && em.slack / em.sin_min <= 0.25 * kEps && arith / em.sin_min <= 0.5 * kEps)) em.ok = false;
     }
     ems.push_back(em);
   }
@@ -579,11 +612,9 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
     std::vector<uint32_t> fill(cell_first.begin(), cell_first.end() - 1);
     for (size_t i = 0; i < shapes; i++) each_cell(i, [&](size_t c) { cell_shapes[fill[c]++] = (uint32_t)i; });
   }
-  // kappa: how far a computed crossing point - and the reference's own (u, v) test - can be off in B's plane: the hit point's tol_p
-  // carried along a ray that meets the plane at sin >= 0.25, plus the rounding of (u, v) (3 ulp x |ro| / sin, |ro| <= the scene's diagonal,
-  // taken sixteen-fold), times 1.5
-  const double kappa = 1.5 * ((tol_p + tol_s) / kSinCell + 16.0 * 5.97e-8 * (scene_diag + scene_maxabs) / kSinCell);
-  const BundleTol btol{tol_p + tol_s, 1e-5 * std::max(1.0, scale), kappa, kSinCell, kTMin};
+  // (the margin of case C is set per pair, in bundle_misses: 1.5 x (the hit point's slide / 0.25 + uv_k x cond(B)))
+  const BundleTol btol{tol_p, tol_s, 1e-5 * std::max(1.0, scale), kSinCell, kTMin, kSigma, 16.0 * kUlp * S / kSinCell};
+  if (mesh_cells) out.mesh_bits.assign(ncell, 0);
 
   std::atomic<size_t> next{0}, clear{0};
   auto run = [&] {
@@ -598,7 +629,8 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
         for (int k = 0; k < 3; k++) { cb.lo[k] = gb.lo[k] + xyz[k] * cell[k] - m; cb.hi[k] = gb.lo[k] + (xyz[k] + 1) * cell[k] + m; }
         const bool on_mesh = wi >= planar_cells;
 
-        const Plane P = on_mesh ? Plane{} : g.plane(first[c]);
+        const Plane P = on_mesh ? Plane{} : planes[first[c]];
+        const double tol_pc = kCondPlanar * tol_p;       // (a hit point on a shape of a planar cell)
         uint8_t bits = 0;
         for (size_t e = 0; e < ems.size() && on_mesh; e++) {
           // A cell on a mesh: the emitter side as for a planar cell; then every flat shape that touches the shaft - the cell's own
@@ -656,7 +688,7 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
           double lo_d, hi_d;
           side_dist(P, em.box, lo_d, hi_d);
           const double near_p = lo_d > 0 ? lo_d : (hi_d < 0 ? -hi_d : 0.0);
-          if (!(near_p - tol_p >= kSinCell * dmax)) continue;
+          if (!(near_p - tol_pc >= kSinCell * dmax)) continue;
           // (the hit point is within tol_p of P, so its distance to Q is what the part of the cell near P has: the cell's box is a superset)
           side_dist(em.q, cb, lo_d, hi_d);
           const double near_q = lo_d > 0 ? lo_d : (hi_d < 0 ? -hi_d : 0.0);
@@ -677,13 +709,13 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
                 // much fatter for the reference as its discriminant is noisy; shadow directions are normalised afresh, |d| = 1)
                 const double r = std::fabs((double)sp.radius);
                 if (!sh.outside_ball(c, r + m + 1e-6 * dmax * dmax / std::max(r, 1e-30))) blocked = true;
-              } else if (!(g.coplanar(shp, P, tol_s) || g.coplanar(shp, em.q, tol_s))) blocked = true;
+              } else if (!((g.coplanar(shp, P, tol_s) && tame(shp)) || g.coplanar(shp, em.q, tol_s))) blocked = true;   // (in Q: all tame, or the emitter is not ok)
             }
             i++;
           }
           if (!blocked) { bits |= (uint8_t)(1u << e); clear.fetch_add(1, std::memory_order_relaxed); }
         }
-        out.bits[c] = bits;
+        if (on_mesh) out.mesh_bits[c] = bits; else out.bits[c] = bits;
       }
     }
   };
@@ -697,14 +729,41 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
   if (timing) std::fprintf(stderr, "light grid: %zu planar cells, %zu cells on meshes\n", planar_cells, work.size() - planar_cells);
   out.pairs_clear = clear.load();
   if (out.pairs_clear == 0) { out = LightGrid{}; return false; }
+  bool any_mesh = false;
+  for (uint8_t b : out.mesh_bits) if (b) { any_mesh = true; break; }
+  if (!any_mesh) out.mesh_bits.clear();
+  else {
+    // what the shade stage checks a hit point with (kernels/hj_light_grid_const.h): n, delta; a, kind.  delta: the float (u, v) of a
+    // ray from anywhere (|ro| <= the diagonal of scene and camera) that meets the shape at sin >= kLightGridSinIn are off by
+    // 7 ulp x cond x |ro| / (sin x edge) at most (the cross product ro x d, the dot products, the normal's own cancellation); twice
+    // that (1 - u - v carries both errors) with a factor 1.5.  A shape that is not tame keeps an all-zero record.
+    double dall = 0;
+    for (int k = 0; k < 3; k++) dall += (all.hi[k] - all.lo[k]) * (all.hi[k] - all.lo[k]);
+    dall = std::sqrt(dall);
+    out.shape_recs.assign(8 * (shapes - g.ns), 0.0f);
+    for (size_t i = g.ns; i < shapes; i++) {
+      if (!flat_ok[i]) continue;
+      double v[4][3];
+      const int nv = g.vertices(i, v);
+      double e1 = 0, e2 = 0;
+      for (int k = 0; k < 3; k++) { e1 += (v[1][k] - v[0][k]) * (v[1][k] - v[0][k]); e2 += (v[2][k] - v[0][k]) * (v[2][k] - v[0][k]); }
+      const double edge = std::sqrt(std::min(e1, e2));
+      if (!(edge > 0)) continue;
+      const double delta = 2.0 * 1.5 * 7.0 * kUlp * planes[i].cond * dall / ((double)hj::kLightGridSinIn * edge);
+      float* r = &out.shape_recs[8 * (i - g.ns)];
+      for (int k = 0; k < 3; k++) { r[k] = (float)planes[i].n[k]; r[4 + k] = (float)v[0][k]; }
+      r[3] = std::nextafter((float)delta, INFINITY);
+      r[7] = nv == 4 ? 1.0f : 0.0f;
+    }
+  }
   return true;
 }
 
 }  // namespace hjapi
 
-// Test entry (no GPU needed): the grid hj_scene_upload would build for `s`.  bits: res^3 bytes (may be null: sizes only).
-extern "C" __attribute__((visibility("default"))) int hj_debug_light_grid(const hj_scene_desc* s, uint32_t res, uint8_t* bits, float lo[3],
-                                                                           float inv[3], uint64_t stats[3]) {
+// Test entries (no GPU needed): the grid hj_scene_upload would build for `s`.  bits: res^3 bytes (may be null: sizes only).
+namespace {
+int debug_grid(const hj_scene_desc* s, uint32_t res, hjapi::LightGrid& g) {
   // build_light_grid trusts what hj_scene_upload has validated; this entry takes a desc nobody has looked at: the same range checks
   // first (a desc that fails them has no grid)
   if (!s || !s->bvh || s->num_bvh_nodes == 0) return 0;
@@ -716,10 +775,41 @@ extern "C" __attribute__((visibility("default"))) int hj_debug_light_grid(const 
   for (size_t i = 0; i < s->num_bvh_nodes; i++)
     if (s->bvh[i].shape_index != HJ_BVH_INNER && s->bvh[i].shape_index >= shapes) return 0;
   for (size_t e = 0; e < s->num_emitters; e++) if (s->emitters[e].shape >= shapes) return 0;
-  hjapi::LightGrid g;
-  if (!hjapi::build_light_grid(s, res, g)) return 0;
-  if (bits) std::memcpy(bits, g.bits.data(), g.bits.size());
+  return hjapi::build_light_grid(s, res, g) ? (int)g.res : 0;
+}
+void debug_grid_out(const hjapi::LightGrid& g, float lo[3], float inv[3], uint64_t stats[3]) {
   for (int k = 0; k < 3; k++) { if (lo) lo[k] = g.lo[k]; if (inv) inv[k] = g.inv[k]; }
   if (stats) { stats[0] = g.cells_surface; stats[1] = g.cells_planar; stats[2] = g.pairs_clear; }
-  return (int)g.res;
+}
+}  // namespace
+
+// bits = planar bits | mesh bits (the latter hold for hits that were not grazing only: hj_debug_light_grid_planes tells them apart)
+extern "C" __attribute__((visibility("default"))) int hj_debug_light_grid(const hj_scene_desc* s, uint32_t res, uint8_t* bits, float lo[3],
+                                                                           float inv[3], uint64_t stats[3]) {
+  hjapi::LightGrid g;
+  const int r = debug_grid(s, res, g);
+  if (r == 0) return 0;
+  if (bits) for (size_t i = 0; i < g.bits.size(); i++) bits[i] = (uint8_t)(g.bits[i] | (g.mesh_bits.empty() ? 0 : g.mesh_bits[i]));
+  debug_grid_out(g, lo, inv, stats);
+  return r;
+}
+
+// planar: res^3 bytes, proofs that hold for every hit point of the cell; mesh: res^3 bytes, bundle proofs (cells on meshes and in
+// corners: for a hit point the shade stage has checked against its shape); recs: 8 floats per quad and triangle, what it checks with
+// (n, delta; a, kind: kernels/hj_light_grid_const.h); limits: {kLightGridSinIn, kLightGridSlide}.  Any output may be null.
+extern "C" __attribute__((visibility("default"))) int hj_debug_light_grid_planes(const hj_scene_desc* s, uint32_t res, uint8_t* planar, uint8_t* mesh,
+                                                                                  float* recs, float limits[2], float lo[3], float inv[3],
+                                                                                  uint64_t stats[3]) {
+  hjapi::LightGrid g;
+  const int r = debug_grid(s, res, g);
+  if (r == 0) return 0;
+  if (planar) std::memcpy(planar, g.bits.data(), g.bits.size());
+  if (mesh) { if (g.mesh_bits.empty()) std::memset(mesh, 0, g.bits.size()); else std::memcpy(mesh, g.mesh_bits.data(), g.mesh_bits.size()); }
+  if (recs) {
+    const size_t n = 8 * (s->num_quads + s->num_triangles);
+    if (g.shape_recs.empty()) std::memset(recs, 0, n * sizeof(float)); else std::memcpy(recs, g.shape_recs.data(), n * sizeof(float));
+  }
+  if (limits) { limits[0] = hj::kLightGridSinIn; limits[1] = hj::kLightGridSlide; }
+  debug_grid_out(g, lo, inv, stats);
+  return r;
 }

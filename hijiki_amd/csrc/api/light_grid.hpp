@@ -13,6 +13,12 @@ struct LightGrid {
   float lo[3] = {0, 0, 0};       // cell index along axis k = (int)((p[k] - lo[k]) * inv[k]), valid in [0, res)
   float inv[3] = {0, 0, 0};
   std::vector<uint8_t> bits;     // res^3 bytes (x fastest); bit e: every shadow ray from this cell to emitter e is unoccluded
+  // cells on meshes and in corners (bundle proofs): bit e holds for a hit point that the shade stage has found to lie on its shape
+  // (kernels/hj_light_grid_const.h); empty when no such cell is proven
+  std::vector<uint8_t> mesh_bits;
+  // with mesh_bits: 8 floats per quad and triangle (shape index - num_spheres) for that check: unit geometric normal, margin delta of
+  // the (u, v) test; vertex a (the quad's origin), 0 for a triangle / 1 for a quad.  All 0: never on its shape.
+  std::vector<float> shape_recs;
   size_t cells_surface = 0, cells_planar = 0, pairs_clear = 0;
 };
 

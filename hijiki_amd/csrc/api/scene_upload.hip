@@ -600,8 +600,14 @@ int hj_scene_upload(hj_context* ctx, const hj_scene_desc* s) {
       have_grid = res >= 2 && (!resident || !host_tree.empty()) && build_light_grid(&for_grid, (uint32_t)res, lg);
     } catch (const std::exception&) { have_grid = false; }   // (out of host memory: no grid)
     if (have_grid) {
-      HJ_UP(upload(ctx, lg.bits.data(), lg.bits.size(), &d.light_grid));
-      d.lg_res = lg.res;
+      // cells (low byte: planar proofs; high byte: bundle proofs, for hits that were not grazing), then - 16-byte aligned - the
+      // records the shade stage checks a hit point against its shape with (kernels/hj_shade.h shadow_ray_proven_free)
+      const size_t ncell = lg.bits.size(), cells_u16 = (ncell + 7) & ~(size_t)7;
+      std::vector<uint16_t> cells(cells_u16 + lg.shape_recs.size() * 2, 0);
+      for (size_t i = 0; i < ncell; i++) cells[i] = (uint16_t)(lg.bits[i] | (lg.mesh_bits.empty() ? 0u : (uint32_t)lg.mesh_bits[i] << 8));
+      if (!lg.shape_recs.empty()) std::memcpy(cells.data() + cells_u16, lg.shape_recs.data(), lg.shape_recs.size() * sizeof(float));
+      HJ_UP(upload(ctx, cells.data(), cells.size(), &d.light_grid));
+      d.lg_res = lg.res | (lg.shape_recs.empty() ? 0u : hj::kLightGridHasRecords);
       for (int k = 0; k < 3; k++) { d.lg_lo[k] = lg.lo[k]; d.lg_inv[k] = lg.inv[k]; }
       if (timing) std::fprintf(stderr, "hj_scene_upload: light grid %u^3: %zu cells hold a surface, %zu a planar one, %zu (cell, emitter) pairs proven free\n",
                                lg.res, lg.cells_surface, lg.cells_planar, lg.pairs_clear);

@@ -3,6 +3,7 @@
 #pragma once
 #include "../../../include/hijiki_hip.h"
 #include "hj_num.h"
+#include "hj_light_grid_const.h"
 
 namespace hj {
 
@@ -72,8 +73,12 @@ struct DeviceScene {
   float tan_half_fov;           // (float)tan(radians(fov/2)) evaluated in double on the host
   // Light-shaft visibility grid (api/light_grid.cpp): bit e of cell (x, y, z) says that EVERY next-event shadow ray from a hit
   // point in that cell to emitter e is unoccluded - the shade stage then adds the sample at once instead of queueing a ray.
-  const uint8_t* light_grid;    // lg_res^3 bytes, x fastest; null: no grid
-  uint32_t lg_res;
+  // Low byte: proofs that hold for every hit point of the cell (planar cells); high byte: cells on meshes and in corners, whose
+  // proofs hold for a hit that was not grazing (|d.n| >= kLightGridSinIn |d| against lg_normals: hj_light_grid_const.h).
+  // Behind the cells, 16-byte aligned, when any high byte is set: two float4 per quad and triangle (shape id - ns) for the check
+  // that a hit point lies on its shape (hj_light_grid_const.h; one pointer for both: the kernels keep this struct in scalar registers).
+  const uint16_t* light_grid;   // lg_res^3 cells, x fastest; null: no grid
+  uint32_t lg_res;              // cells per axis | kLightGridHasRecords
   float lg_lo[3], lg_inv[3];    // cell index along axis k = (int)((p[k] - lg_lo[k]) * lg_inv[k])
 };
 

@@ -2,6 +2,7 @@
 // texture (shader/materials/diffusecb.glsl) - used by the shade stage (hj_stages.h).
 #pragma once
 #include "hj_intersect.h"
+#include "hj_light_grid_const.h"
 
 #pragma clang fp contract(off)
 
@@ -103,15 +104,36 @@ HJ_DEV v3 sample_emitter(const DeviceScene& sc, v3 ref, uint32_t& rng, v3& sh_di
   return divs(power, pdf);
 }
 
-// Light-shaft visibility grid (api/light_grid.cpp): true when the grid PROVES that the shadow ray from hit point p to the sampled
-// point of emitter e is unoccluded (whatever tree is walked): no ray needs to be traced for this sample.
-HJ_DEV bool shadow_ray_proven_free(const DeviceScene& sc, v3 p, uint32_t e) {
+// Light-shaft visibility grid (api/light_grid.cpp).  A cell on a mesh or in a corner is proven for hit points that lie ON their shape,
+// and the reference's hit point need not (hj_light_grid_const.h): is this one - p, of the ray with direction rd that hit shape id at
+// (hu, hv) - where such a proof assumes it?  Depends on the hit alone, so the shade stage asks at its top, where the two records
+// travel with the loads populate needs anyway (asked at the grid lookup it was one more dependent round trip per round: -6 % on c2).
+HJ_DEV bool hit_point_on_its_shape(const DeviceScene& sc, uint32_t id, v3 p, v3 rd, float hu, float hv) {
+  if (sc.light_grid == nullptr || (sc.lg_res & kLightGridHasRecords) == 0u) return false;          // (uniform)
+  const uint32_t res = sc.lg_res & kLightGridResMask;
+  const uint32_t cells_bytes = (res * res * res * (uint32_t)sizeof(uint16_t) + 15u) & ~15u;
+  const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.light_grid) + cells_bytes) + 2u * (id >= sc.ns ? id - sc.ns : 0u);
+  const float4 r0 = rec[0], r1 = rec[1];                                         // n, delta; a, kind
+  const v3 n = xyz(r0);
+  const float dn = dot3(rd, n), dd = dot3(rd, rd), f = dot3(n, p - xyz(r1));
+  const float third = (r1.w != 0.0f) ? f_min(1.0f - hu, 1.0f - hv) : (1.0f - hu) - hv;
+  const float inside = f_min(f_min(hu, hv), third);
+  // (every comparison is false for a NaN and for the all-zero record of a shape nothing is claimed about)
+  return id >= sc.ns && inside >= r0.w && dn * dn >= (kLightGridSinIn * kLightGridSinIn) * dd && dd > 0.0f &&
+         (f * f) * dd <= (kLightGridSlide * kLightGridSlide) * (dn * dn);
+}
+
+// True when the grid PROVES that the shadow ray from hit point p to the sampled point of emitter e is unoccluded (whatever tree is
+// walked): no ray needs to be traced for this sample.  Low byte of the cell: for every hit point in it; high byte: for one on its shape.
+HJ_DEV bool shadow_ray_proven_free(const DeviceScene& sc, v3 p, uint32_t e, bool on_its_shape) {
   if (sc.light_grid == nullptr || e >= 8u) return false;
   const float fx = (p.x - sc.lg_lo[0]) * sc.lg_inv[0], fy = (p.y - sc.lg_lo[1]) * sc.lg_inv[1], fz = (p.z - sc.lg_lo[2]) * sc.lg_inv[2];
-  const float r = (float)sc.lg_res;
+  const uint32_t res = sc.lg_res & kLightGridResMask;
+  const float r = (float)res;
   if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < r && fy < r && fz < r)) return false;   // (NaN: false)
-  const uint32_t cell = ((uint32_t)fz * sc.lg_res + (uint32_t)fy) * sc.lg_res + (uint32_t)fx;
-  return ((sc.light_grid[cell] >> e) & 1u) != 0u;
+  const uint32_t cell = ((uint32_t)fz * res + (uint32_t)fy) * res + (uint32_t)fx;
+  const uint32_t bits = sc.light_grid[cell];
+  return ((bits >> e) & 1u) != 0u || (on_its_shape && ((bits >> (8u + e)) & 1u) != 0u);
 }
 
 // reference shader/materials/diffusecb.glsl:6-13

@@ -481,6 +481,7 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
       const uint32_t bounce = flags >> 1;
       const uint32_t id = (uint32_t)__float_as_int(hr.y);
       its.p = V(fmaf(hr.x, rd.x, ro.x), fmaf(hr.x, rd.y, ro.y), fmaf(hr.x, rd.z, ro.z));   // scene.glsl:164
+      const bool on_its_shape = hit_point_on_its_shape(sc, id, its.p, rd, hr.z, hr.w);      // (for the light-shaft grid, below)
       if (id < sc.ns) populate_sphere(sc.spheres[id], its);
       else if (id < sc.ns + sc.nq) populate_quad(sc, id - sc.ns, hr.z, hr.w, its);
       else populate_triangle(sc, id - sc.ns - sc.nq, hr.z, hr.w, its);
@@ -515,7 +516,7 @@ HJ_DEV void stage_shade(const BatchState& st, const DeviceScene& sc, uint32_t g,
             scol = (T * f) * imp;
             // intersectScene(shadowRay) is known to be false for this cell and emitter (api/light_grid.cpp): the sample is
             // added here, where render.glsl:122-124 adds it, instead of after a walk in the next round
-            add_now = shadow_ray_proven_free(sc, its.p, em);
+            add_now = shadow_ray_proven_free(sc, its.p, em, on_its_shape);
 #ifdef HJ_PROBE_ALL_SHADOW_FREE   // measurement only (WRONG image): no shadow ray is ever walked - the ceiling of everything a visibility structure could prove
             add_now = true;
 #endif

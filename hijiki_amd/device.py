@@ -22,7 +22,7 @@ EXPORTS = ("hj_context_create", "hj_context_destroy", "hj_last_error", "hj_versi
            "hj_pass_offset", "hj_block_owner", "hj_debug_trace", "hj_debug_samples", "hj_reduce_framebuffers",
            "hj_build_bvh_device", "hj_render_frame_async", "hj_sync", "hj_set_progress_callback", "hj_device_count",
            "hj_comm_create", "hj_comm_destroy", "hj_comm_reduce_framebuffers", "hj_reserve", "hj_framebuffer_bind",
-           "hj_pipeline_wait", "hj_debug_light_grid", "hj_tune_bvh_device", "hj_bvh_device_read")
+           "hj_pipeline_wait", "hj_debug_light_grid", "hj_debug_light_grid_planes", "hj_tune_bvh_device", "hj_bvh_device_read")
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
 

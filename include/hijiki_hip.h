@@ -413,6 +413,15 @@ int hj_debug_samples(hj_context* ctx, const hj_image_block* block, const hj_rend
  *   point p along axis k is (int)((p[k] - lo[k]) * inv[k]) in float arithmetic; stats = cells that hold a surface, cells whose
  *   surfaces lie in one plane, (cell, emitter) pairs proven free.  tests/test_light_grid.py attacks the claim with the oracle. */
 int hj_debug_light_grid(const hj_scene_desc* scene, uint32_t res, uint8_t* bits, float lo[3], float inv[3], uint64_t stats[3]);
+/* hj_debug_light_grid_planes: the same grid with its two kinds of proof apart.  planar (res^3 bytes): bits that hold for EVERY hit
+ *   point of the cell (all shapes of the cell in one plane); mesh (res^3 bytes): bits of cells on meshes and in corners, which hold
+ *   for a hit point that lies on its shape - a grazing hit leaves the reference's hit point off it, so the shade stage checks
+ *   (DESIGN.md section 4): with recs, 8 floats per quad and triangle (shape index - num_spheres) = unit normal n, margin delta;
+ *   vertex a, 0 (triangle) / 1 (quad), and limits = {sin_in, slide}: |d.n| >= sin_in |d|, |n.(p - a)| |d| <= slide |d.n|,
+ *   min(u, v, 1 - u - v) >= delta (a quad: u, v, 1 - u, 1 - v) for the ray (o, d) that hit and its (t, u, v).
+ *   hj_debug_light_grid's bits = planar | mesh.  Any output may be NULL. */
+int hj_debug_light_grid_planes(const hj_scene_desc* scene, uint32_t res, uint8_t* planar, uint8_t* mesh, float* recs, float limits[2],
+                               float lo[3], float inv[3], uint64_t stats[3]);
 
 /* The deterministic replacement of `rand::random()` in the block generator.
  * Pure functions (no context); the same definitions are used by the host

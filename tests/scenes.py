@@ -189,3 +189,138 @@ def nasty_scene(seed):
         s.add_triangle(b + a, b + c, b + d, int(rng.choice(mats + [light])))
         if rng.random() < 0.3: s.add_triangle(b + a, b + c, b + d, int(rng.choice(mats)))   # duplicates
     return s.compile()
+
+
+def _rotation(rng, amount=1.0):
+    """A random rotation matrix (amount 0: identity ... 1: anything)."""
+    q = rng.normal(size=4) * amount + np.array([0, 0, 0, 1.0]) * (1.0 - amount) * 4
+    x, y, z, w = q / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _grid_surface(fn, nu, nv, wrap_u, wrap_v):
+    """Vertices of the parametric surface fn(u, v) -> (n, 3) on an nu x nv grid over [0, 1]^2 and its two triangles per cell."""
+    us = np.arange(nu) / (nu if wrap_u else nu - 1)
+    vs = np.arange(nv) / (nv if wrap_v else nv - 1)
+    U, V = np.meshgrid(us, vs, indexing="ij")
+    P = fn(U.ravel(), V.ravel())
+    tri = []
+    for i in range(nu if wrap_u else nu - 1):
+        for j in range(nv if wrap_v else nv - 1):
+            a, b = i * nv + j, ((i + 1) % nu) * nv + j
+            c, d = i * nv + (j + 1) % nv, ((i + 1) % nu) * nv + (j + 1) % nv
+            tri += [(a, b, d), (a, d, c)]
+    return P, np.array(tri, np.int64)
+
+
+def smooth_mesh_scene(seed):
+    """Tessellated smooth surfaces in a box - what the light-shaft grid's cells on meshes are meant for, and what could break them:
+    convex bodies (ellipsoids, capsules), bodies with concave parts (tori, the INSIDE of bowls, wavy height fields, saddles),
+    bodies with creases (cylinders with caps, cones, boxes), at random resolution (coarse facets ... facets far smaller than a
+    grid cell), rotation, size and winding, with smooth, faceted or random shading normals; one to three lights - quads or
+    triangles, on the ceiling, on a side wall or floating and tilted - and walls made of quads or of triangles."""
+    rng = np.random.default_rng(91000 + seed)
+    s = host.Scene()
+    q = rng.normal(size=4) * 0.1 + np.array([0, 0, 0, 1.0])
+    q /= np.linalg.norm(q)
+    s.set_camera((float(rng.uniform(-0.3, 0.3)), float(rng.uniform(0.6, 1.3)), float(rng.uniform(3.0, 3.6))), tuple(float(x) for x in q),
+                 float(rng.uniform(28, 45)))
+    diffuse = [s.add_diffuse(tuple(rng.uniform(0.2, 0.9, 3))) for _ in range(4)]
+    others = [s.add_mirror(), s.add_dielectric(1.5), s.add_diffuse_cboard((0.8, 0.8, 0.3), 0.1, (0.2, 0.3, 0.8), 0.17)]
+    lights = [s.add_emissive(tuple(rng.uniform(6, 25, 3))) for _ in range(3)]
+    sc = float(rng.choice([1.0, 1.0, 1.0, 0.05, 12.0]))                  # the whole scene magnified (the reference's epsilons are not)
+
+    def quad(o, e1, e2, m, as_triangles=False):
+        o, e1, e2 = np.array(o, float) * sc, np.array(e1, float) * sc, np.array(e2, float) * sc
+        if as_triangles:
+            n = np.cross(e1, e2)
+            n /= np.linalg.norm(n)
+            b = s.add_vertices(np.array([o, o + e1, o + e1 + e2, o + e2], np.float32), np.tile(n, (4, 1)).astype(np.float32))
+            s.add_triangles(np.array([[b, b + 1, b + 2], [b, b + 2, b + 3]]), m)
+        else:
+            s.add_quad(tuple(o), tuple(e1), tuple(e2), m)
+
+    wt = rng.random() < 0.4                                               # walls of triangles (as cbox.obj has them)
+    quad((-1.2, 0, 1.2), (2.4, 0, 0), (0, 0, -2.4), diffuse[0], wt)       # floor
+    quad((-1.2, 2.0, -1.2), (2.4, 0, 0), (0, 0, 2.4), diffuse[0], wt)     # ceiling
+    quad((-1.2, 0, -1.2), (2.4, 0, 0), (0, 2.0, 0), diffuse[1], wt)       # back
+    quad((-1.2, 0, 1.2), (0, 0, -2.4), (0, 2.0, 0), diffuse[2], wt)       # left
+    quad((1.2, 0, -1.2), (0, 0, 2.4), (0, 2.0, 0), diffuse[3], wt)        # right
+    for li in range(int(rng.integers(1, 4))):
+        kind = rng.integers(0, 4)
+        w, d = rng.uniform(0.15, 0.9, 2)
+        if kind == 0:                                                      # under the ceiling, facing down
+            o = (rng.uniform(-1.1, 1.1 - w), 2.0 - rng.choice([0.01, 0.002, 0.1]), rng.uniform(-1.1, 1.1 - d))
+            e1, e2 = (w, 0, 0), (0, 0, d)
+        elif kind == 1:                                                    # on the left wall, facing +x
+            o = (-1.2 + rng.choice([0.01, 0.003]), rng.uniform(0.2, 1.8 - w), rng.uniform(-1.0, 1.0 - d))
+            e1, e2 = (0, w, 0), (0, 0, d)
+        elif kind == 2:                                                    # on the back wall, facing +z
+            o = (rng.uniform(-1.0, 1.0 - w), rng.uniform(0.2, 1.8 - d), -1.2 + 0.01)
+            e1, e2 = (w, 0, 0), (0, d, 0)
+        else:                                                              # floating and tilted
+            R = _rotation(rng, 0.5)
+            o = tuple(rng.uniform([-0.6, 1.0, -0.6], [0.4, 1.7, 0.4]))
+            e1, e2 = tuple(R @ np.array([w * 0.6, 0, 0])), tuple(R @ np.array([0, 0, d * 0.6]))
+        quad(o, e1, e2, lights[li], rng.random() < 0.5)
+
+    for _ in range(int(rng.integers(1, 4))):
+        kind = int(rng.integers(0, 8))
+        n1, n2 = int(rng.choice([5, 8, 12, 20, 32, 56])), int(rng.choice([4, 7, 12, 20, 32, 56]))
+        rx, ry, rz = rng.uniform(0.12, 0.45, 3)
+        wrap = (True, False)
+        if kind == 0:                                                      # ellipsoid
+            fn = lambda u, v: np.stack([rx * np.cos(2 * np.pi * u) * np.sin(np.pi * v), ry * np.cos(np.pi * v), rz * np.sin(2 * np.pi * u) * np.sin(np.pi * v)], 1)
+        elif kind == 1:                                                    # torus
+            r2 = rng.uniform(0.2, 0.6) * rx
+            wrap = (True, True)
+            fn = lambda u, v: np.stack([(rx + r2 * np.cos(2 * np.pi * v)) * np.cos(2 * np.pi * u), r2 * np.sin(2 * np.pi * v), (rx + r2 * np.cos(2 * np.pi * v)) * np.sin(2 * np.pi * u)], 1)
+        elif kind == 2:                                                    # a bowl: half an ellipsoid, seen from inside and outside
+            fn = lambda u, v: np.stack([rx * np.cos(2 * np.pi * u) * np.sin(0.5 * np.pi * v), -ry * np.cos(0.5 * np.pi * v), rz * np.sin(2 * np.pi * u) * np.sin(0.5 * np.pi * v)], 1)
+        elif kind == 3:                                                    # a wavy sheet
+            wrap = (False, False)
+            k1, k2, amp = rng.uniform(1, 5), rng.uniform(1, 5), rng.uniform(0.01, 0.15)
+            fn = lambda u, v: np.stack([2 * rx * (u - 0.5) * 2, amp * np.sin(k1 * 2 * np.pi * u) * np.cos(k2 * 2 * np.pi * v), 2 * rz * (v - 0.5) * 2], 1)
+        elif kind == 4:                                                    # a saddle
+            wrap = (False, False)
+            fn = lambda u, v: np.stack([2 * rx * (u - 0.5), ry * ((2 * u - 1) ** 2 - (2 * v - 1) ** 2), 2 * rz * (v - 0.5)], 1)
+        elif kind == 5:                                                    # a cylinder with flat caps (creases at the rims)
+            def fn(u, v):
+                rr = np.where((v < 0.2) | (v > 0.8), np.minimum(v, 1 - v) / 0.2, 1.0)
+                y = np.clip((v - 0.2) / 0.6, 0, 1) - 0.5
+                return np.stack([rx * rr * np.cos(2 * np.pi * u), 2 * ry * y, rx * rr * np.sin(2 * np.pi * u)], 1)
+        elif kind == 6:                                                    # a cone
+            fn = lambda u, v: np.stack([rx * v * np.cos(2 * np.pi * u), ry * (1 - 2 * v), rx * v * np.sin(2 * np.pi * u)], 1)
+        else:                                                              # a superellipsoid: from a rounded box to almost a box
+            e = rng.uniform(0.15, 1.0)
+            sp = lambda x: np.sign(x) * np.abs(x) ** e
+            fn = lambda u, v: np.stack([rx * sp(np.cos(2 * np.pi * u)) * sp(np.sin(np.pi * v)), ry * sp(np.cos(np.pi * v)), rz * sp(np.sin(2 * np.pi * u)) * sp(np.sin(np.pi * v))], 1)
+        P, tri = _grid_surface(fn, n1, n2, *wrap)
+        R = _rotation(rng, float(rng.choice([0.0, 0.3, 1.0])))
+        c = rng.uniform([-0.7, 0.35, -0.7], [0.7, 1.3, 0.7])
+        if rng.random() < 0.3: c[1] = float(np.abs(P @ R.T)[:, 1].max()) + rng.choice([0.0, 0.001, 0.05])       # standing on the floor
+        P = (P @ R.T + c) * sc
+        if rng.random() < 0.3: tri = tri[:, ::-1]                         # the other winding
+        # shading normals: smooth (area-weighted facet normals), the facet's own (vertices not shared), or random
+        fnrm = np.cross(P[tri[:, 1]] - P[tri[:, 0]], P[tri[:, 2]] - P[tri[:, 0]])
+        mode = rng.integers(0, 4)
+        if mode == 1:
+            P2 = P[tri].reshape(-1, 3)
+            N2 = np.repeat(fnrm, 3, axis=0)
+            tri = np.arange(len(P2)).reshape(-1, 3)
+            P, N = P2, N2
+        elif mode == 2:
+            N = rng.normal(size=P.shape)
+        else:
+            N = np.zeros_like(P)
+            for k in range(3): np.add.at(N, tri[:, k], fnrm)
+        ln = np.linalg.norm(N, axis=1, keepdims=True)
+        N = np.where(ln > 0, N / np.where(ln > 0, ln, 1), np.array([0.0, 1.0, 0.0]))
+        b = s.add_vertices(P.astype(np.float32), N.astype(np.float32))
+        mat = int(rng.choice(diffuse + diffuse + others + lights[2:]))
+        s.add_triangles(tri + b, mat)
+    if rng.random() < 0.3:
+        s.add_sphere(tuple(rng.uniform([-0.8, 0.2, -0.8], [0.8, 1.2, 0.8]) * sc), float(rng.uniform(0.1, 0.3) * sc), int(rng.choice(diffuse + others)))
+    return s.compile()

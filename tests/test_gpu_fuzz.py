@@ -83,3 +83,33 @@ def test_light_grid_never_frees_an_occluded_ray(gpu_renderer, cbox, cbox_spheres
         shadow_total += shadow
         done += 1
     print(f"light grid: seed {SEED}, 2 + {done} scenes, {proven_total} of {shadow_total} shadow rays proven free, 0 disagreements, {time.time() - t0:.1f} s")
+
+
+def test_the_shade_stage_checks_hit_points_like_its_cpu_restatement(gpu_renderer, cbox, cbox_spheres):
+    """Cells on meshes and in corners are proven for hit points that lie ON their shape, and kernels/hj_shade.h hit_point_on_its_shape
+    decides that per hit.  tests/test_light_grid.py Grid.on_its_shape restates the check in numpy; over the oracle's logged shadow
+    rays of a frame it must count exactly the rays the GPU reports as proven free for the same blocks (the rays are the same bit
+    for bit, so one hit judged differently shows) - and among them not one that the oracle found occluded."""
+    import test_light_grid as TL
+    from oracle import hj_oracle as O
+    rng = np.random.default_rng(SEED + 2)
+    cases = [("c2 scene", cbox), ("c3 scene", cbox_spheres)] + [(f"smooth-mesh scene {s}", scenes.smooth_mesh_scene(s)) for s in (int(x) for x in rng.integers(0, 100000, 6))]
+    checked = 0
+    for name, cs in cases:
+        grid = TL.Grid(cs)
+        if not grid.got:
+            continue
+        blocks = host.make_blocks(128, 96, 2, 5)
+        sh, ids, d, u, v = TL.oracle_shadow_rays(cs, O, blocks)
+        e = sh[:, 10].astype(np.int64)
+        planar = grid.proven(sh[:, 0:3], e)
+        proven = grid.proven(sh[:, 0:3], e, ids, d, u, v)
+        assert not (proven & (sh[:, 9] >= 0)).any(), f"HJ_FUZZ_SEED={SEED}: {name}: a proven ray is occluded"
+        gpu_renderer.upload_scene(cs)
+        gpu_renderer.create_framebuffer(128, 96)
+        st = gpu_renderer.render_blocks(blocks)
+        assert st["shadow_rays"] == len(sh)
+        assert st["shadow_rays_proven_free"] == int(proven.sum()), (f"HJ_FUZZ_SEED={SEED}: {name}: the GPU proved {st['shadow_rays_proven_free']} rays free, "
+                                                                    f"the restatement {int(proven.sum())} ({int(planar.sum())} of them in planar cells)")
+        checked += int((proven & ~planar).sum())
+    assert checked > 1000                                                  # (rays that only a checked hit point proves)

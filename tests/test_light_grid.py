@@ -28,6 +28,104 @@ def build_grid(cs, res=RES):
     return got, bits, np.array(list(lo), np.float32), np.array(list(inv), np.float32), [int(x) for x in st]
 
 
+class Grid:
+    """The grid with its two kinds of proof apart (hj_debug_light_grid_planes): `planar` bits hold for every hit point of the cell,
+    `mesh` bits (cells on meshes and in corners) for hit points that lie on their shape - which kernels/hj_shade.h
+    shadow_ray_proven_free checks per hit, and `on_its_shape` below restates in numpy float32."""
+
+    def __init__(self, cs, res=RES):
+        L = C.CDLL(device.HIP_LIB_PATH)
+        L.hj_debug_light_grid_planes.argtypes = [C.POINTER(abi.SceneDesc), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float),
+                                                 C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+        d = cs.desc
+        self.res, self.ns = res, int(d.num_spheres)
+        self.planar, self.mesh = np.zeros(res ** 3, np.uint8), np.zeros(res ** 3, np.uint8)
+        self.recs = np.zeros((int(d.num_quads) + int(d.num_triangles), 8), np.float32)
+        lo, inv, lim, st = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 2)(), (C.c_uint64 * 3)()
+        self.got = L.hj_debug_light_grid_planes(C.byref(d), res, self.planar.ctypes.data, self.mesh.ctypes.data, self.recs.ctypes.data, lim, lo, inv, st)
+        self.lo, self.inv = np.array(list(lo), np.float32), np.array(list(inv), np.float32)
+        self.sin_in, self.slide = np.float32(lim[0]), np.float32(lim[1])
+        self.stats = [int(x) for x in st]
+
+    def cells(self, p):
+        """(inside the grid, cell index) of points p, in float32 as the kernel computes them."""
+        f = ((np.asarray(p, np.float32) - self.lo) * self.inv).astype(np.float32)
+        inside = (f >= 0).all(1) & (f < self.res).all(1)
+        c = np.where(inside[:, None], f, 0).astype(np.uint32).astype(np.int64)
+        return inside, (c[:, 2] * self.res + c[:, 1]) * self.res + c[:, 0]
+
+    def on_its_shape(self, ids, p, d, u, v):
+        """kernels/hj_shade.h: is hit point p (of the ray with direction d, which hit shape ids at (u, v)) where a bundle proof
+        assumes it to be?"""
+        ids = np.asarray(ids, np.int64)
+        flat = ids >= self.ns
+        r = self.recs[np.where(flat, ids - self.ns, 0)]
+        n, delta, a, quad = r[:, 0:3], r[:, 3], r[:, 4:7], r[:, 7] != 0
+        p, d, u, v = (np.asarray(x, np.float32) for x in (p, d, u, v))
+        # kernels/hj_num.h dot3 = fmaf(z, z', fmaf(y, y', x x')): a float32 product is exact in float64, so is the sum before its one rounding
+        fma = lambda x, y, z: (x.astype(np.float64) * y.astype(np.float64) + z.astype(np.float64)).astype(np.float32)
+        dot = lambda x, y: fma(x[:, 2], y[:, 2], fma(x[:, 1], y[:, 1], (x[:, 0] * y[:, 0]).astype(np.float32)))
+        dn, dd, f = dot(d, n), dot(d, d), dot(n, (p - a).astype(np.float32))
+        one = np.float32(1)
+        third = np.where(quad, np.minimum(one - u, one - v), (one - u) - v).astype(np.float32)
+        inside = np.minimum(np.minimum(u, v), third)
+        with np.errstate(all="ignore"):
+            return flat & (inside >= delta) & (dn * dn >= (self.sin_in * self.sin_in) * dd) & (dd > 0) & ((f * f) * dd <= (self.slide * self.slide) * (dn * dn))
+
+    def proven(self, p, e, ids=None, d=None, u=None, v=None):
+        """shadow_ray_proven_free for hit points p and emitter indices e; without the hit (ids ... v): the planar bits alone."""
+        e = np.asarray(e, np.int64)
+        inside, cell = self.cells(p)
+        ok = inside & (e >= 0) & (e < 8)
+        es = np.where(ok, e, 0)
+        out = ok & (((self.planar[cell] >> es) & 1) != 0)
+        if ids is not None:
+            out |= ok & (((self.mesh[cell] >> es) & 1) != 0) & self.on_its_shape(ids, p, d, u, v)
+        return out
+
+
+def oracle_shadow_rays(cs, O, blocks):
+    """The oracle's next-event shadow rays for `blocks` with the hit each one starts from: (shadow rows of the log, id, d, u, v of
+    the closest-hit ray logged right before each - re-traced for its (u, v), which the log does not hold)."""
+    log = O.logged_rays(cs, blocks)
+    idx = np.nonzero(log[:, 8] == 1)[0]
+    idx = idx[idx > 0]
+    prev = log[idx - 1]
+    keep = prev[:, 8] == 0
+    idx, prev = idx[keep], prev[keep]
+    rays = np.ascontiguousarray(prev[:, 0:8])
+    ids, _, u, v = O.intersect(cs, rays, use_bvh=True)
+    return log[idx], ids, prev[:, 3:6], u, v
+
+
+def crafted_hits(cs, grid, rng, per_shape):
+    """Hit points as the shade stage can see them on every flat shape (uniform per shape): X = a + u e1 + v e2 on the shape, moved
+    ALONG a random incoming direction d by up to 9e-6 either way (more than the check admits: it filters) - returns ids, p, d, u, v."""
+    tri, pos, quad, _, ns, nq = scene_arrays(cs)
+    ids, X, N, U, V = [], [], [], [], []
+    if len(quad):
+        k = np.repeat(np.arange(len(quad)), per_shape * 4)
+        q = quad[k].astype(np.float64)
+        u, v = rng.uniform(0, 1, (2, len(k)))
+        ids.append(ns + k); X.append(q[:, 0:3] + q[:, 4:7] * u[:, None] + q[:, 8:11] * v[:, None]); N.append(np.cross(q[:, 4:7], q[:, 8:11])); U.append(u); V.append(v)
+    if len(tri):
+        k = np.repeat(np.arange(len(tri)), per_shape)
+        a, b, c = (pos[tri[k, j]].astype(np.float64) for j in range(3))
+        u, v = rng.uniform(0, 1, (2, len(k)))
+        fl = u + v > 1
+        u, v = np.where(fl, 1 - u, u), np.where(fl, 1 - v, v)
+        ids.append(ns + nq + k); X.append(a + (b - a) * u[:, None] + (c - a) * v[:, None]); N.append(np.cross(b - a, c - a)); U.append(u); V.append(v)
+    ids, X, N, U, V = (np.concatenate(x) for x in (ids, X, N, U, V))
+    ln = np.linalg.norm(N, axis=1)
+    keep = ln > 0
+    ids, X, N, U, V = ids[keep], X[keep], N[keep] / ln[keep, None], U[keep], V[keep]
+    d = rng.normal(size=X.shape)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d *= rng.uniform(0.5, 2.0, (len(d), 1))                                # (directions are not always unit vectors)
+    p = X + d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(-9e-6, 9e-6, (len(X), 1))
+    return ids, p.astype(np.float32), d.astype(np.float32), U.astype(np.float32), V.astype(np.float32)
+
+
 def scene_arrays(cs):
     d = cs.desc
     tri = np.ctypeslib.as_array(d.triangles, shape=(d.num_triangles,)).view(np.uint32).reshape(-1, 3) if d.num_triangles else np.zeros((0, 3), np.uint32)
@@ -113,25 +211,28 @@ def shape_points(cs, rng, per_shape):
 
 def attack(cs, oracle, rng, n=60000, res=RES, per_shape=0):
     """Number of shadow rays tried from cells whose bit is set, and how many the oracle found occluded (must be 0)."""
-    got, bits, lo, inv, st = build_grid(cs, res)
-    if got == 0:
+    grid = Grid(cs, res)
+    st = grid.stats
+    if grid.got == 0:
         return 0, 0, st
     _, _, _, em, _, _ = scene_arrays(cs)
+    # planar bits: any point of the cell within tol of the plane - points on the shapes, a hair across their edges, moved by up to
+    # +-1e-5 along the normal (the grid allows 2e-6 x scale); bits of cells on meshes and in corners: hit points that pass the shade
+    # stage's check (crafted_hits: on the shape, slid along a random incoming direction)
     p, nrm = shape_points(cs, rng, per_shape) if per_shape else planar_points(cs, rng, n)
-    # a computed hit point is not exactly on its shape: move it by up to +-1e-5 along the normal (the grid allows 2e-6 x scale)
     p = (p + nrm * rng.uniform(-1e-5, 1e-5, (len(p), 1))).astype(np.float32)
-    f = (p - lo) * inv
-    inr = ((f >= 0) & (f < res)).all(1)
-    ci = np.clip(f.astype(np.int64), 0, res - 1)
-    cell = (ci[:, 2] * res + ci[:, 1]) * res + ci[:, 0]
+    hits = crafted_hits(cs, grid, rng, per_shape) if per_shape else None
     tried = bad = 0
     for e, shape in enumerate(em[:8]):
-        sel = inr & (((bits[cell] >> e) & 1) != 0)
-        if not sel.any():
-            continue
-        y = emitter_points(cs, int(shape), rng, int(sel.sum()))
-        assert y is not None, "a bit is set for a sphere emitter"
+        sel = grid.proven(p, np.full(len(p), e))
         o = p[sel]
+        if hits is not None:
+            hsel = grid.proven(hits[1], np.full(len(hits[1]), e), *(hits[k] for k in (0, 2, 3, 4)))
+            o = np.concatenate([o, hits[1][hsel]])
+        if not len(o):
+            continue
+        y = emitter_points(cs, int(shape), rng, len(o))
+        assert y is not None, "a bit is set for a sphere emitter"
         d = y - o
         dist = np.sqrt((d.astype(np.float32) ** 2).sum(1, dtype=np.float32)).astype(np.float32)
         d = (d / dist[:, None]).astype(np.float32)
@@ -218,19 +319,12 @@ def test_grid_against_the_oracles_own_shadow_rays(name):
         cs = scenes.random_cluster_scene(int(parts[1]), scale=float(parts[3]) if len(parts) > 3 else 1.0)
     else:
         cs = scenes.random_scene(int(name.split()[1]))
-    got, bits, lo, inv, st = build_grid(cs)
-    if not got:
+    grid = Grid(cs)
+    if not grid.got:
         pytest.skip("no grid for this scene")
-    log = O.logged_rays(cs, host.make_blocks(128, 96, 3, 4))
-    sh = log[log[:, 8] == 1]
+    sh, ids, d, u, v = oracle_shadow_rays(cs, O, host.make_blocks(128, 96, 3, 4))
     assert len(sh) > 1000
-    e = sh[:, 10].astype(np.int64)
-    f = ((sh[:, 0:3] - lo) * inv).astype(np.float32)                      # (float32, as the kernel computes it)
-    inside = (f >= 0).all(1) & (f < RES).all(1) & (e >= 0) & (e < 8)
-    c = f[inside].astype(np.uint32)
-    cell = (c[:, 2].astype(np.int64) * RES + c[:, 1]) * RES + c[:, 0]
-    proven = np.zeros(len(sh), bool)
-    proven[inside] = ((bits[cell] >> e[inside]) & 1) != 0
+    proven = grid.proven(sh[:, 0:3], sh[:, 10].astype(np.int64), ids, d, u, v)
     occluded = sh[:, 9] >= 0
     assert not (proven & occluded).any(), (name, int((proven & occluded).sum()), sh[proven & occluded][:3])
     if name in ("cbox", "cbox + spheres"):

@@ -8,28 +8,22 @@ kind = {"c2": host.SYNTH_CBOX, "c3": host.SYNTH_CBOX_SPHERES}[sys.argv[1]]
 cs = host.Scene.synthetic(kind).compile()
 W = H = 192
 blocks = host.make_blocks(W, H, 2, 1)
-log = O.logged_rays(cs, blocks)
-# grid
-res = 64
-bits = np.zeros(res**3, np.uint8); lo = (C.c_float*3)(); inv = (C.c_float*3)(); stats = (C.c_uint64*3)()
-L = device.lib()
-L.hj_debug_light_grid.argtypes = [C.POINTER(abi.SceneDesc), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-r = L.hj_debug_light_grid(C.byref(cs.desc), res, bits.ctypes.data, lo, inv, stats)
-print("grid res", r, list(stats))
-lo = np.array(list(lo), np.float32); inv = np.array(list(inv), np.float32)
-sh = log[log[:, 8] == 1]
-# origin shape: the closest ray logged right before each shadow ray hit shape id
-idx = np.nonzero(log[:, 8] == 1)[0]
-prev_hit = log[idx - 1, 9].astype(np.int64)
+log = O.logged_rays(cs, blocks)        # (for the closest-hit rays' cost below)
+# the grid, looked up as kernels/hj_shade.h does: planar bits for every hit point, bits of cells on meshes and in corners for hit
+# points that pass the shade stage's check (tests/test_light_grid.py Grid)
+import test_light_grid as TL
+grid = TL.Grid(cs, 64)
+print("grid res", grid.got, grid.stats)
+sh, prev_hit, prev_d, prev_u, prev_v = TL.oracle_shadow_rays(cs, O, blocks)
+prev_hit = prev_hit.astype(np.int64)
 ns, nq = int(cs.desc.num_spheres), int(cs.desc.num_quads)
-wall_tris = 12   # synthetic cbox: which triangles are walls? find by size: use triangle area
-tri = cs.triangles if hasattr(cs, 'triangles') else None
-f = ((sh[:, 0:3] - lo) * inv).astype(np.float32)
-cell = (f[:, 2].astype(np.int64) * res + f[:, 1].astype(np.int64)) * res + f[:, 0].astype(np.int64)
 e = sh[:, 10].astype(np.int64)
-ok = (f >= 0).all(axis=1) & (f < res).all(axis=1)
-proven = np.zeros(len(sh), bool)
-proven[ok] = ((bits[cell[ok]] >> e[ok]) & 1) != 0
+planar = grid.proven(sh[:, 0:3], e)
+proven = grid.proven(sh[:, 0:3], e, prev_hit, prev_d, prev_u, prev_v)
+inside, cell = grid.cells(sh[:, 0:3])
+mesh_bit = inside & (((grid.mesh[cell] >> np.clip(e, 0, 7)) & 1) != 0) & ~planar
+print(f"proven in planar cells {planar.mean():.4f}; in cells on meshes and in corners {(proven & ~planar).mean():.4f} "
+      f"({(proven & ~planar).sum() / max(1, mesh_bit.sum()):.3f} of the hit points in such cells pass the check)")
 occl = sh[:, 9] >= 0
 print(f"shadow rays {len(sh)}, proven {proven.mean():.3f}, occluded {occl.mean():.3f}, proven&occluded {int((proven & occl).sum())}")
 # classify the origin: sphere / big triangle (wall) / small triangle (mesh)
