@@ -2,10 +2,12 @@
 different shape kinds, random cameras) through the HIP path with every exact shortcut on (light-shaft grid, leaf guards, pair nodes,
 collapse, camera packets) against the oracle, bit for bit; the share of shadow rays the grid proved free is printed per scene.
 
-    python tools/soak_random_scenes.py [first_seed] [count] [--device-tree] [--clusters]
+    python tools/soak_random_scenes.py [first_seed] [count] [--device-tree] [--clusters | --smooth]
 
 --clusters: tests/scenes.py random_cluster_scene instead of random_scene (hundreds of small spheres of all materials, small triangles,
 three lights: the class of scene in which round 5's sphere guards were wrong).
+--smooth: tests/scenes.py smooth_mesh_scene (tessellated smooth bodies in a box, one to three lights: what the light-shaft grid's cells on
+meshes and in corners are for; the share of proven rays is high here).
 --device-tree: every scene a second time on the tree hj_build_bvh_device builds for it (Morton clusters, SAH re-split, host top, the
 ray vote of kernels/hj_vote.h on the device), which must be a valid tree the oracle and the HIP path walk to the same bits.
 """
@@ -19,6 +21,7 @@ from oracle import hj_oracle as O
 
 device_tree = "--device-tree" in sys.argv
 clusters = "--clusters" in sys.argv
+smooth = "--smooth" in sys.argv
 scale = float(os.environ.get("SOAK_SCALE", "1"))              # with --clusters: the scene magnified (the reference's epsilons are not)
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 first = int(argv[0]) if len(argv) > 0 else 100
@@ -27,7 +30,7 @@ r = device.Renderer(0)
 W, H = 160, 96
 bad_total = proven = shadow = 0
 for seed in range(first, first + count):
-    cs = scenes.random_cluster_scene(seed, scale=scale) if clusters else scenes.random_scene(seed)
+    cs = scenes.smooth_mesh_scene(seed) if smooth else scenes.random_cluster_scene(seed, scale=scale) if clusters else scenes.random_scene(seed)
     blocks = host.make_blocks(W, H, 3, seed)
     want, ctr, _ = O.render_blocks(cs, blocks, W, H)
     r.upload_scene(cs); r.create_framebuffer(W, H)
