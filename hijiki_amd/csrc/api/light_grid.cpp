@@ -513,10 +513,9 @@ bool build_light_grid(const hj_scene_desc* s, uint32_t res, LightGrid& out) {
     for (size_t i = a; i < b; i++) {
       flat[i].pl = planes[i];
       flat[i].poly.n = g.polygon(i, flat[i].poly.v);
-      // (the shade stage evaluates n.(p - a) in float: 4 ulp of the shape's diameter have to fit between its bound and sigma)
-      double diam = 0;
-      for (int c = 1; c < flat[i].poly.n; c++) { double d2 = 0; for (int k = 0; k < 3; k++) d2 += (flat[i].poly.v[c][k] - flat[i].poly.v[0][k]) * (flat[i].poly.v[c][k] - flat[i].poly.v[0][k]); diam = std::max(diam, std::sqrt(d2)); }
-      flat_ok[i] = tame(i) && flat[i].poly.n >= 3 && 4.0 * kUlp * diam <= kSigma - (double)hj::kLightGridSlide ? 1 : 0;
+      // (the shade stage evaluates n.(p - a) in float and adds what that can lose - 5 ulp of |p - a| - before it divides by |cos(d, n)|:
+      // far from a on a wide shape only steep hits pass, whatever the shape)
+      flat_ok[i] = tame(i) && flat[i].poly.n >= 3 ? 1 : 0;
     }
   });
   auto cell_range = [&](const Box& b, int lo[3], int hi[3]) {

@@ -114,8 +114,10 @@ HJ_DEV bool hit_point_on_its_shape(const DeviceScene& sc, uint32_t id, v3 p, v3 
   const uint32_t cells_bytes = (res * res * res * (uint32_t)sizeof(uint16_t) + 15u) & ~15u;
   const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.light_grid) + cells_bytes) + 2u * (id >= sc.ns ? id - sc.ns : 0u);
   const float4 r0 = rec[0], r1 = rec[1];                                         // n, delta; a, kind
-  const v3 n = xyz(r0);
-  const float dn = dot3(rd, n), dd = dot3(rd, rd), f = dot3(n, p - xyz(r1));
+  const v3 n = xyz(r0), pa = p - xyz(r1);
+  // |n.(p - a)| and what its float evaluation can lose: 5 ulp of |p - a| (the difference, three products, two sums, n's own rounding)
+  const float f = __builtin_fabsf(dot3(n, pa)) + kLightGridUlp5 * ((__builtin_fabsf(pa.x) + __builtin_fabsf(pa.y)) + __builtin_fabsf(pa.z));
+  const float dn = dot3(rd, n), dd = dot3(rd, rd);
   const float third = (r1.w != 0.0f) ? f_min(1.0f - hu, 1.0f - hv) : (1.0f - hu) - hv;
   const float inside = f_min(f_min(hu, hv), third);
   // (every comparison is false for a NaN and for the all-zero record of a shape nothing is claimed about)

@@ -417,7 +417,7 @@ int hj_debug_light_grid(const hj_scene_desc* scene, uint32_t res, uint8_t* bits,
  *   point of the cell (all shapes of the cell in one plane); mesh (res^3 bytes): bits of cells on meshes and in corners, which hold
  *   for a hit point that lies on its shape - a grazing hit leaves the reference's hit point off it, so the shade stage checks
  *   (DESIGN.md section 4): with recs, 8 floats per quad and triangle (shape index - num_spheres) = unit normal n, margin delta;
- *   vertex a, 0 (triangle) / 1 (quad), and limits = {sin_in, slide}: |d.n| >= sin_in |d|, |n.(p - a)| |d| <= slide |d.n|,
+ *   vertex a, 0 (triangle) / 1 (quad), and limits = {sin_in, slide}: |d.n| >= sin_in |d|, (|n.(p - a)| + 3e-7 |p - a|_1) |d| <= slide |d.n|,
  *   min(u, v, 1 - u - v) >= delta (a quad: u, v, 1 - u, 1 - v) for the ray (o, d) that hit and its (t, u, v).
  *   hj_debug_light_grid's bits = planar | mesh.  Any output may be NULL. */
 int hj_debug_light_grid_planes(const hj_scene_desc* scene, uint32_t res, uint8_t* planar, uint8_t* mesh, float* recs, float limits[2],

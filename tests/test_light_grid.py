@@ -65,7 +65,10 @@ class Grid:
         # kernels/hj_num.h dot3 = fmaf(z, z', fmaf(y, y', x x')): a float32 product is exact in float64, so is the sum before its one rounding
         fma = lambda x, y, z: (x.astype(np.float64) * y.astype(np.float64) + z.astype(np.float64)).astype(np.float32)
         dot = lambda x, y: fma(x[:, 2], y[:, 2], fma(x[:, 1], y[:, 1], (x[:, 0] * y[:, 0]).astype(np.float32)))
-        dn, dd, f = dot(d, n), dot(d, d), dot(n, (p - a).astype(np.float32))
+        pa = (p - a).astype(np.float32)
+        l1 = ((np.abs(pa[:, 0]) + np.abs(pa[:, 1])).astype(np.float32) + np.abs(pa[:, 2])).astype(np.float32)
+        f = (np.abs(dot(n, pa)) + (np.float32(3e-7) * l1).astype(np.float32)).astype(np.float32)
+        dn, dd = dot(d, n), dot(d, d)
         one = np.float32(1)
         third = np.where(quad, np.minimum(one - u, one - v), (one - u) - v).astype(np.float32)
         inside = np.minimum(np.minimum(u, v), third)
