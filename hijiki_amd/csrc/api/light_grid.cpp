@@ -10,8 +10,9 @@
 //
 // A bit is set when all of this holds (scale = extent of the scene incl. the camera; tol_p = 2e-6 scale bounds the distance
 // of a computed hit point from its shape's plane, tol_s = 2e-7 scale is "coplanar", m = 1e-4 max(1, scale) pads every box):
-//   1. every shape whose padded bounding box overlaps the padded cell is a triangle or quad, and all of them lie in ONE
-//      plane P (every vertex within tol_s): a hit point p in the cell lies on one of them, i.e. within tol_p of P;
+//   1. every shape whose padded bounding box overlaps the padded cell is a triangle or quad whose float test is well conditioned
+//      (cond <= 2, "tame shapes" below: a needle triangle reports hits of itself), and all of them lie in ONE plane P (every
+//      vertex within tol_s): a hit point p in the cell lies on one of them, i.e. within 2 tol_p of P;
 //   2. emitter e is a triangle or quad (plane Q) and all of it lies on one side of P at an angle: for every point y of its
 //      padded box, |dist(y, P)| - tol_p >= 0.25 |y - x| for every x of the padded cell.  A ray leaving P that steeply is more
 //      than tol_s away from P from t = 1e-4 on (tMin of a shadow ray is 2e-4, scene.glsl:85), so no shape coplanar with P
@@ -23,6 +24,8 @@
 //      extruded 2-D hulls of their projections (every facet normal of the hull is perpendicular to an axis), so a box is
 //      outside it as soon as one projection separates them: by the union rectangle or by one of the four lines through
 //      corresponding corners.  The test errs only towards "touches".
+// Cells that hold several planes - corners, the facets of a mesh - are proven by bundle proofs (further down), for hit points the
+// shade stage has checked against their shape: a second byte per cell.
 // The leaves are enumerated through the uploaded skip-link array itself, with subtree bounds recomputed from the shapes
 // (the array's own boxes are not trusted: tests upload trees with wrong boxes): every leaf whose bounds touch the shaft is
 // looked at, in any well- or ill-formed array whose exits point forward.  Shapes the array does not hold cannot be hit.
